@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""Headline benchmark: examples/sec of one forward+backward pass (loss -> gradient
+of every parameter, optimizer step excluded) on synthetic Criteo-shaped batches.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload deepfm|xdeepfm|dcn]
+
+N = 1 runs in this process; N > 1 is launched by the driver as
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (one rank
+per GPU, RCCL), the embedding table row-sharded over the ranks (recman_amd/dist.py),
+per-GPU batch fixed (weak scaling).  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json `configs`), seed 2019, dropout keep 1,
+embedding_l2_reg 0, weights N(0, 0.01), indices uniform over each field's vocabulary:
+  deepfm  (default) configs[1]: 26 sparse x 1,000,001 rows + 13 dense, D=16, MLP (32,32) relu, B=65536
+  xdeepfm           configs[2]: same inputs, CIN [128,128] leaky_relu, MLP (32,32) leaky_relu
+  dcn               configs[3]: 6 vector cross layers + MLP [400,400] relu, B=131072
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    "deepfm": dict(model="deepfm", B=65536, D=16, F=26, V=1_000_001, Dn=13,
+                   hp=dict(deep_hidden_units=(32, 32), deep_activation="relu")),
+    "xdeepfm": dict(model="xdeepfm", B=65536, D=16, F=26, V=1_000_001, Dn=13,
+                    hp=dict(deep_hidden_units=(32, 32), deep_activation="leaky_relu",
+                            cin_cross_layer_units=(128, 128), cin_activation="leaky_relu")),
+    "dcn": dict(model="dcn", B=131072, D=16, F=26, V=1_000_001, Dn=13,
+                hp=dict(deep_hidden_units=(400, 400), deep_activation="relu", cross_layer_num=6)),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="deepfm", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (tests)")
+    ap.add_argument("--vocab", type=int, default=0, help="override rows per field (tests)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent for indices (0 = uniform)")
+    return ap.parse_args()
+
+
+def synth_inputs(w, B, V, device, seed, zipf=0.0):
+    g = torch.Generator(device=device).manual_seed(seed)
+    if zipf > 0:
+        # inverse-CDF sampling of a truncated Zipf(s) over [1, V]; slot 0 stays the null row
+        u = torch.rand(B, w["F"], generator=g, device=device, dtype=torch.float64)
+        s = zipf
+        idx = ((u * (float(V) ** (1 - s) - 1) + 1) ** (1 / (1 - s))).long().clamp_(1, V - 1)
+    else:
+        idx = torch.randint(0, V, (B, w["F"]), generator=g, device=device, dtype=torch.int64)
+    dense = torch.randn(B, w["Dn"], generator=g, device=device, dtype=torch.float32)
+    y = (torch.rand(B, generator=g, device=device) < 0.25).long()
+    return idx, dense, y
+
+
+def init_engine(engine, seed):
+    """weights ~ N(0, 0.01) written in place (tables in chunks: 1.66 GB at config 2)."""
+    g = torch.Generator(device=engine.device).manual_seed(seed)
+    seen = set()
+    for t in [engine.table, engine.bias_table, engine.linear_w] + list(engine.params.values()):
+        if t is None or t.data_ptr() in seen or t._base is not None and t._base.data_ptr() in seen:
+            continue
+        base = t if t._base is None else t._base
+        if base.data_ptr() in seen:
+            continue
+        seen.add(base.data_ptr())
+        flat = base.view(-1)
+        for s in range(0, flat.numel(), 1 << 26):
+            e = min(flat.numel(), s + (1 << 26))
+            flat[s:e] = torch.randn(e - s, generator=g, device=engine.device) * 0.01
+
+
+def algorithmic_bytes_embed_fwd(B, F, D, Dn, fm, lin):
+    """SURVEY.md section 8d, per launch of rm_embed_fwd: idx + gathered rows (+ bias
+    and linear entries) read, E (+ S, logits) written."""
+    per = F * 8 + F * 4 * D + F * 4 * D  # idx, rows read, E written
+    if fm:
+        per += F * 4 + 4 * D + 4  # bias entries, S, fm_logit
+    if lin:
+        per += F * 4 + Dn * 4 + 4
+    return B * per
+
+
+def cpu_baseline(w, hp, idx, dense, y, engine, sample, iters=5, warm=2):
+    """The CPU PyTorch restatement (oracle/, kind "port") on the host cores, same
+    inputs and weights, fwd+bwd, sparse embedding gradients (what TF's IndexedSlices
+    are with embedding_l2_reg = 0).  Bounded sample of the workload's batch."""
+    from oracle import th_layers as T
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    spec = T.Spec(engine.spec.sparse_names, engine.spec.feat_sizes, engine.spec.dense_names)
+    p = {k: v.detach().cpu() for k, v in engine.state_dict().items()}
+    idx_c, dense_c, y_c = idx[:sample].cpu(), dense[:sample].cpu(), y[:sample].cpu()
+    hp_c = dict(hp)
+    chunk = 4096 if w["model"] == "xdeepfm" else sample
+
+    def step():
+        leaves = {k: v.requires_grad_(True) for k, v in p.items()}
+        for v in leaves.values():
+            v.grad = None
+        total = 0.0
+        logits = []
+        for s in range(0, sample, chunk):
+            sl = slice(s, min(sample, s + chunk))
+            loss, logit, _ = T.model_loss(w["model"], leaves, spec, idx_c[sl], dense_c[sl], y_c[sl],
+                                          hp_c, sparse_grad=True)
+            (loss * (sl.stop - sl.start) / sample).backward()
+            total += float(loss) * (sl.stop - sl.start) / sample
+            logits.append(logit.detach().reshape(-1))
+        return total, torch.cat(logits)
+
+    for _ in range(warm):
+        step()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        _, logit = step()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return dict(value=sample / med, unit="examples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{sample} examples of the same batch, {iters} timed fwd+bwd passes (median), "
+                       f"oracle/th_layers.py, sparse embedding grads"
+                       + (f", CIN in chunks of {chunk}" if chunk != sample else "")), logit
+
+
+def main():
+    a = parse()
+    w = dict(WORKLOADS[a.workload])
+    B = a.batch or w["B"]
+    V = a.vocab or w["V"]
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    from recman_amd import engine as eng
+
+    spec = eng.FeatureSpec([f"C{i + 1}" for i in range(w["F"])], [V] * w["F"],
+                           [f"I{j + 1}" for j in range(w["Dn"])])
+    hp = dict(w["hp"], embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=0.0, cin_l2_reg=0.0,
+              cross_layer_l2_reg=0.0)
+    if world > 1:
+        from recman_amd import dist as rdist
+
+        engine = rdist.make_sharded_engine(w["model"], spec, w["D"], hp, dev, rank, world)
+    else:
+        engine = eng.ENGINES[w["model"]](spec, w["D"], hp, device=dev)
+    init_engine(engine, 2019)
+    idx, dense, y = synth_inputs(w, B, V, dev, 2019 + rank, a.zipf)
+
+    def step():
+        return engine.fwd_bwd(idx, dense, y)
+
+    # ---- optional hipGraph capture of the whole step (launch-bound otherwise) ----
+    use_graph = not a.no_graph and world == 1
+    graph = None
+    step()
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as e:  # capture is an optimisation, never a requirement
+            print(f"[bench] hipGraph capture failed, running eager: {e}", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms = elapsed / a.steps * 1e3
+    value = world * B * a.steps / elapsed
+
+    # ---- roofline of the dominant hand-written kernel, HIP events on its stream ----
+    roof = engine.roofline_probe(idx, dense, y, iters=max(10, min(a.steps, 50)))
+
+    out = {
+        "metric": "examples/sec fwd+bwd, Criteo-shape batch %d" % B,
+        "value": round(value, 1), "unit": "examples/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": a.workload, "model": w["model"], "per_gpu_batch": B,
+                   "global_batch": B * world, "sparse_fields": w["F"], "rows_per_field": V,
+                   "dense_fields": w["Dn"], "emb_dim": w["D"], "hp": {k: v for k, v in w["hp"].items()},
+                   "indices": "uniform" if a.zipf == 0 else f"zipf({a.zipf})",
+                   "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
+                   "hipgraph": graph is not None,
+                   "table": "replicated" if world == 1 else f"row-sharded mod {world}"},
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        sample = min(B, 16384 if w["model"] == "xdeepfm" else B)
+        base, logit_cpu = cpu_baseline(w, hp, idx, dense, y, engine, sample)
+        out["cpu_baseline"] = base
+        engine.forward(idx[:sample].contiguous(), dense[:sample].contiguous(), training=True)
+        err = float((engine.logit[:sample].cpu() - logit_cpu).abs().max())
+        out["parity_check"] = {"max_abs_logit_err_vs_cpu_oracle": err, "examples": sample,
+                               "tolerance": 1e-5}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

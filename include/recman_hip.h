@@ -1,0 +1,183 @@
+/*
+ * recman_hip.h - C ABI of librecman_hip.so: the MI355X (gfx950) kernels behind
+ * recman's CTR forward+backward path (DeepFM / DCN / xDeepFM).
+ *
+ * The reference (dev-wei/recman) has no native code, no operator registry and no
+ * FFI: its seam is the Python layer-callable protocol `Layer(variables, ...)(x)`
+ * of recman/tf/core/layers.py, composed by xDeepFM._out (recman/tf/core/xDeepFM.py:47-104),
+ * DeepFM._init_graph (DeepFM.py:107-163) and DCN._init_graph (DCN.py:99-149).
+ * Each entry point below cites the span of that Python it replaces.  The Python
+ * host side that binds these (ctypes) is recman_amd/_lib.py; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless named host_*; the caller owns all
+ *    buffers, the library allocates nothing and keeps no global mutable state;
+ *  - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream) and return immediately: asynchronous, graph-capturable;
+ *  - return value: RM_OK (0) or a negative RM_E* code; rm_last_error() gives a
+ *    thread-local message for the last failing call.  No exceptions cross the ABI;
+ *  - floats are IEEE fp32, indices are int64 (recman/tf/inputs.py:158,199);
+ *  - layouts are row-major; E is [B, F, D] exactly as tf.concat(axis=1) of the
+ *    per-field [B,1,D] lookups produces it (layers.py:248-253).
+ */
+#ifndef RECMAN_HIP_H
+#define RECMAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_OK 0
+#define RM_EINVAL (-1)  /* bad argument (null pointer, size, alignment)      */
+#define RM_ELAUNCH (-2) /* hipLaunch / runtime error, see rm_last_error()    */
+#define RM_EUNSUPPORTED (-3)
+
+/* activation ids (layers.py:601,738; tf.nn.leaky_relu alpha = 0.2) */
+#define RM_ACT_IDENTITY 0
+#define RM_ACT_RELU 1
+#define RM_ACT_LEAKY_RELU 2
+
+typedef void *rm_stream_t;
+
+int rm_version(void);
+const char *rm_last_error(void);
+/* number of compute units of the current device (grid sizing for callers) */
+int rm_device_cus(void);
+
+/* ------------------------------------------------------------------------
+ * Embedding gather (+ FM, + sparse/dense linear term), forward.
+ * Replaces: FeatEmbedding.__call__ SparseFeat branch + FeatEmbeddingLayer.__call__
+ *   (layers.py:117-128, 238-261), FMLayer.__call__ (layers.py:457-478) and
+ *   LinearCombiner/LinearLayer resp. SparseLinearCombiner/SparseLinearLayer
+ *   (layers.py:281-347, 368-439; one_hot utils.py:51-67) in gather form.
+ *
+ *   idx        [B,F]  per-field row index (0 = null/unknown, inputs.py:166)
+ *   table      [R,D]  all field tables concatenated, row r at table + r*table_ld
+ *                     (table_ld >= D floats); field f owns rows
+ *                     field_off[f] .. field_off[f]+V_f-1
+ *   bias_table [R]    first-order FM bias tables, same row numbering, element r at
+ *                     bias_table + r*bias_ld, or NULL
+ *   lin_w             sparse part of linear_w (one one-hot block per feature), or
+ *                     NULL; element (f, i) at lin_w + (lin_off[f]+i)*lin_ld.
+ *                     (the *_ld strides let bias and linear weight live inside the
+ *                     embedding row - one HBM sector per lookup instead of three)
+ *   lin_w_dense [Dn]  linear weights of the dense columns, lin_w0 [1] the bias
+ *   dense      [B,Dn] scaled dense features or NULL (Dn = 0)
+ *   mask_b [B,F], mask_e [B,F,D]: FMLayer dropout multipliers (0 or 1/keep,
+ *                     layers.py:461,466) or NULL = keep-probability 1
+ * outputs (each may be NULL = not wanted):
+ *   E        [B,F,D]  gathered rows (the un-dropped embeddings the DNN/CIN/cross use)
+ *   fm_sum   [B,D]    S = sum_f mask_e*E  (saved for the backward)
+ *   fm_logit [B]      sum_f mask_b*bias + 0.5*sum_k(S_k^2 - sum_f (mask_e*E)_fk^2)
+ *   lin_logit[B]      sum_f lin_w[lin_off[f]+idx] + dense . lin_w[dense block] + lin_w0
+ * D must be a multiple of 4 and <= 256; table/E 16-byte aligned.
+ */
+int rm_embed_fwd(const int64_t *idx, const float *table, int64_t table_ld,
+                 const int64_t *field_off, const float *bias_table, int64_t bias_ld,
+                 const float *lin_w, int64_t lin_ld, const int64_t *lin_off,
+                 const float *lin_w_dense, const float *lin_w0, const float *dense, int Dn,
+                 const float *mask_b, const float *mask_e, int64_t B, int F, int D,
+                 float *E, float *fm_sum, float *fm_logit, float *lin_logit,
+                 rm_stream_t stream);
+
+/* Backward of the embedding + FM block w.r.t. the gathered rows: the IndexedSlices
+ * values TF's autodiff produces for tf.nn.embedding_lookup (one row per (b,f)
+ * occurrence, duplicates NOT merged; the indices are `idx` itself).
+ *   d_rows[b,f,:] = dE_up[b,f,:] + g_fm[b] * mask_e[b,f,:] * (S[b,:] - mask_e*E[b,f,:])
+ *   d_bias[b,f]   = g_fm[b] * mask_b[b,f]
+ * dE_up (upstream gradient from DNN / CIN / cross w.r.t. E) may be NULL; g_fm may
+ * be NULL (no FM term: d_rows = dE_up).  d_rows may alias dE_up.  d_bias may be NULL.
+ */
+int rm_embed_bwd(const float *E, const float *fm_sum, const float *dE_up, const float *g_fm,
+                 const float *mask_b, const float *mask_e, int64_t B, int F, int D,
+                 float *d_rows, float *d_bias, rm_stream_t stream);
+
+/* Scatter-add of occurrence rows into a dense table gradient (what TF's
+ * IndexedSlices densify to once the l2 term touches every row, layers.py:188-193):
+ *   d_table[(field_off[f]+idx[b,f])*ld + k] += rows[b,f,k], k < width   (float atomics)
+ * `width` = D for embedding tables, 1 for bias tables / linear weights (then
+ * field_off = lin_off).  When g_row != NULL, rows is ignored and the added value
+ * is g_row[b] (width must be 1): the D=1 linear / bias gradient. */
+int rm_scatter_add_rows(const int64_t *idx, const int64_t *field_off, const float *rows,
+                        const float *g_row, int64_t B, int F, int width, int64_t ld,
+                        float *d_table, rm_stream_t stream);
+
+/* Dense part of the linear-layer backward: d_w_dense[j] = sum_b g[b]*dense[b,j],
+ * d_w0 = sum_b g[b].  Deterministic two-stage reduction; workspace >= 256*(Dn+1) floats. */
+int rm_linear_dense_bwd(const float *g, const float *dense, int64_t B, int Dn,
+                        float *d_w_dense, float *d_w0, float *workspace, rm_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * PredictionLayer + create_loss, forward and backward in one pass.
+ * Replaces: tf.add_n of the branch logits (xDeepFM.py:99-102, DeepFM.py:149-158,
+ *   DCN.py:140-144), PredictionLayer.__call__ (layers.py:796-808), create_loss
+ *   (utils.py:192-198: Keras binary_crossentropy on probabilities, clip 1e-7) and
+ *   their gradient.
+ *   logit_a..d [B]  branch logits (NULL = absent); coef_* multiply them (DCN's
+ *                   double-counted dnn logit uses coef 2 under strict_reference)
+ *   y   [B] int64 labels (classification) or NULL with y_f [B] float (regression)
+ *   task 0 = classification (sigmoid + BCE), 1 = regression (MSE)
+ * outputs: logit [B] (sum), pred [B], dlogit [B] = d(mean loss)/d(logit) (NULL ok),
+ *   loss [1] (NULL ok; needs workspace >= 1024 floats).
+ */
+int rm_logit_loss(const float *logit_a, float coef_a, const float *logit_b, float coef_b,
+                  const float *logit_c, float coef_c, const float *logit_d, float coef_d,
+                  const int64_t *y, const float *y_f, int task, int64_t B, float *logit,
+                  float *pred, float *dlogit, float *loss, float *workspace,
+                  rm_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * CrossNet (DCN v1, vector form), all L layers fused.
+ * Replaces: CrossNet(layer_num, l2_reg)(dnn_input) -> logit [B,1] used at
+ *   DCN.py:134-137 - the class itself is ABSENT from the reference
+ *   (DCN.py:7 comments the import out); arithmetic per arXiv 1708.05123 eq. (3):
+ *   x_{l+1} = x0 * (x_l . w_l) + b_l + x_l,  logit = x_L . w_out
+ * x0 = [xe | xd]: xe [B,FD] is the flattened embedding block E, xd [B,Dn] the dense
+ * columns (DNNCombiner, layers.py:494-501) - never concatenated in memory.
+ *   w, b [L,d], w_out [d], d = FD + Dn, FD % 4 == 0, d <= 512, L <= 8.
+ */
+int rm_cross_fwd(const float *xe, const float *xd, int FD, int Dn, const float *w,
+                 const float *b, const float *w_out, int L, int64_t B, float *logit,
+                 float *s_out /* [B,L] layer scalars x_l.w_l, saved for the backward; NULL ok */,
+                 rm_stream_t stream);
+
+/* Backward: given g [B] = dLoss/dlogit and s [B,L] from the forward,
+ *   d_xe [B,FD] (+= dx_in_e when given), d_xd [B,Dn] (+= dx_in_d when given):
+ *       gradient w.r.t. x0, optionally summed with another branch's gradient
+ *   coef [B, 2L+2]: per-example scalars from which the parameter gradients follow
+ *       by one skinny GEMM (see recman_amd/engine.py and DESIGN.md):
+ *       columns 0..L-1 = t_l*c_l, L = g*c_L, L+1..2L = t_l, 2L+1 = g
+ */
+int rm_cross_bwd(const float *xe, const float *xd, int FD, int Dn, const float *w,
+                 const float *b, const float *w_out, int L, int64_t B, const float *g,
+                 const float *s, const float *dx_in_e, const float *dx_in_d, float *d_xe,
+                 float *d_xd, float *coef, rm_stream_t stream);
+
+/* Finishes the CrossNet parameter gradients from P = x0^T @ coef[:, :L+1] ([d, L+1],
+ * row-major) and colsum = sum_b coef[:, L+1:] ([L+1]):
+ *   d_w[l] = P[:,l] + T_l * Bp_l,  d_w_out = P[:,L] + G * Bp_L,
+ *   d_b[l] = G * w_out + sum_{j>l} T_j * w_j,   Bp_l = sum_{j<l} b_j */
+int rm_cross_param_grads(const float *P, const float *colsum, const float *w, const float *b,
+                         const float *w_out, int L, int d, float *d_w, float *d_b,
+                         float *d_w_out, rm_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Row helpers (owner-side gather and re-ordering for the row-sharded table).
+ */
+/* rows_out[i,:] = table[rows[i],:] for i < n (owner-side gather of the requested
+ * local rows; width floats per row, width % 4 == 0). */
+int rm_gather_rows(const float *table, const int64_t *rows, int64_t n, int width,
+                   float *rows_out, rm_stream_t stream);
+
+/* dst[i,:] = src[slot[i],:] (un-route: received rows back into (b,f) order) when
+ * inverse == 0;  dst[slot[i],:] = src[i,:] when inverse != 0 (route gradient rows). */
+int rm_permute_rows(const float *src, const int64_t *slot, int64_t n, int width, int inverse,
+                    float *dst, rm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECMAN_HIP_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of librecman_hip.so (the C ABI declared in include/recman_hip.h).
+
+There is NO fallback: if the library is missing or a symbol does not resolve the
+import raises, and every call that returns a non-zero code raises RecmanHipError
+with the library's thread-local message.  The product path never computes on the CPU.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librecman_hip.so")
+
+
+class RecmanHipError(RuntimeError):
+    pass
+
+
+P = c_void_p  # every device pointer and the stream travel as void*
+I64 = c_int64
+
+# name -> argtypes, in the order of include/recman_hip.h
+SIGNATURES = {
+    "rm_version": [],
+    "rm_device_cus": [],
+    "rm_embed_fwd": [P, P, I64, P, P, I64, P, I64, P, P, P, P, c_int, P, P, I64, c_int, c_int,
+                     P, P, P, P, P],
+    "rm_embed_bwd": [P, P, P, P, P, P, I64, c_int, c_int, P, P, P],
+    "rm_scatter_add_rows": [P, P, P, P, I64, c_int, c_int, I64, P, P],
+    "rm_linear_dense_bwd": [P, P, I64, c_int, P, P, P, P],
+    "rm_logit_loss": [P, c_float, P, c_float, P, c_float, P, c_float, P, P, c_int, I64, P, P, P,
+                      P, P, P],
+    "rm_cross_fwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P],
+    "rm_cross_bwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P, P, P, P, P, P],
+    "rm_cross_param_grads": [P, P, P, P, P, c_int, c_int, P, P, P, P],
+    "rm_gather_rows": [P, P, I64, c_int, P, P],
+    "rm_permute_rows": [P, P, I64, c_int, c_int, P, P],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RecmanHipError(
+            f"{LIB_PATH} not found: build it with `python -m recman_amd.build` "
+            "(hipcc --offload-arch=gfx950). recman_amd has no CPU fallback.")
+    # torch first: it bundles its own libamdhip64; loading ours before it would bring
+    # in a second HIP runtime (the system one) that does not share torch's context
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.rm_last_error.restype = c_char_p
+    lib.rm_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def call(name, *args):
+    """Calls an int-returning entry point; raises RecmanHipError on a non-zero code."""
+    l = lib()
+    rc = getattr(l, name)(*args)
+    if rc != 0:
+        msg = l.rm_last_error().decode("utf-8", "replace")
+        raise RecmanHipError(f"{name} failed ({rc}): {msg}")
+    return rc

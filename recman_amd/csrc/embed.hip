@@ -1,0 +1,393 @@
+// Embedding gather + FM + linear term (forward), their backward, and the row
+// scatter/gather helpers.  gfx950 only: 64-lane waves, 16-byte lane accesses.
+//
+// Mapping (forward): a group of G = D/4 lanes owns ONE example and walks its F
+// fields; each lane keeps a float4 slice of S = sum_f E_f and a scalar partial of
+// sum_f |E_f|^2, so the FM reduction over fields needs no cross-lane traffic and
+// only log2(G) shuffles at the end.  A wave therefore has 64/G examples in flight
+// and issues UNR independent 16-byte row gathers per lane before it consumes any
+// (memory-level parallelism is what a random 64-byte-row gather lives on).
+#include "rm_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kUnroll = 8;
+
+template <int G, bool MASK>
+__global__ __launch_bounds__(kBlock) void embed_fwd_kernel(
+    const int64_t *__restrict__ idx, const float *__restrict__ table, int64_t table_ld,
+    const int64_t *__restrict__ field_off, const float *__restrict__ bias_table, int64_t bias_ld,
+    const float *__restrict__ lin_w, int64_t lin_ld, const int64_t *__restrict__ lin_off,
+    const float *__restrict__ lin_w_dense, const float *__restrict__ lin_w0,
+    const float *__restrict__ dense, int Dn, const float *__restrict__ mask_b,
+    const float *__restrict__ mask_e, int64_t B, int F, float *__restrict__ E,
+    float *__restrict__ fm_sum, float *__restrict__ fm_logit, float *__restrict__ lin_logit) {
+  constexpr int EPW = 64 / G;  // examples per wave
+  constexpr int D = 4 * G;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % G;
+  const int ex = lane / G;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+  const bool want_fm = fm_logit != nullptr || fm_sum != nullptr;
+
+  for (int64_t b0 = wave * EPW; b0 < B; b0 += nwaves * EPW) {
+    const int64_t b = b0 + ex;
+    const bool valid = b < B;
+    const int64_t bb = valid ? b : B - 1;  // clamp: keep every lane's loads in bounds
+    const int64_t *ip = idx + bb * F;
+    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ss = 0.f, y1 = 0.f, lin = 0.f;
+
+    for (int f0 = 0; f0 < F; f0 += kUnroll) {
+      int64_t r[kUnroll];
+      float4 v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int f = f0 + u < F ? f0 + u : F - 1;
+        r[u] = ip[f];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int f = f0 + u < F ? f0 + u : F - 1;
+        const int64_t row = field_off[f] + r[u];
+        v[u] = *reinterpret_cast<const float4 *>(table + row * table_ld + sub * 4);
+      }
+      if (sub == 0) {
+        if (bias_table != nullptr) {
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            const int f = f0 + u;
+            if (f < F) {
+              float bv = bias_table[(field_off[f] + r[u]) * bias_ld];
+              if (MASK && mask_b != nullptr) bv *= mask_b[bb * F + f];
+              y1 += bv;
+            }
+          }
+        }
+        if (lin_w != nullptr) {
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            const int f = f0 + u;
+            if (f < F) lin += lin_w[(lin_off[f] + r[u]) * lin_ld];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int f = f0 + u;
+        if (f < F) {
+          if (E != nullptr && valid)
+            *reinterpret_cast<float4 *>(E + (bb * F + f) * D + sub * 4) = v[u];
+          float4 m = v[u];
+          if (MASK && mask_e != nullptr) {
+            const float4 mk =
+                *reinterpret_cast<const float4 *>(mask_e + (bb * F + f) * D + sub * 4);
+            m.x *= mk.x; m.y *= mk.y; m.z *= mk.z; m.w *= mk.w;
+          }
+          S.x += m.x; S.y += m.y; S.z += m.z; S.w += m.w;
+          ss += m.x * m.x + m.y * m.y + m.z * m.z + m.w * m.w;
+        }
+      }
+    }
+
+    if (want_fm) {
+      if (fm_sum != nullptr && valid)
+        *reinterpret_cast<float4 *>(fm_sum + bb * D + sub * 4) = S;
+      float part = S.x * S.x + S.y * S.y + S.z * S.z + S.w * S.w - ss;
+      part = rm_group_sum<G>(part);
+      if (fm_logit != nullptr && valid && sub == 0) fm_logit[bb] = y1 + 0.5f * part;
+    }
+    if (lin_logit != nullptr && valid && sub == 0) {
+      if (dense != nullptr) {
+        for (int j = 0; j < Dn; ++j) lin += dense[bb * Dn + j] * lin_w_dense[j];
+      }
+      if (lin_w0 != nullptr) lin += lin_w0[0];
+      lin_logit[bb] = lin;
+    }
+  }
+}
+
+// Backward: purely elementwise over the [B, F*D/4] float4 grid once S is saved.
+template <bool MASK>
+__global__ __launch_bounds__(kBlock) void embed_bwd_kernel(
+    const float4 *__restrict__ E, const float4 *__restrict__ fm_sum,
+    const float4 *__restrict__ dE_up, const float *__restrict__ g_fm,
+    const float *__restrict__ mask_b, const float4 *__restrict__ mask_e, int64_t B, int F, int G,
+    float4 *__restrict__ d_rows, float *__restrict__ d_bias) {
+  const int64_t per_ex = (int64_t)F * G;
+  const int64_t total = B * per_ex;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / per_ex;
+    const int rem = (int)(t - b * per_ex);
+    const int sub = rem % G;
+    float4 out = dE_up != nullptr ? dE_up[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g_fm != nullptr) {
+      const float g = g_fm[b];
+      float4 e = E[t];
+      const float4 s = fm_sum[b * G + sub];
+      if (MASK && mask_e != nullptr) {
+        const float4 mk = mask_e[t];
+        e.x *= mk.x; e.y *= mk.y; e.z *= mk.z; e.w *= mk.w;
+        out.x += g * mk.x * (s.x - e.x);
+        out.y += g * mk.y * (s.y - e.y);
+        out.z += g * mk.z * (s.z - e.z);
+        out.w += g * mk.w * (s.w - e.w);
+      } else {
+        out.x += g * (s.x - e.x);
+        out.y += g * (s.y - e.y);
+        out.z += g * (s.z - e.z);
+        out.w += g * (s.w - e.w);
+      }
+      if (d_bias != nullptr && sub == 0) {
+        const int f = rem / G;
+        float gb = g;
+        if (MASK && mask_b != nullptr) gb *= mask_b[b * F + f];
+        d_bias[b * F + f] = gb;
+      }
+    }
+    d_rows[t] = out;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(
+    const int64_t *__restrict__ idx, const int64_t *__restrict__ field_off,
+    const float *__restrict__ rows, const float *__restrict__ g_row, int64_t B, int F, int width,
+    int64_t ld, float *__restrict__ d_table) {
+  const int64_t total = B * F * width;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t occ = t / width;
+    const int k = (int)(t - occ * width);
+    const int f = (int)(occ % F);
+    const int64_t row = field_off[f] + idx[occ];
+    const float v = g_row != nullptr ? g_row[occ / F] : rows[t];
+    atomicAdd(d_table + row * ld + k, v);
+  }
+}
+
+// d_w_dense[j] = sum_b g[b]*dense[b,j]; d_w0 = sum_b g[b].  Stage 1: one partial
+// per block; stage 2 (last launch) sums the partials in block order: deterministic.
+__global__ __launch_bounds__(kBlock) void linear_dense_bwd_stage1(
+    const float *__restrict__ g, const float *__restrict__ dense, int64_t B, int Dn,
+    float *__restrict__ partial) {
+  extern __shared__ float sm[];  // [4 waves][Dn+1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int cols = Dn + 1;
+  for (int j = 0; j < cols; ++j) {
+    float acc = 0.f;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride)
+      acc += j < Dn ? g[b] * dense[b * Dn + j] : g[b];
+    acc = rm_wave_sum(acc);
+    if (lane == 0) sm[wave * cols + j] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < cols) {
+    float acc = 0.f;
+    for (int w = 0; w < kBlock / 64; ++w) acc += sm[w * cols + threadIdx.x];
+    partial[(int64_t)blockIdx.x * cols + threadIdx.x] = acc;
+  }
+}
+
+__global__ void linear_dense_bwd_stage2(const float *__restrict__ partial, int nblk, int Dn,
+                                        float *__restrict__ d_w_dense, float *__restrict__ d_w0) {
+  const int j = threadIdx.x;
+  const int cols = Dn + 1;
+  if (j >= cols) return;
+  float acc = 0.f;
+  for (int i = 0; i < nblk; ++i) acc += partial[(int64_t)i * cols + j];
+  if (j < Dn) {
+    if (d_w_dense != nullptr) d_w_dense[j] = acc;
+  } else if (d_w0 != nullptr) {
+    d_w0[0] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(
+    const float4 *__restrict__ table, const int64_t *__restrict__ rows, int64_t n, int G,
+    float4 *__restrict__ out) {
+  const int64_t total = n * G;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t i = t / G;
+    const int sub = (int)(t - i * G);
+    out[t] = table[rows[i] * G + sub];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void permute_rows_kernel(
+    const float4 *__restrict__ src, const int64_t *__restrict__ slot, int64_t n, int G,
+    int inverse, float4 *__restrict__ dst) {
+  const int64_t total = n * G;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t i = t / G;
+    const int sub = (int)(t - i * G);
+    if (inverse)
+      dst[slot[i] * G + sub] = src[t];
+    else
+      dst[t] = src[slot[i] * G + sub];
+  }
+}
+
+template <int G>
+int launch_embed_fwd(bool mask, dim3 grid, hipStream_t st, const int64_t *idx, const float *table,
+                     int64_t table_ld, const int64_t *field_off, const float *bias_table,
+                     int64_t bias_ld, const float *lin_w, int64_t lin_ld, const int64_t *lin_off,
+                     const float *lin_w_dense, const float *lin_w0, const float *dense, int Dn,
+                     const float *mask_b, const float *mask_e, int64_t B, int F, float *E,
+                     float *fm_sum, float *fm_logit, float *lin_logit) {
+  if (mask)
+    hipLaunchKernelGGL((embed_fwd_kernel<G, true>), grid, dim3(kBlock), 0, st, idx, table,
+                       table_ld, field_off, bias_table, bias_ld, lin_w, lin_ld, lin_off,
+                       lin_w_dense, lin_w0, dense, Dn, mask_b, mask_e, B, F, E, fm_sum, fm_logit,
+                       lin_logit);
+  else
+    hipLaunchKernelGGL((embed_fwd_kernel<G, false>), grid, dim3(kBlock), 0, st, idx, table,
+                       table_ld, field_off, bias_table, bias_ld, lin_w, lin_ld, lin_off,
+                       lin_w_dense, lin_w0, dense, Dn, mask_b, mask_e, B, F, E, fm_sum, fm_logit,
+                       lin_logit);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int rm_embed_fwd(const int64_t *idx, const float *table, int64_t table_ld,
+                            const int64_t *field_off, const float *bias_table, int64_t bias_ld,
+                            const float *lin_w, int64_t lin_ld, const int64_t *lin_off,
+                            const float *lin_w_dense, const float *lin_w0, const float *dense,
+                            int Dn, const float *mask_b, const float *mask_e, int64_t B, int F,
+                            int D, float *E, float *fm_sum, float *fm_logit, float *lin_logit,
+                            rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && F > 0 && D > 0, "rm_embed_fwd: bad sizes B=%lld F=%d D=%d", (long long)B, F, D);
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(idx && table && field_off, "rm_embed_fwd: idx/table/field_off must not be NULL");
+  RM_REQUIRE(D % 4 == 0 && D <= 256 && (64 % (D / 4)) == 0,
+             "rm_embed_fwd: D=%d unsupported (need D in {4,8,16,32,64,128,256})", D);
+  RM_REQUIRE(table_ld >= D && table_ld % 4 == 0 && rm_aligned16(table),
+             "rm_embed_fwd: table must be 16-byte aligned with ld %% 4 == 0 (ld=%lld)", (long long)table_ld);
+  RM_REQUIRE(!E || rm_aligned16(E), "rm_embed_fwd: E must be 16-byte aligned");
+  RM_REQUIRE(!fm_sum || rm_aligned16(fm_sum), "rm_embed_fwd: fm_sum must be 16-byte aligned");
+  RM_REQUIRE(!mask_e || rm_aligned16(mask_e), "rm_embed_fwd: mask_e must be 16-byte aligned");
+  RM_REQUIRE(!lin_w || lin_off, "rm_embed_fwd: lin_w given without lin_off");
+  RM_REQUIRE(!(lin_logit && dense) || lin_w_dense, "rm_embed_fwd: dense given without lin_w_dense");
+  RM_REQUIRE(Dn >= 0, "rm_embed_fwd: Dn < 0");
+  const int G = D / 4;
+  const int epw = 64 / G;
+  const int64_t waves = (B + epw - 1) / epw;
+  dim3 grid(rm_grid_cap((waves + 3) / 4, 256 * 16));
+  hipStream_t st = (hipStream_t)stream;
+  const bool mask = mask_b != nullptr || mask_e != nullptr;
+#define RM_EMBED_CASE(g)                                                                       \
+  case g:                                                                                      \
+    launch_embed_fwd<g>(mask, grid, st, idx, table, table_ld, field_off, bias_table, bias_ld,  \
+                        lin_w, lin_ld, lin_off, lin_w_dense, lin_w0, dense, Dn, mask_b, mask_e, \
+                        B, F, E, fm_sum, fm_logit, lin_logit);                                 \
+    break;
+  switch (G) {
+    RM_EMBED_CASE(1)
+    RM_EMBED_CASE(2)
+    RM_EMBED_CASE(4)
+    RM_EMBED_CASE(8)
+    RM_EMBED_CASE(16)
+    RM_EMBED_CASE(32)
+    RM_EMBED_CASE(64)
+    default:
+      rm_set_error("rm_embed_fwd: D=%d unsupported", D);
+      return RM_EUNSUPPORTED;
+  }
+#undef RM_EMBED_CASE
+  RM_CHECK_LAUNCH("rm_embed_fwd");
+  return RM_OK;
+}
+
+extern "C" int rm_embed_bwd(const float *E, const float *fm_sum, const float *dE_up,
+                            const float *g_fm, const float *mask_b, const float *mask_e, int64_t B,
+                            int F, int D, float *d_rows, float *d_bias, rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && F > 0 && D > 0 && D % 4 == 0, "rm_embed_bwd: bad sizes B=%lld F=%d D=%d",
+             (long long)B, F, D);
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(d_rows && rm_aligned16(d_rows), "rm_embed_bwd: d_rows NULL or unaligned");
+  RM_REQUIRE(dE_up || g_fm, "rm_embed_bwd: neither dE_up nor g_fm given");
+  RM_REQUIRE(!g_fm || (E && fm_sum), "rm_embed_bwd: g_fm needs E and fm_sum");
+  RM_REQUIRE((!E || rm_aligned16(E)) && (!fm_sum || rm_aligned16(fm_sum)) &&
+                 (!dE_up || rm_aligned16(dE_up)) && (!mask_e || rm_aligned16(mask_e)),
+             "rm_embed_bwd: 16-byte alignment required");
+  const int G = D / 4;
+  const int64_t total = B * F * G;
+  dim3 grid(rm_grid_cap((total + kBlock - 1) / kBlock, 256 * 16));
+  hipStream_t st = (hipStream_t)stream;
+  if (mask_b || mask_e)
+    hipLaunchKernelGGL((embed_bwd_kernel<true>), grid, dim3(kBlock), 0, st, (const float4 *)E,
+                       (const float4 *)fm_sum, (const float4 *)dE_up, g_fm, mask_b,
+                       (const float4 *)mask_e, B, F, G, (float4 *)d_rows, d_bias);
+  else
+    hipLaunchKernelGGL((embed_bwd_kernel<false>), grid, dim3(kBlock), 0, st, (const float4 *)E,
+                       (const float4 *)fm_sum, (const float4 *)dE_up, g_fm, mask_b,
+                       (const float4 *)mask_e, B, F, G, (float4 *)d_rows, d_bias);
+  RM_CHECK_LAUNCH("rm_embed_bwd");
+  return RM_OK;
+}
+
+extern "C" int rm_scatter_add_rows(const int64_t *idx, const int64_t *field_off, const float *rows,
+                                   const float *g_row, int64_t B, int F, int width, int64_t ld,
+                                   float *d_table, rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && F > 0 && width > 0 && ld >= width, "rm_scatter_add_rows: bad sizes");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(idx && field_off && d_table && (rows || g_row), "rm_scatter_add_rows: NULL argument");
+  RM_REQUIRE(!g_row || width == 1, "rm_scatter_add_rows: g_row needs width == 1");
+  const int64_t total = B * F * width;
+  dim3 grid(rm_grid_cap((total + kBlock - 1) / kBlock, 256 * 16));
+  hipLaunchKernelGGL(scatter_add_rows_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, idx,
+                     field_off, rows, g_row, B, F, width, ld, d_table);
+  RM_CHECK_LAUNCH("rm_scatter_add_rows");
+  return RM_OK;
+}
+
+extern "C" int rm_linear_dense_bwd(const float *g, const float *dense, int64_t B, int Dn,
+                                   float *d_w_dense, float *d_w0, float *workspace,
+                                   rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && Dn >= 0 && Dn <= 255, "rm_linear_dense_bwd: bad sizes (Dn <= 255)");
+  RM_REQUIRE(g && workspace && (Dn == 0 || dense), "rm_linear_dense_bwd: NULL argument");
+  const int nblk = rm_grid_cap((B + kBlock - 1) / kBlock, 256);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(linear_dense_bwd_stage1, dim3(nblk), dim3(kBlock),
+                     (kBlock / 64) * (Dn + 1) * sizeof(float), st, g, dense, B, Dn, workspace);
+  hipLaunchKernelGGL(linear_dense_bwd_stage2, dim3(1), dim3(256), 0, st, workspace, nblk, Dn,
+                     d_w_dense, d_w0);
+  RM_CHECK_LAUNCH("rm_linear_dense_bwd");
+  return RM_OK;
+}
+
+extern "C" int rm_gather_rows(const float *table, const int64_t *rows, int64_t n, int width,
+                              float *rows_out, rm_stream_t stream) {
+  RM_REQUIRE(n >= 0 && width > 0 && width % 4 == 0, "rm_gather_rows: bad sizes");
+  if (n == 0) return RM_OK;
+  RM_REQUIRE(table && rows && rows_out && rm_aligned16(table) && rm_aligned16(rows_out),
+             "rm_gather_rows: NULL or unaligned argument");
+  const int G = width / 4;
+  const int64_t total = n * G;
+  dim3 grid(rm_grid_cap((total + kBlock - 1) / kBlock, 256 * 16));
+  hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream,
+                     (const float4 *)table, rows, n, G, (float4 *)rows_out);
+  RM_CHECK_LAUNCH("rm_gather_rows");
+  return RM_OK;
+}
+
+extern "C" int rm_permute_rows(const float *src, const int64_t *slot, int64_t n, int width,
+                               int inverse, float *dst, rm_stream_t stream) {
+  RM_REQUIRE(n >= 0 && width > 0 && width % 4 == 0, "rm_permute_rows: bad sizes");
+  if (n == 0) return RM_OK;
+  RM_REQUIRE(src && slot && dst && rm_aligned16(src) && rm_aligned16(dst),
+             "rm_permute_rows: NULL or unaligned argument");
+  const int G = width / 4;
+  const int64_t total = n * G;
+  dim3 grid(rm_grid_cap((total + kBlock - 1) / kBlock, 256 * 16));
+  hipLaunchKernelGGL(permute_rows_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream,
+                     (const float4 *)src, slot, n, G, inverse, (float4 *)dst);
+  RM_CHECK_LAUNCH("rm_permute_rows");
+  return RM_OK;
+}

@@ -1,0 +1,89 @@
+// Branch-logit sum + PredictionLayer + loss, forward and backward in one pass.
+// Replaces xDeepFM.py:99-104, layers.py:796-808, utils.py:192-198 (see recman_hip.h).
+#include "rm_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 1024;
+constexpr float kEps = 1e-7f;  // Keras backend epsilon()
+
+__global__ __launch_bounds__(kBlock) void logit_loss_kernel(
+    const float *__restrict__ la, float ca, const float *__restrict__ lb, float cb,
+    const float *__restrict__ lc, float cc, const float *__restrict__ ld, float cd,
+    const int64_t *__restrict__ y, const float *__restrict__ y_f, int task, int64_t B,
+    float *__restrict__ logit, float *__restrict__ pred, float *__restrict__ dlogit,
+    float *__restrict__ partial) {
+  __shared__ float sm[kBlock / 64];
+  const float invB = 1.0f / (float)B;
+  float acc = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
+    float z = 0.f;
+    if (la) z += ca * la[i];
+    if (lb) z += cb * lb[i];
+    if (lc) z += cc * lc[i];
+    if (ld) z += cd * ld[i];
+    if (logit) logit[i] = z;
+    const float t = y ? (float)y[i] : (y_f ? y_f[i] : 0.f);
+    if (task == 0) {
+      const float p = 1.0f / (1.0f + expf(-z));
+      if (pred) pred[i] = p;
+      const float lo = kEps, hi = 1.0f - kEps;
+      const float pc = fminf(fmaxf(p, lo), hi);
+      const float a = pc + kEps, c = 1.0f - pc + kEps;
+      acc += -(t * logf(a) + (1.0f - t) * logf(c));
+      if (dlogit) {
+        const bool inside = p >= lo && p <= hi;  // clip passes the gradient only inside
+        const float dp = inside ? -(t / a - (1.0f - t) / c) : 0.f;
+        dlogit[i] = dp * p * (1.0f - p) * invB;
+      }
+    } else {
+      if (pred) pred[i] = z;
+      const float e = z - t;
+      acc += e * e;
+      if (dlogit) dlogit[i] = 2.0f * e * invB;
+    }
+  }
+  acc = rm_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && partial) {
+    float s = 0.f;
+    for (int w = 0; w < kBlock / 64; ++w) s += sm[w];
+    partial[blockIdx.x] = s;
+  }
+}
+
+__global__ void loss_finish_kernel(const float *__restrict__ partial, int n, float invB,
+                                   float *__restrict__ loss) {
+  // one wave, fixed order: deterministic
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) acc += partial[i];
+  acc = rm_wave_sum(acc);
+  if (threadIdx.x == 0) loss[0] = acc * invB;
+}
+
+}  // namespace
+
+extern "C" int rm_logit_loss(const float *logit_a, float coef_a, const float *logit_b,
+                             float coef_b, const float *logit_c, float coef_c,
+                             const float *logit_d, float coef_d, const int64_t *y,
+                             const float *y_f, int task, int64_t B, float *logit, float *pred,
+                             float *dlogit, float *loss, float *workspace, rm_stream_t stream) {
+  RM_REQUIRE(B > 0, "rm_logit_loss: B must be > 0 (got %lld)", (long long)B);
+  RM_REQUIRE(task == 0 || task == 1, "rm_logit_loss: task must be 0 or 1");
+  RM_REQUIRE(logit_a || logit_b || logit_c || logit_d, "rm_logit_loss: no branch logit given");
+  RM_REQUIRE(!(dlogit || loss) || y || y_f, "rm_logit_loss: labels needed for loss/dlogit");
+  RM_REQUIRE(!loss || workspace, "rm_logit_loss: loss needs a workspace of >= 1024 floats");
+  const int nblk = rm_grid_cap((B + kBlock - 1) / kBlock, kMaxBlocks);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(logit_loss_kernel, dim3(nblk), dim3(kBlock), 0, st, logit_a, coef_a, logit_b,
+                     coef_b, logit_c, coef_c, logit_d, coef_d, y, y_f, task, B, logit, pred, dlogit,
+                     loss ? workspace : nullptr);
+  if (loss)
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, workspace, nblk,
+                       1.0f / (float)B, loss);
+  RM_CHECK_LAUNCH("rm_logit_loss");
+  return RM_OK;
+}

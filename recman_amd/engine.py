@@ -1,0 +1,551 @@
+"""Explicit forward+backward engines for DeepFM / DCN / xDeepFM on one MI355X.
+
+No autograd and no tracing compiler: each engine owns its parameters (laid out
+for the kernels: ONE concatenated embedding table in HBM, per-feature variables
+are views of it), a workspace sized once per batch size, and enqueues a fixed
+sequence of HIP kernels (recman_amd/ops.py -> librecman_hip.so) on the current
+stream - which makes a whole step capturable in a hipGraph (`capture=True`).
+
+The MLP ("DNN", layers.py:576-609) GEMMs go to rocBLAS/hipBLASLt through
+torch.mm: SURVEY.md section 7 step 6 - a library GEMM, not one of the hand-written
+kernels the north star names.
+
+Variable names are the reference's (layers.py:96,106,318,324,533,541,548,558,564,
+572,663,673,687,693) so state_dict() round-trips with its checkpoints' keys.
+"""
+import torch
+
+from . import ops
+
+F32, I64 = torch.float32, torch.int64
+
+_ACTS = {"relu": 0.0, "leaky_relu": 0.2}
+
+
+def act_name(a):
+    """Maps the reference's activation argument (a TF callable such as tf.nn.relu,
+    DeepFM.py:40, or a name) to a name this package knows."""
+    if a is None:
+        return "identity"
+    if isinstance(a, str):
+        name = a
+    else:
+        name = getattr(a, "__name__", str(a))
+    name = name.lower()
+    for k in ("leaky_relu", "relu", "identity", "linear"):
+        if k in name:
+            return "identity" if k == "linear" else k
+    raise ValueError(f"unsupported activation {a!r} (relu, leaky_relu, identity)")
+
+
+class FeatureSpec:
+    """Host-side description of the inputs: embedding (sparse) features in
+    FeatureDictionary order (inputs.py:13-15) with their feat_size (null slot
+    included, inputs.py:166) and the dense feature names."""
+
+    def __init__(self, sparse_names, feat_sizes, dense_names=()):
+        self.sparse_names = list(sparse_names)
+        self.feat_sizes = [int(v) for v in feat_sizes]
+        self.dense_names = list(dense_names)
+        if len(self.sparse_names) != len(self.feat_sizes):
+            raise ValueError("sparse_names and feat_sizes differ in length")
+
+    @property
+    def F(self):
+        return len(self.sparse_names)
+
+    @property
+    def Dn(self):
+        return len(self.dense_names)
+
+    @property
+    def rows(self):
+        return sum(self.feat_sizes)
+
+    def offsets(self):
+        off, out = 0, []
+        for v in self.feat_sizes:
+            out.append(off)
+            off += v
+        return out
+
+
+class MLP:
+    """DNN.__call__ (layers.py:576-609) with an explicit backward.  x = [xe | xd] is
+    never concatenated: layer 0 is two GEMMs accumulating into one output."""
+
+    def __init__(self, params, grads, FD, Dn, hidden, activation, device, prefix=""):
+        self.FD, self.Dn = FD, Dn
+        self.hidden = list(hidden)
+        self.act = act_name(activation)
+        if self.act not in ("relu", "leaky_relu", "identity"):
+            raise ValueError(self.act)
+        self.p, self.g, self.prefix = params, grads, prefix
+        dims = [FD + Dn] + self.hidden
+        for i in range(len(self.hidden)):
+            for nm, shape in ((f"{prefix}dnn_layer_{i}_weights", (dims[i], dims[i + 1])),
+                              (f"{prefix}dnn_layer_{i}_bias", (dims[i + 1],))):
+                params[nm] = torch.zeros(shape, dtype=F32, device=device)
+                grads[nm] = torch.zeros(shape, dtype=F32, device=device)
+        for nm, shape in ((f"{prefix}dnn_w", (dims[-1], 1)), (f"{prefix}dnn_w0", (1,))):
+            params[nm] = torch.zeros(shape, dtype=F32, device=device)
+            grads[nm] = torch.zeros(shape, dtype=F32, device=device)
+        self._B = None
+
+    def _alloc(self, B, device):
+        if self._B == B:
+            return
+        self._B = B
+        self.a = [torch.empty(B, h, dtype=F32, device=device) for h in self.hidden]
+        self.da = [torch.empty(B, h, dtype=F32, device=device) for h in self.hidden]
+        self.out = torch.empty(B, 1, dtype=F32, device=device)
+
+    def _act_(self, h):
+        if self.act == "relu":
+            torch.relu_(h)
+        elif self.act == "leaky_relu":
+            torch.nn.functional.leaky_relu_(h, 0.2)
+        return h
+
+    def forward(self, xe, xd, keep=None, masks=None):
+        """xe [B,FD], xd [B,Dn] or None -> logit [B] (a view of an internal buffer).
+        keep/masks: DNN dropout keep-probabilities and 0/1 masks (layers.py:589,602)."""
+        B = xe.shape[0]
+        self._alloc(B, xe.device)
+        p, pre = self.p, self.prefix
+        n = len(self.hidden)
+        self.keep = keep if keep is not None else [1] * (n + 1)
+        self.masks = masks if masks is not None else [None] * (n + 1)
+        self.xe, self.xd = xe, xd
+        if self.keep[0] < 1 and self.masks[0] is not None:
+            m = self.masks[0] / self.keep[0]
+            xe = xe * m[:, : self.FD]
+            xd = xd * m[:, self.FD:] if xd is not None else None
+            self.xe, self.xd = xe, xd
+        for i in range(n):
+            W, b = p[f"{pre}dnn_layer_{i}_weights"], p[f"{pre}dnn_layer_{i}_bias"]
+            a = self.a[i]
+            if i == 0:
+                torch.addmm(b, xe, W[: self.FD], out=a)
+                if xd is not None and self.Dn:
+                    a.addmm_(xd, W[self.FD:])
+            else:
+                torch.addmm(b, self.a[i - 1], W, out=a)
+            self._act_(a)
+            if self.keep[i + 1] < 1 and self.masks[i + 1] is not None:
+                a.mul_(self.masks[i + 1] / self.keep[i + 1])
+        torch.addmm(p[f"{pre}dnn_w0"], self.a[-1], p[f"{pre}dnn_w"], out=self.out)
+        return self.out.view(B)
+
+    def backward(self, g, dxe):
+        """g [B] = dLoss/dlogit; writes dLoss/dxe into dxe [B,FD] and the parameter
+        gradients into self.g.  (No gradient is needed for the dense inputs.)"""
+        p, gr, pre = self.p, self.g, self.prefix
+        n = len(self.hidden)
+        g2 = g.view(-1, 1)
+        torch.mm(self.a[-1].t(), g2, out=gr[f"{pre}dnn_w"])
+        gr[f"{pre}dnn_w0"].copy_(g.sum().view(1))
+        da = self.da[-1]
+        torch.mm(g2, p[f"{pre}dnn_w"].t(), out=da)
+        for i in range(n - 1, -1, -1):
+            a = self.a[i]
+            if self.keep[i + 1] < 1 and self.masks[i + 1] is not None:
+                # a holds the dropped activations; the mask is 0 where a was zeroed
+                da.mul_(self.masks[i + 1] / self.keep[i + 1])
+            if self.act != "identity":
+                # act'(pre-activation) from the stored post-activation: same sign, and
+                # dropped positions (a == 0) already have da == 0
+                slope = _ACTS[self.act]
+                if slope:
+                    da.mul_(torch.where(a > 0, 1.0, slope))
+                else:
+                    da.mul_(a > 0)
+            W = p[f"{pre}dnn_layer_{i}_weights"]
+            gW = gr[f"{pre}dnn_layer_{i}_weights"]
+            gr[f"{pre}dnn_layer_{i}_bias"].copy_(da.sum(0))
+            if i == 0:
+                torch.mm(self.xe.t(), da, out=gW[: self.FD])
+                if self.xd is not None and self.Dn:
+                    torch.mm(self.xd.t(), da, out=gW[self.FD:])
+                torch.mm(da, W[: self.FD].t(), out=dxe)
+                if self.keep[0] < 1 and self.masks[0] is not None:
+                    dxe.mul_(self.masks[0][:, : self.FD] / self.keep[0])
+            else:
+                torch.mm(self.a[i - 1].t(), da, out=gW)
+                torch.mm(da, W.t(), out=self.da[i - 1])
+                da = self.da[i - 1]
+
+    def l2(self, reg):
+        ws = [self.p[f"{self.prefix}dnn_layer_{i}_weights"] for i in range(len(self.hidden))]
+        ws.append(self.p[f"{self.prefix}dnn_w"])
+        return sum(reg * 0.5 * w.square().sum() for w in ws)  # layers.py:611-628
+
+    def add_l2_grads(self, reg):
+        for i in range(len(self.hidden)):
+            nm = f"{self.prefix}dnn_layer_{i}_weights"
+            self.g[nm].add_(self.p[nm], alpha=reg)
+        nm = f"{self.prefix}dnn_w"
+        self.g[nm].add_(self.p[nm], alpha=reg)
+
+
+class Engine:
+    """Shared storage + the embedding / linear / loss plumbing.  Subclasses add the
+    model-specific branches and define `_branches_fwd` / `_branches_bwd`."""
+
+    model = "base"
+    use_bias_tables = False
+
+    def __init__(self, spec, embedding_size, hp, task="classification", device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("recman_amd engines need a GPU (MI355X); there is no CPU path")
+        self.spec, self.D, self.hp, self.task = spec, int(embedding_size), dict(hp), task
+        self.device = torch.device(device)
+        dev = self.device
+        F, R, Dn = spec.F, spec.rows, spec.Dn
+        self.F, self.Dn, self.FD = F, Dn, F * self.D
+        self.params, self.grads = {}, {}
+        # --- HBM layout: one [R, D] table, one [R] bias table, one linear vector ---
+        self.table = torch.zeros(R, self.D, dtype=F32, device=dev)
+        self.bias_table = torch.zeros(R, dtype=F32, device=dev) if self.use_bias_tables else None
+        self.linear_w = torch.zeros(R + Dn, dtype=F32, device=dev)  # utils.py:31-36 order
+        offs = spec.offsets()
+        self.field_off = torch.tensor(offs, dtype=I64, device=dev)
+        self.lin_off = self.field_off  # sparse one-hot blocks share the table's row numbering
+        for name, off, V in zip(spec.sparse_names, offs, spec.feat_sizes):
+            self.params[f"{name}_feat_embed"] = self.table[off: off + V]
+            if self.use_bias_tables:
+                self.params[f"{name}_feat_bias"] = self.bias_table[off: off + V].view(V, 1)
+        self.params["linear_w"] = self.linear_w.view(-1, 1)
+        self.params["linear_w0"] = torch.zeros(1, dtype=F32, device=dev)
+        self.grads["linear_w0"] = torch.zeros(1, dtype=F32, device=dev)
+        self.grads["linear_w_dense"] = torch.zeros(Dn, dtype=F32, device=dev)
+        self._B = None
+        self.use_linear = True
+
+    # ------------------------------------------------------------------ storage
+    def load_params(self, params):
+        """Copies a name -> tensor dict (reference variable names) into the engine."""
+        for k, v in params.items():
+            if k not in self.params:
+                raise KeyError(f"unknown variable {k!r}")
+            dst = self.params[k]
+            dst.copy_(torch.as_tensor(v).to(dst.device, F32).reshape(dst.shape))
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.params.items()}
+
+    def _alloc(self, B):
+        if self._B == B:
+            return
+        self._B = B
+        dev = self.device
+        self.E = torch.empty(B, self.F, self.D, dtype=F32, device=dev)
+        self.d_rows = torch.empty(B, self.F, self.D, dtype=F32, device=dev)
+        self.fm_sum = torch.empty(B, self.D, dtype=F32, device=dev)
+        self.fm_logit = torch.empty(B, dtype=F32, device=dev)
+        self.lin_logit = torch.empty(B, dtype=F32, device=dev)
+        self.logit = torch.empty(B, dtype=F32, device=dev)
+        self.pred = torch.empty(B, dtype=F32, device=dev)
+        self.dlogit = torch.empty(B, dtype=F32, device=dev)
+        self.loss = torch.zeros(1, dtype=F32, device=dev)
+        self.ws = torch.empty(max(1024, 256 * (self.Dn + 1)), dtype=F32, device=dev)
+        self._alloc_model(B)
+
+    def _alloc_model(self, B):
+        pass
+
+    # ------------------------------------------------------------------ forward
+    def _embed(self, idx, dense, want_fm, masks, lin_w=None):
+        m = masks or {}
+        fm_masks = m.get("fm", (None, None))
+        lw = self.linear_w if lin_w is None else lin_w
+        ops.embed_fwd(
+            idx, self.table, self.field_off,
+            bias_table=self.bias_table if want_fm else None,
+            lin_w=lw if self.use_linear else None, lin_off=self.lin_off,
+            lin_w_dense=lw[self.spec.rows:] if (self.use_linear and self.Dn) else None,
+            lin_w0=self.params["linear_w0"] if self.use_linear else None,
+            dense=dense if (self.use_linear and self.Dn) else None,
+            mask_b=fm_masks[0] if want_fm else None, mask_e=fm_masks[1] if want_fm else None,
+            E=self.E, fm_sum=self.fm_sum if want_fm else None,
+            fm_logit=self.fm_logit if want_fm else None,
+            lin_logit=self.lin_logit if self.use_linear else None)
+
+    def forward(self, idx, dense=None, training=False, masks=None, manual_weights=None):
+        """-> (logit [B], pred [B]).  training=False disables dropout and (as the
+        reference does, layers.py:338-345) adds the per-feature manual weights."""
+        self._alloc(idx.shape[0])
+        lin_w = None
+        if manual_weights is not None:
+            lin_w = self.linear_w + manual_weights.to(self.device, F32)
+        branches = self._branches_fwd(idx, dense, training, masks, lin_w)
+        ops.logit_loss(branches, task=self.task, logit=self.logit, pred=self.pred)
+        return self.logit, self.pred
+
+    # --------------------------------------------------------- forward+backward
+    def fwd_bwd(self, idx, dense, y, masks=None):
+        """One training step's forward + backward.  Returns the loss tensor [1]
+        (data loss + l2 terms).  Gradients: self.grads (dense parameters),
+        self.d_rows [B,F,D] + idx (embedding rows, IndexedSlices form), self.dlogit
+        (per-occurrence gradient of the bias-table / sparse linear entries)."""
+        B = idx.shape[0]
+        self._alloc(B)
+        branches = self._branches_fwd(idx, dense, True, masks, None)
+        yk = dict(y=y) if y.dtype == I64 else dict(y_f=y)
+        ops.logit_loss(branches, task=self.task, logit=self.logit, pred=self.pred,
+                       dlogit=self.dlogit, loss=self.loss, workspace=self.ws, **yk)
+        self._branches_bwd(idx, dense, self.dlogit, masks)
+        if self.use_linear:
+            ops.linear_dense_bwd(self.dlogit, dense if self.Dn else None,
+                                 self.grads["linear_w_dense"] if self.Dn else None,
+                                 self.grads["linear_w0"], self.ws)
+        return self._add_l2(self.loss)
+
+    def _add_l2(self, loss):
+        hp = self.hp
+        total = loss
+        reg = hp.get("embedding_l2_reg", 0.0)
+        if reg:
+            total = total + reg * 0.5 * self.table.square().sum()
+        reg = hp.get("linear_l2_reg", 0.0)
+        if reg and self.use_linear:
+            total = total + reg * 0.5 * self.linear_w.square().sum()
+        return self._add_l2_model(total)
+
+    def _add_l2_model(self, total):
+        return total
+
+    # ------------------------------------------------------------ measurement
+    def roofline_probe(self, idx, dense, y, iters=20):
+        """Times the dominant hand-written kernel of this model with HIP events on the
+        stream it is launched on and prices it against its roofline."""
+        self._alloc(idx.shape[0])
+        name, fn, work, bound = self._dominant_kernel(idx, dense)
+        for _ in range(3):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(iters)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in ev) / iters
+        if bound == "hbm":
+            achieved, peak, unit = work / (ms * 1e-3) / 1e9, 8000.0, "GB/s"
+        else:
+            achieved, peak, unit = work / (ms * 1e-3) / 1e12, 157.3, "TFLOP/s"
+        return {"kernel": name, "bound": bound, "achieved": round(achieved, 2), "peak": peak,
+                "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
+                "avg_launch_us": round(ms * 1e3, 2),
+                "algorithmic_per_launch": work, "timing": f"hipEvent pairs, {iters} launches"}
+
+    def _embed_fwd_bytes(self, B, fm):
+        F, D, Dn = self.F, self.D, self.Dn
+        per = F * 8 + 2 * F * 4 * D  # idx read, rows read, E written
+        if fm:
+            per += F * 4 + 4 * D + 4  # bias entries, S written, fm_logit written
+        if self.use_linear:
+            per += F * 4 + Dn * 4 + 4  # linear entries, dense columns, lin_logit
+        return B * per
+
+    def _dominant_kernel(self, idx, dense):
+        fm = self._has_fm()
+        return ("embed_fwd_kernel (rm_embed_fwd: gather + FM + linear)",
+                lambda: self._embed(idx, dense, fm, None), self._embed_fwd_bytes(idx.shape[0], fm),
+                "hbm")
+
+    # ----------------------------------------------- dense views of the sparse grads
+    def dense_grads(self, idx):
+        """Densifies the sparse gradients of the last fwd_bwd (scatter-add with float
+        atomics) and adds the l2 terms: name -> tensor, the shapes of state_dict().
+        What TF's IndexedSlices + dense l2 gradient add up to (layers.py:188-193)."""
+        hp = self.hp
+        out = {k: v.clone() for k, v in self.grads.items() if k != "linear_w_dense"}
+        d_table = torch.zeros_like(self.table)
+        ops.scatter_add_rows(d_table, idx, self.field_off, rows=self.d_rows)
+        reg = hp.get("embedding_l2_reg", 0.0)
+        if reg:
+            d_table.add_(self.table, alpha=reg)
+        offs = self.spec.offsets()
+        d_bias = None
+        if self.use_bias_tables:
+            d_bias = torch.zeros_like(self.bias_table)
+            if self._has_fm():
+                if getattr(self, "d_bias", None) is not None:
+                    ops.scatter_add_rows(d_bias, idx, self.field_off, rows=self.d_bias, width=1,
+                                         ld=1)
+                else:
+                    ops.scatter_add_rows(d_bias, idx, self.field_off, g_row=self.dlogit)
+        for name, off, V in zip(self.spec.sparse_names, offs, self.spec.feat_sizes):
+            out[f"{name}_feat_embed"] = d_table[off: off + V]
+            if d_bias is not None:
+                out[f"{name}_feat_bias"] = d_bias[off: off + V].view(V, 1)
+        d_lin = torch.zeros_like(self.linear_w)
+        if self.use_linear:
+            ops.scatter_add_rows(d_lin, idx, self.lin_off, g_row=self.dlogit)
+            if self.Dn:
+                d_lin[self.spec.rows:] = self.grads["linear_w_dense"]
+            reg = hp.get("linear_l2_reg", 0.0)
+            if reg:
+                d_lin.add_(self.linear_w, alpha=reg)
+        else:
+            out["linear_w0"] = torch.zeros_like(self.grads["linear_w0"])
+        out["linear_w"] = d_lin.view(-1, 1)
+        self._dense_grads_model(out)
+        return out
+
+    def _dense_grads_model(self, out):
+        pass
+
+    def _has_fm(self):
+        return False
+
+
+class DeepFMEngine(Engine):
+    """DeepFM._init_graph (DeepFM.py:107-158): final = linear + fm + dnn."""
+
+    model = "deepfm"
+    use_bias_tables = True
+
+    def __init__(self, spec, embedding_size, hp, task="classification", device="cuda"):
+        super().__init__(spec, embedding_size, hp, task, device)
+        self.use_fm = bool(hp.get("use_fm", True))
+        self.use_deep = bool(hp.get("use_deep", True))
+        assert self.use_fm or self.use_deep  # DeepFM.py:54
+        self.mlp = None
+        if self.use_deep:
+            self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
+                           hp.get("deep_activation", "relu"), self.device)
+
+    def _has_fm(self):
+        return self.use_fm
+
+    def _branches_fwd(self, idx, dense, training, masks, lin_w):
+        hp = self.hp
+        m = masks or {}
+        if not training:
+            m = {}
+        self._embed(idx, dense, self.use_fm, m, lin_w)
+        branches = [(self.lin_logit, 1.0)]
+        if self.use_fm:
+            branches.append((self.fm_logit, 1.0))
+        if self.use_deep:
+            n = len(hp["deep_hidden_units"])
+            keep = list(hp.get("deep_dropout", [1] * (n + 1))) if training else [1] * (n + 1)
+            self.dnn_logit = self.mlp.forward(self.E.view(-1, self.FD), dense if self.Dn else None,
+                                              keep, m.get("dnn"))
+            branches.append((self.dnn_logit, 1.0))
+        return branches
+
+    def _branches_bwd(self, idx, dense, g, masks):
+        m = masks or {}
+        fm_masks = m.get("fm", (None, None))
+        dE_up = None
+        if self.use_deep:
+            self.mlp.backward(g, self.d_rows.view(-1, self.FD))
+            dE_up = self.d_rows
+        self.d_bias = None
+        if self.use_fm and fm_masks[0] is not None:
+            self.d_bias = torch.empty(idx.shape[0], self.F, dtype=F32, device=self.device)
+        ops.embed_bwd(self.d_rows, E=self.E if self.use_fm else None,
+                      fm_sum=self.fm_sum if self.use_fm else None, dE_up=dE_up,
+                      g_fm=g if self.use_fm else None, mask_b=fm_masks[0], mask_e=fm_masks[1],
+                      d_bias=self.d_bias)
+        if self.use_deep:
+            reg = self.hp.get("deep_l2_reg", 0.0)
+            if reg:
+                self.mlp.add_l2_grads(reg)
+
+    def _add_l2_model(self, total):
+        reg = self.hp.get("deep_l2_reg", 0.0)
+        if reg and self.use_deep:
+            total = total + self.mlp.l2(reg)
+        return total
+
+
+class DCNEngine(Engine):
+    """DCN._init_graph (DCN.py:99-144): dnn_input feeds the DNN and the CrossNet;
+    final = dnn + cross (+ dnn again under strict_reference, DCN.py:140-142)
+    (+ linear if use_linear).  CrossNet is absent from the reference (DCN.py:7):
+    DCN-v1 vector form, see csrc/cross.hip."""
+
+    model = "dcn"
+    use_bias_tables = False
+
+    def __init__(self, spec, embedding_size, hp, task="classification", device="cuda"):
+        super().__init__(spec, embedding_size, hp, task, device)
+        self.use_linear = bool(hp.get("use_linear", True))
+        self.L = int(hp.get("cross_layer_num", 3))
+        self.dnn_coef = 2.0 if hp.get("strict_reference", False) else 1.0
+        d = self.FD + self.Dn
+        dev = self.device
+        self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
+                       hp.get("deep_activation", "relu"), dev)
+        for nm, shape in (("cross_w", (self.L, d)), ("cross_b", (self.L, d)), ("cross_w_out", (d, 1))):
+            self.params[nm] = torch.zeros(shape, dtype=F32, device=dev)
+            self.grads[nm] = torch.zeros(shape, dtype=F32, device=dev)
+
+    def _alloc_model(self, B):
+        dev = self.device
+        L = self.L
+        self.cross_logit = torch.empty(B, dtype=F32, device=dev)
+        self.cross_s = torch.empty(B, L, dtype=F32, device=dev)
+        self.coef = torch.empty(B, 2 * L + 2, dtype=F32, device=dev)
+        self.P = torch.empty(self.FD + self.Dn, L + 1, dtype=F32, device=dev)
+        self.dxe_dnn = torch.empty(B, self.FD, dtype=F32, device=dev)
+
+    def _branches_fwd(self, idx, dense, training, masks, lin_w):
+        hp = self.hp
+        m = (masks or {}) if training else {}
+        self._embed(idx, dense, False, m, lin_w)
+        xe, xd = self.E.view(-1, self.FD), (dense if self.Dn else None)
+        n = len(hp["deep_hidden_units"])
+        keep = list(hp.get("deep_dropout", [1] * (n + 1))) if training else [1] * (n + 1)
+        self.dnn_logit = self.mlp.forward(xe, xd, keep, m.get("dnn"))
+        p = self.params
+        ops.cross_fwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1),
+                      self.cross_logit, self.cross_s)
+        branches = [(self.dnn_logit, self.dnn_coef), (self.cross_logit, 1.0)]
+        if self.use_linear:
+            branches.append((self.lin_logit, 1.0))
+        return branches
+
+    def _branches_bwd(self, idx, dense, g, masks):
+        p, gr = self.params, self.grads
+        xe, xd = self.E.view(-1, self.FD), (dense if self.Dn else None)
+        g_dnn = g if self.dnn_coef == 1.0 else g * self.dnn_coef
+        self.mlp.backward(g_dnn, self.dxe_dnn)
+        # cross backward adds the DNN's dx and writes straight into the row-gradient
+        # buffer: with no FM term d_rows IS dLoss/dE (no separate embed_bwd launch)
+        ops.cross_bwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1), g,
+                      self.cross_s, self.d_rows.view(-1, self.FD), None, self.coef,
+                      dx_in_e=self.dxe_dnn)
+        L = self.L
+        torch.mm(xe.t(), self.coef[:, : L + 1], out=self.P[: self.FD])
+        if self.Dn:
+            torch.mm(xd.t(), self.coef[:, : L + 1], out=self.P[self.FD:])
+        colsum = self.coef[:, L + 1:].sum(0)
+        ops.cross_param_grads(self.P, colsum, p["cross_w"], p["cross_b"],
+                              p["cross_w_out"].view(-1), gr["cross_w"], gr["cross_b"],
+                              gr["cross_w_out"].view(-1))
+        reg = self.hp.get("deep_l2_reg", 0.0)
+        if reg:
+            self.mlp.add_l2_grads(reg)
+        reg = self.hp.get("cross_layer_l2_reg", 0.0)
+        if reg:
+            gr["cross_w"].add_(p["cross_w"], alpha=reg)
+            gr["cross_w_out"].add_(p["cross_w_out"], alpha=reg)
+
+    def _add_l2_model(self, total):
+        reg = self.hp.get("deep_l2_reg", 0.0)
+        if reg:
+            total = total + self.mlp.l2(reg)
+        reg = self.hp.get("cross_layer_l2_reg", 0.0)
+        if reg:
+            total = total + reg * 0.5 * (self.params["cross_w"].square().sum()
+                                         + self.params["cross_w_out"].square().sum())
+        return total
+
+
+ENGINES = {"deepfm": DeepFMEngine, "dcn": DCNEngine}

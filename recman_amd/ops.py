@@ -1,0 +1,169 @@
+"""Tensor-level wrappers over the C ABI: shape/dtype/device checks in Python (the
+reference raises Python asserts before any arithmetic, layers.py:49,85,458,521-522),
+raw pointers and sizes across the boundary, kernels enqueued on torch's current
+stream.  torch is plumbing here: device memory and streams, nothing else.
+"""
+import torch
+
+from . import _lib
+
+F32, I64 = torch.float32, torch.int64
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype, shape=None, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError(f"{name} must not be None")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (recman_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t.data_ptr()
+
+
+def embed_fwd(idx, table, field_off, *, bias_table=None, bias_ld=1, lin_w=None, lin_ld=1,
+              lin_off=None, lin_w_dense=None, lin_w0=None, dense=None, mask_b=None, mask_e=None,
+              E=None, fm_sum=None, fm_logit=None, lin_logit=None, table_ld=None, D=None):
+    """Gather + FM + linear forward (see rm_embed_fwd in include/recman_hip.h).
+    `table` is [R, table_ld]; D defaults to table.shape[1]."""
+    B, F = idx.shape
+    ld = table.shape[1] if table_ld is None else table_ld
+    D = table.shape[1] if D is None else D
+    Dn = 0 if dense is None else dense.shape[1]
+    _lib.call(
+        "rm_embed_fwd", _chk(idx, "idx", I64), _chk(table, "table", F32), ld,
+        _chk(field_off, "field_off", I64, (F,)),
+        _chk(bias_table, "bias_table", F32, allow_none=True), bias_ld,
+        _chk(lin_w, "lin_w", F32, allow_none=True), lin_ld,
+        _chk(lin_off, "lin_off", I64, (F,), allow_none=True),
+        _chk(lin_w_dense, "lin_w_dense", F32, (Dn,), allow_none=True),
+        _chk(lin_w0, "lin_w0", F32, (1,), allow_none=True),
+        _chk(dense, "dense", F32, (B, Dn), allow_none=True), Dn,
+        _chk(mask_b, "mask_b", F32, (B, F), allow_none=True),
+        _chk(mask_e, "mask_e", F32, (B, F, D), allow_none=True), B, F, D,
+        _chk(E, "E", F32, (B, F, D), allow_none=True),
+        _chk(fm_sum, "fm_sum", F32, (B, D), allow_none=True),
+        _chk(fm_logit, "fm_logit", F32, (B,), allow_none=True),
+        _chk(lin_logit, "lin_logit", F32, (B,), allow_none=True), _stream())
+
+
+def embed_bwd(d_rows, *, E=None, fm_sum=None, dE_up=None, g_fm=None, mask_b=None, mask_e=None,
+              d_bias=None):
+    B, F, D = d_rows.shape
+    _lib.call(
+        "rm_embed_bwd", _chk(E, "E", F32, (B, F, D), allow_none=True),
+        _chk(fm_sum, "fm_sum", F32, (B, D), allow_none=True),
+        _chk(dE_up, "dE_up", F32, (B, F, D), allow_none=True),
+        _chk(g_fm, "g_fm", F32, (B,), allow_none=True),
+        _chk(mask_b, "mask_b", F32, (B, F), allow_none=True),
+        _chk(mask_e, "mask_e", F32, (B, F, D), allow_none=True), B, F, D,
+        _chk(d_rows, "d_rows", F32), _chk(d_bias, "d_bias", F32, (B, F), allow_none=True),
+        _stream())
+
+
+def scatter_add_rows(d_table, idx, field_off, *, rows=None, g_row=None, width=None, ld=None):
+    B, F = idx.shape
+    if width is None:
+        width = 1 if g_row is not None else rows.shape[-1]
+    if ld is None:
+        ld = d_table.shape[1] if d_table.dim() == 2 else 1
+    _lib.call(
+        "rm_scatter_add_rows", _chk(idx, "idx", I64), _chk(field_off, "field_off", I64, (F,)),
+        _chk(rows, "rows", F32, allow_none=True), _chk(g_row, "g_row", F32, (B,), allow_none=True),
+        B, F, width, ld, _chk(d_table, "d_table", F32), _stream())
+
+
+def linear_dense_bwd(g, dense, d_w_dense, d_w0, workspace):
+    B = g.shape[0]
+    Dn = 0 if dense is None else dense.shape[1]
+    if workspace.numel() < 256 * (Dn + 1):
+        raise ValueError("linear_dense_bwd: workspace too small")
+    _lib.call(
+        "rm_linear_dense_bwd", _chk(g, "g", F32, (B,)),
+        _chk(dense, "dense", F32, (B, Dn), allow_none=True), B, Dn,
+        _chk(d_w_dense, "d_w_dense", F32, (Dn,), allow_none=True),
+        _chk(d_w0, "d_w0", F32, (1,), allow_none=True), _chk(workspace, "workspace", F32),
+        _stream())
+
+
+def logit_loss(branches, *, y=None, y_f=None, task="classification", logit=None, pred=None,
+               dlogit=None, loss=None, workspace=None):
+    """branches: up to four (tensor [B], coefficient) pairs."""
+    if not 1 <= len(branches) <= 4:
+        raise ValueError("logit_loss takes 1..4 branch logits")
+    B = branches[0][0].shape[0]
+    args = []
+    for i in range(4):
+        if i < len(branches):
+            t, c = branches[i]
+            args += [_chk(t, f"logit_{i}", F32, (B,)), float(c)]
+        else:
+            args += [None, 0.0]
+    if loss is not None and (workspace is None or workspace.numel() < 1024):
+        raise ValueError("logit_loss: loss needs a workspace of >= 1024 floats")
+    _lib.call(
+        "rm_logit_loss", *args, _chk(y, "y", I64, (B,), allow_none=True),
+        _chk(y_f, "y_f", F32, (B,), allow_none=True), 0 if task == "classification" else 1, B,
+        _chk(logit, "logit", F32, (B,), allow_none=True),
+        _chk(pred, "pred", F32, (B,), allow_none=True),
+        _chk(dlogit, "dlogit", F32, (B,), allow_none=True),
+        _chk(loss, "loss", F32, (1,), allow_none=True),
+        _chk(workspace, "workspace", F32, allow_none=True), _stream())
+
+
+def cross_fwd(xe, xd, w, b, w_out, logit, s_out=None):
+    B, FD = xe.shape
+    Dn = 0 if xd is None else xd.shape[1]
+    L, d = w.shape
+    if d != FD + Dn:
+        raise ValueError(f"cross_fwd: w has d={d}, inputs have {FD}+{Dn}")
+    _lib.call(
+        "rm_cross_fwd", _chk(xe, "xe", F32), _chk(xd, "xd", F32, (B, Dn), allow_none=True), FD, Dn,
+        _chk(w, "w", F32), _chk(b, "b", F32, (L, d)), _chk(w_out, "w_out", F32, (d,)), L, B,
+        _chk(logit, "logit", F32, (B,)), _chk(s_out, "s_out", F32, (B, L), allow_none=True),
+        _stream())
+
+
+def cross_bwd(xe, xd, w, b, w_out, g, s, d_xe, d_xd, coef, dx_in_e=None, dx_in_d=None):
+    B, FD = xe.shape
+    Dn = 0 if xd is None else xd.shape[1]
+    L, d = w.shape
+    _lib.call(
+        "rm_cross_bwd", _chk(xe, "xe", F32), _chk(xd, "xd", F32, (B, Dn), allow_none=True), FD, Dn,
+        _chk(w, "w", F32), _chk(b, "b", F32, (L, d)), _chk(w_out, "w_out", F32, (d,)), L, B,
+        _chk(g, "g", F32, (B,)), _chk(s, "s", F32, (B, L)),
+        _chk(dx_in_e, "dx_in_e", F32, (B, FD), allow_none=True),
+        _chk(dx_in_d, "dx_in_d", F32, (B, Dn), allow_none=True), _chk(d_xe, "d_xe", F32, (B, FD)),
+        _chk(d_xd, "d_xd", F32, (B, Dn), allow_none=True),
+        _chk(coef, "coef", F32, (B, 2 * L + 2)), _stream())
+
+
+def cross_param_grads(P, colsum, w, b, w_out, d_w, d_b, d_w_out):
+    L, d = w.shape
+    _lib.call(
+        "rm_cross_param_grads", _chk(P, "P", F32, (d, L + 1)),
+        _chk(colsum, "colsum", F32, (L + 1,)), _chk(w, "w", F32), _chk(b, "b", F32, (L, d)),
+        _chk(w_out, "w_out", F32, (d,)), L, d, _chk(d_w, "d_w", F32, (L, d)),
+        _chk(d_b, "d_b", F32, (L, d)), _chk(d_w_out, "d_w_out", F32, (d,)), _stream())
+
+
+def gather_rows(table, rows, out):
+    n = rows.shape[0]
+    width = table.shape[1]
+    _lib.call("rm_gather_rows", _chk(table, "table", F32), _chk(rows, "rows", I64, (n,)), n, width,
+              _chk(out, "out", F32, (n, width)), _stream())
+
+
+def permute_rows(src, slot, dst, inverse=False):
+    n, width = src.shape
+    _lib.call("rm_permute_rows", _chk(src, "src", F32), _chk(slot, "slot", I64, (n,)), n, width,
+              1 if inverse else 0, _chk(dst, "dst", F32, (n, width)), _stream())

@@ -1,0 +1,171 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Tolerances: logits 1e-5 absolute (north star), gradients 1e-5
+relative to the gradient's max magnitude + 1e-6 absolute; indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import th_layers as T
+from tests.cases import make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(t):
+    return t.cuda() if t is not None else None
+
+
+def _close(got, want, rtol=1e-5, atol=1e-6, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= atol + rtol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e})"
+
+
+def _engine(model, spec, D, hp, p):
+    from recman_amd import engine as eng
+
+    espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names)
+    e = eng.ENGINES[model](espec, D, hp)
+    e.load_params({k: v for k, v in p.items() if k in e.params})
+    return e
+
+
+def _check_model(model, hip_lib, D=8, B=37, **kw):
+    spec, p, idx, dense, y, hp = make_case(model, B=B, D=D, **kw)
+    loss_o, logit_o, pred_o, grads_o = T.fwd_bwd(model, p, spec, idx, dense, y, hp)
+    e = _engine(model, spec, D, hp, p)
+    idx_d, dense_d, y_d = idx.cuda(), dense.cuda(), y.cuda()
+    loss = e.fwd_bwd(idx_d, dense_d, y_d)
+    torch.cuda.synchronize()
+    _close(e.logit, logit_o, rtol=0, atol=1e-5, what="logit")
+    _close(e.pred, pred_o, rtol=0, atol=1e-6, what="pred")
+    _close(loss, loss_o.reshape(1), what="loss")
+    grads = e.dense_grads(idx_d)
+    for k in grads_o:
+        if k in grads:
+            _close(grads[k], grads_o[k], what=f"grad {k}")
+        else:  # a variable this configuration does not use (e.g. DNN weights with use_deep=False)
+            assert float(grads_o[k].abs().max()) <= 1e-3 * 1.0001 * float(p[k].abs().max()), k
+    assert set(grads) <= set(grads_o), set(grads) - set(grads_o)
+    # inference path: dropout off, same logits when no dropout is configured
+    logit_i, pred_i = e.forward(idx_d, dense_d, training=False)
+    _close(logit_i, logit_o, rtol=0, atol=1e-5, what="inference logit")
+    return e
+
+
+@pytest.mark.parametrize("D", [4, 8, 16, 32, 64])
+def test_deepfm_fwd_bwd_matches_oracle(hip_lib, D):
+    _check_model("deepfm", hip_lib, D=D)
+
+
+def test_deepfm_criteo_like_shape(hip_lib):
+    _check_model("deepfm", hip_lib, D=16, B=300, F=26, Dn=13, hidden=(32, 32), scale=0.05)
+
+
+def test_deepfm_single_example_and_ragged_tail(hip_lib):
+    for B in (1, 2, 15, 17, 63, 65):
+        _check_model("deepfm", hip_lib, D=16, B=B)
+
+
+def test_deepfm_no_dense_features(hip_lib):
+    _check_model("deepfm", hip_lib, D=8, Dn=0)
+
+
+def test_deepfm_use_fm_only_and_deep_only(hip_lib):
+    _check_model("deepfm", hip_lib, D=8, hp_extra=dict(use_deep=False))
+    _check_model("deepfm", hip_lib, D=8, hp_extra=dict(use_fm=False))
+
+
+@pytest.mark.parametrize("L", [1, 3, 6, 8])
+def test_dcn_fwd_bwd_matches_oracle(hip_lib, L):
+    _check_model("dcn", hip_lib, D=8, cross_layers=L, scale=0.15)
+
+
+def test_dcn_criteo_like_shape(hip_lib):
+    _check_model("dcn", hip_lib, D=16, B=200, F=26, Dn=13, hidden=(40, 24), cross_layers=6, scale=0.03)
+
+
+def test_dcn_strict_reference_counts_dnn_twice_and_no_linear(hip_lib):
+    _check_model("dcn", hip_lib, D=8, cross_layers=2, scale=0.15, hp_extra=dict(strict_reference=True))
+    _check_model("dcn", hip_lib, D=8, cross_layers=2, scale=0.15, hp_extra=dict(use_linear=False))
+
+
+def test_fm_dropout_masks_injected(hip_lib):
+    from recman_amd import ops
+
+    spec, p, idx, dense, y, hp = make_case("deepfm", B=50, D=16)
+    g = torch.Generator().manual_seed(5)
+    B, F, D = 50, spec.F, 16
+    keep = (0.7, 0.8)
+    mb = (torch.rand(B, F, 1, generator=g) < keep[0]).float()
+    me = (torch.rand(B, F, D, generator=g) < keep[1]).float()
+    E, bias = T.feat_embedding_layer(p, spec, idx)
+    want = T.fm_layer(E, bias, keep, (mb, me)).reshape(-1)
+    e = _engine("deepfm", spec, D, hp, p)
+    e._alloc(B)
+    masks = {"fm": ((mb.reshape(B, F) / keep[0]).cuda().contiguous(), (me / keep[1]).cuda().contiguous())}
+    e._embed(idx.cuda(), dense.cuda(), True, masks)
+    _close(e.fm_logit, want, rtol=0, atol=1e-5, what="fm logit with dropout")
+
+
+def test_mlp_dropout_masks_injected(hip_lib):
+    spec, p, idx, dense, y, hp = make_case("deepfm", B=40, D=8)
+    hp["deep_dropout"] = (0.9, 0.8, 0.7)
+    g = torch.Generator().manual_seed(7)
+    dims = [spec.F * 8 + spec.Dn, 16, 8]
+    masks = [(torch.rand(40, d, generator=g) < k).float() for d, k in zip(dims, hp["deep_dropout"])]
+    loss_o, logit_o, pred_o, grads_o = T.fwd_bwd("deepfm", p, spec, idx, dense, y, hp,
+                                                 masks={"dnn": masks})
+    e = _engine("deepfm", spec, 8, hp, p)
+    loss = e.fwd_bwd(idx.cuda(), dense.cuda(), y.cuda(), masks={"dnn": [m.cuda() for m in masks]})
+    _close(e.logit, logit_o, rtol=0, atol=1e-5, what="logit")
+    grads = e.dense_grads(idx.cuda())
+    for k in grads_o:
+        _close(grads[k], grads_o[k], what=f"grad {k}")
+
+
+def test_regression_task(hip_lib):
+    from recman_amd import engine as eng
+
+    spec, p, idx, dense, y, hp = make_case("deepfm", B=33, D=8)
+    yf = torch.randn(33)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    logit = T.deepfm_logit(leaves, spec, idx, dense, hp)
+    loss_o = T.create_loss(yf, T.prediction(logit, "regression"), "regression") + T.deepfm_l2(leaves, spec, hp)
+    loss_o.backward()
+    e = eng.DeepFMEngine(eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names), 8, hp,
+                         task="regression")
+    e.load_params(p)
+    loss = e.fwd_bwd(idx.cuda(), dense.cuda(), yf.cuda())
+    _close(loss, loss_o.detach().reshape(1), what="mse loss")
+    grads = e.dense_grads(idx.cuda())
+    for k, v in leaves.items():
+        _close(grads[k], v.grad, what=f"grad {k}")
+
+
+def test_loss_clip_region_gradient_is_zero(hip_lib):
+    from recman_amd import ops
+
+    z = torch.tensor([40.0, -40.0, 0.3, 20.0], device="cuda")
+    y = torch.tensor([1, 0, 1, 0], device="cuda")
+    zc = z.cpu().clone().requires_grad_(True)
+    loss_o = T.create_loss(y.cpu(), T.prediction(zc))
+    loss_o.backward()
+    logit, pred, dl = (torch.empty(4, device="cuda") for _ in range(3))
+    loss, ws = torch.empty(1, device="cuda"), torch.empty(1024, device="cuda")
+    ops.logit_loss([(z, 1.0)], y=y, logit=logit, pred=pred, dlogit=dl, loss=loss, workspace=ws)
+    _close(loss, loss_o.detach().reshape(1), what="loss")
+    _close(dl, zc.grad, rtol=1e-5, atol=1e-9, what="dlogit")
+
+
+def test_error_reporting_is_loud(hip_lib):
+    from recman_amd import _lib, ops
+
+    with pytest.raises(ValueError):
+        ops.embed_fwd(torch.zeros(2, 2, dtype=torch.int64), torch.zeros(4, 8).cuda(),
+                      torch.zeros(2, dtype=torch.int64).cuda())  # idx on the CPU
+    with pytest.raises(_lib.RecmanHipError, match="unsupported"):
+        t = torch.zeros(4, 12).cuda()  # D = 12: G = 3 does not divide a wave
+        ops.embed_fwd(torch.zeros(2, 2, dtype=torch.int64).cuda(), t,
+                      torch.zeros(2, dtype=torch.int64).cuda(), E=torch.empty(2, 2, 12).cuda())
