@@ -165,6 +165,27 @@ int rm_cross_param_grads(const float *P, const float *colsum, const float *w, co
                          float *d_w_out, rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * CIN (xDeepFM), one layer, on the f32-input MFMA.
+ * Replaces the loop body of CIN.__call__ (layers.py:714-752):
+ *   Z[b,d,i*H+j] = X0[b,i,d] * Xk[b,j,d];  M = Z @ W + bias;  out = act(M)
+ *   out laid out [B,N,D] (after the transpose of layers.py:739); Z is never formed.
+ *   X0 [B,m,D]; Xk: rows j < H of a [B,*,D] tensor with xk_bstride floats between
+ *   examples (the "next hidden" half of the previous layer's map, layers.py:744-746);
+ *   W [m*H, N] (cin_filter_k[0]), bias [N].
+ *   pooled [B, pool_stride]: when not NULL, sum_d out[b,n,d] for n in [pool_from, N)
+ *   is written to pooled[b, pool_col0 + n - pool_from] (the direct-connect half and
+ *   the reduce_sum of layers.py:751-755).
+ *   filter_ws: scratch of rm_cin_filter_workspace(m,H,N) floats (the filter
+ *   re-laid out as MFMA B-operand; rewritten by every call).
+ * N <= 128; D a multiple of 4 dividing 256; (m+1+H)*1 KiB + 32 KiB of LDS <= 160 KiB.
+ */
+int64_t rm_cin_filter_workspace(int m, int H, int N);
+int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bstride, const float *W,
+                     const float *bias, int act, int64_t B, int m, int H, int N, int D,
+                     float *out, float *pooled, int pool_stride, int pool_col0, int pool_from,
+                     float *filter_ws, rm_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Row helpers (owner-side gather and re-ordering for the row-sharded table).
  */
 /* rows_out[i,:] = table[rows[i],:] for i < n (owner-side gather of the requested

@@ -33,8 +33,16 @@ SIGNATURES = {
     "rm_cross_fwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P],
     "rm_cross_bwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P, P, P, P, P, P],
     "rm_cross_param_grads": [P, P, P, P, P, c_int, c_int, P, P, P, P],
+    "rm_cin_layer_fwd": [P, P, I64, P, P, c_int, I64, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
+                         c_int, P, P],
     "rm_gather_rows": [P, P, I64, c_int, P, P],
     "rm_permute_rows": [P, P, I64, c_int, c_int, P, P],
+}
+
+
+# int64-returning size queries
+SIGNATURES_I64 = {
+    "rm_cin_filter_workspace": [c_int, c_int, c_int],
 }
 
 
@@ -50,6 +58,10 @@ def _load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.rm_last_error.restype = c_char_p
     lib.rm_last_error.argtypes = []
+    for name, argtypes in SIGNATURES_I64.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int64
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud
         fn.argtypes = argtypes

@@ -167,3 +167,29 @@ def permute_rows(src, slot, dst, inverse=False):
     n, width = src.shape
     _lib.call("rm_permute_rows", _chk(src, "src", F32), _chk(slot, "slot", I64, (n,)), n, width,
               1 if inverse else 0, _chk(dst, "dst", F32, (n, width)), _stream())
+
+
+ACT_IDS = {"identity": 0, "relu": 1, "leaky_relu": 2}
+
+
+def cin_filter_workspace(m, H, N):
+    return int(_lib.lib().rm_cin_filter_workspace(m, H, N))
+
+
+def cin_layer_fwd(X0, Xk, H, W, bias, act, out, filter_ws, pooled=None, pool_col0=0, pool_from=0):
+    """One CIN layer forward.  X0 [B,m,D]; Xk [B,Hk,D] of which rows j < H are used;
+    W [m*H, N]; out [B,N,D]; pooled [B, P] gets sum_d out[:, pool_from:, :] at pool_col0."""
+    B, m, D = X0.shape
+    N = W.shape[1]
+    if W.shape[0] != m * H:
+        raise ValueError(f"cin_layer_fwd: filter has {W.shape[0]} rows, expected m*H = {m * H}")
+    if Xk.shape[0] != B or Xk.shape[2] != D or Xk.shape[1] < H:
+        raise ValueError("cin_layer_fwd: Xk shape mismatch")
+    if filter_ws.numel() < cin_filter_workspace(m, H, N):
+        raise ValueError("cin_layer_fwd: filter workspace too small")
+    _lib.call(
+        "rm_cin_layer_fwd", _chk(X0, "X0", F32), _chk(Xk, "Xk", F32), Xk.shape[1] * D,
+        _chk(W, "W", F32), _chk(bias, "bias", F32, (N,)), ACT_IDS[act], B, m, H, N, D,
+        _chk(out, "out", F32, (B, N, D)), _chk(pooled, "pooled", F32, allow_none=True),
+        0 if pooled is None else pooled.shape[1], pool_col0, pool_from,
+        _chk(filter_ws, "filter_ws", F32), _stream())

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 
 def test_binding_table_covers_the_header(hip_lib):
-    bound = set(_lib.SIGNATURES) | {"rm_last_error"}
+    bound = set(_lib.SIGNATURES) | set(_lib.SIGNATURES_I64) | {"rm_last_error"}
     assert set(declared_symbols()) == bound, set(declared_symbols()) ^ bound
 
 
