@@ -185,6 +185,24 @@ int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bstride, const
                      float *out, float *pooled, int pool_stride, int pool_col0, int pool_from,
                      float *filter_ws, rm_stream_t stream);
 
+/* Backward of one CIN layer (three MFMA passes over the same GEMM shape).
+ *   out [B,N,D]: the layer's post-activation map (act' is read off its sign);
+ *   the gradient w.r.t. out is never materialised by the caller:
+ *     n <  pool_from: d_hidden[b,n,d]  (the next layer's dXk, dh_bstride floats per example)
+ *     n >= pool_from: g[b] * cin_w_direct[n - pool_from]   (reduce_sum + cin_w, layers.py:754-758)
+ *   dX0 [B,m,D] (+= when accumulate_dx0) = sum_j (dM @ W^T)[.,(i,j)] * Xk[b,j,d]
+ *   dXk [B,H,D] (dxk_bstride floats per example) = sum_i (dM @ W^T)[.,(i,j)] * X0[b,i,d];
+ *        with xk_is_x0 (first layer: Xk is X0 itself) it is added into dX0 instead
+ *   dW [m*H,N] = Z^T @ dM,  dbias [N] = colsum(dM)   (dM = d_out * act'(out))
+ *   workspace: rm_cin_bwd_workspace(B,m,H,N,D) floats.  D must divide 64. */
+int64_t rm_cin_bwd_workspace(int64_t B, int m, int H, int N, int D);
+int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int xk_is_x0,
+                     const float *W, int act, const float *out, const float *d_hidden,
+                     int64_t dh_bstride, const float *g, const float *cin_w_direct, int pool_from,
+                     int64_t B, int m, int H, int N, int D, float *dX0, int accumulate_dx0,
+                     float *dXk, int64_t dxk_bstride, float *dW, float *dbias, float *workspace,
+                     int64_t workspace_floats, rm_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Row helpers (owner-side gather and re-ordering for the row-sharded table).
  */

@@ -187,6 +187,356 @@ __global__ __launch_bounds__(256, 1) void cin_fwd_kernel(
   }
 }
 
+// ===========================================================================
+// Backward.
+// ===========================================================================
+// dM[p][n] = dOut[b,n,d] * act'(out[b,n,d]),  p = b*D + d, row-major [B*D][Np]
+// (zero for n >= N).  dOut = the next layer's dXk for the "next hidden" half
+// (n < pool_from) and g[b]*cin_w[col] for the direct-connect half (the gradient of
+// reduce_sum + matmul, layers.py:754-758).  Also dbias[n] += sum_p dM[p][n].
+__global__ __launch_bounds__(256) void cin_dm_kernel(
+    const float *__restrict__ out, const float *__restrict__ d_hidden, int64_t dh_bstride,
+    const float *__restrict__ g, const float *__restrict__ cw, int pool_from, int act, int64_t B,
+    int N, int Np, int D, float *__restrict__ dM, float *__restrict__ dbias) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *tile = smem;             // [D][Np + 1]
+  float *colsum = tile + D * (Np + 1);  // [Np]
+  const int tid = threadIdx.x;
+  const int ld = Np + 1;
+  for (int t = tid; t < Np; t += 256) colsum[t] = 0.f;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    const float gb = g[b];
+    for (int t = tid; t < Np * D; t += 256) {
+      const int n = t / D, d = t - n * D;
+      float v = 0.f;
+      if (n < N) {
+        const float o = out[(b * N + n) * D + d];
+        const float up = n >= pool_from ? gb * cw[n - pool_from]
+                                        : d_hidden[b * dh_bstride + (int64_t)n * D + d];
+        v = up * act_grad_from_out(o, act);
+      }
+      tile[d * ld + n] = v;
+    }
+    __syncthreads();
+    for (int t = tid; t < Np * D; t += 256) {
+      const int d = t / Np, n = t - d * Np;
+      dM[(b * D + d) * Np + n] = tile[d * ld + n];
+    }
+    if (tid < Np) {
+      float sacc = 0.f;
+      for (int d = 0; d < D; ++d) sacc += tile[d * ld + tid];
+      colsum[tid] += sacc;
+    }
+  }
+  __syncthreads();
+  if (tid < N && dbias != nullptr) atomicAdd(dbias + tid, colsum[tid]);
+}
+
+// Wq[k'][n] = W[(i*H+j)*N + n] (zero where padded): the A-operand source of the dX kernel.
+__global__ void cin_prep_bwd_kernel(const float *__restrict__ W, int m, int H, int N, int Np,
+                                    float *__restrict__ Wq) {
+  const int He = cin_He(H), Kp = cin_Kp(m, H);
+  const int total = Kp * Np;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int kp = t / Np, n = t - kp * Np;
+    const int i = kp / He, j = kp - i * He;
+    Wq[t] = (i < m && j < H && n < N) ? W[(int64_t)(i * H + j) * N + n] : 0.f;
+  }
+}
+
+constexpr int kRowsX = 128;  // rows per dX block (4 waves x 32)
+
+// dZ^T tile [32 k'][32 rows] = W[k'][:] . dM[row][:]^T on the MFMA (A = filter chunk from
+// LDS, B = the lane's own dM row kept in registers), then contracted on the fly:
+//   dX0[i][row] += dZ * Xk[j][row],   dXk[j][row] += dZ * X0[i][row]     (LDS float atomics)
+template <int NT>
+__global__ __launch_bounds__(256, 1) void cin_dx_kernel(
+    const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride, int xk_is_x0,
+    const float *__restrict__ Wq, const float *__restrict__ dM, int64_t B, int m, int H, int D,
+    float *__restrict__ dX0, int accumulate_dx0, float *__restrict__ dXk, int64_t dxk_bstride) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int Np = 32 * NT;
+  constexpr int LDW = Np + 4;
+  const int He = cin_He(H);
+  const int Kp = cin_Kp(m, H);
+  float *X0s = smem;                         // [(m+1)][128]
+  float *Xks = X0s + (m + 1) * kRowsX;       // [He][128]
+  float *dX0s = Xks + He * kRowsX;           // [(m+1)][128]
+  float *dXks = dX0s + (m + 1) * kRowsX;     // [He][128]
+  float *Wt = dXks + He * kRowsX;            // [2][32][LDW]
+  int2 *tab = reinterpret_cast<int2 *>(Wt + 2 * 32 * LDW);  // [Kp] (i*128, j*128)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+  const int epb = kRowsX / D;
+  const int64_t b0 = (int64_t)blockIdx.x * epb;
+  const int D4 = D / 4;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int t = tid; t < epb * m * D4; t += 256) {
+    const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+    const int64_t b = b0 + bl;
+    const float4 v = b < B ? *reinterpret_cast<const float4 *>(X0 + (b * m + i) * D + 4 * d4) : z4;
+    *reinterpret_cast<float4 *>(X0s + i * kRowsX + bl * D + 4 * d4) = v;
+  }
+  for (int t = tid; t < epb * H * D4; t += 256) {
+    const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
+    const int64_t b = b0 + bl;
+    const float4 v =
+        b < B ? *reinterpret_cast<const float4 *>(Xk + b * xk_bstride + (int64_t)j * D + 4 * d4) : z4;
+    *reinterpret_cast<float4 *>(Xks + j * kRowsX + bl * D + 4 * d4) = v;
+  }
+  if (tid < kRowsX) {
+    X0s[m * kRowsX + tid] = 0.f;
+    if (He > H) Xks[H * kRowsX + tid] = 0.f;
+  }
+  for (int t = tid; t < (m + 1) * kRowsX; t += 256) dX0s[t] = 0.f;
+  for (int t = tid; t < He * kRowsX; t += 256) dXks[t] = 0.f;
+  for (int t = tid; t < Kp; t += 256) {
+    const int i = t / He, j = t - i * He;
+    tab[t] = make_int2((i < m ? i : m) * kRowsX, j * kRowsX);
+  }
+  // the lane's own dM row, in MFMA B-operand order: step s=4u+q <-> n = 8u + 4h + q
+  const int prow = wave * 32 + c;
+  const int64_t pg = b0 * D + prow;  // global row
+  float dm[Np / 2];
+#pragma unroll
+  for (int u = 0; u < Np / 8; ++u) {
+    const float4 v = pg < B * D ? *reinterpret_cast<const float4 *>(dM + pg * Np + 8 * u + 4 * h) : z4;
+    dm[4 * u + 0] = v.x; dm[4 * u + 1] = v.y; dm[4 * u + 2] = v.z; dm[4 * u + 3] = v.w;
+  }
+  // filter chunk 0
+  constexpr int F4 = 32 * Np / 4 / 256;  // float4 per thread per chunk (= NT)
+#pragma unroll
+  for (int q = 0; q < F4; ++q) {
+    const int f = tid + q * 256, row = f / (Np / 4), c4 = f - row * (Np / 4);
+    *reinterpret_cast<float4 *>(Wt + row * LDW + 4 * c4) =
+        *reinterpret_cast<const float4 *>(Wq + (int64_t)row * Np + 4 * c4);
+  }
+  __syncthreads();
+
+  const int ntiles = Kp / 32;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    float4 pf[F4];
+    if (kt + 1 < ntiles) {
+#pragma unroll
+      for (int q = 0; q < F4; ++q) {
+        const int f = tid + q * 256, row = f / (Np / 4), c4 = f - row * (Np / 4);
+        pf[q] = *reinterpret_cast<const float4 *>(Wq + ((int64_t)(kt + 1) * 32 + row) * Np + 4 * c4);
+      }
+    }
+    const float *Wb = Wt + (kt & 1) * 32 * LDW;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < Np / 8; ++u) {
+      const float4 a4 = *reinterpret_cast<const float4 *>(Wb + c * LDW + 8 * u + 4 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, dm[4 * u + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, dm[4 * u + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, dm[4 * u + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, dm[4 * u + 3], acc, 0, 0, 0);
+    }
+    // acc[r] = dZ[row = prow][k' = kt*32 + (r&3) + 8*(r>>2) + 4h]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kp = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int2 ij = tab[kp];
+      const float x0 = X0s[ij.x + prow], xk = Xks[ij.y + prow];
+      atomicAdd(dX0s + ij.x + prow, acc[r] * xk);
+      atomicAdd(dXks + ij.y + prow, acc[r] * x0);
+    }
+    if (kt + 1 < ntiles) {
+      float *Wn = Wt + ((kt + 1) & 1) * 32 * LDW;
+#pragma unroll
+      for (int q = 0; q < F4; ++q) {
+        const int f = tid + q * 256, row = f / (Np / 4), c4 = f - row * (Np / 4);
+        *reinterpret_cast<float4 *>(Wn + row * LDW + 4 * c4) = pf[q];
+      }
+    }
+    __syncthreads();
+  }
+
+  for (int t = tid; t < epb * m * D4; t += 256) {
+    const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+    const int64_t b = b0 + bl;
+    if (b >= B) continue;
+    float4 v = *reinterpret_cast<const float4 *>(dX0s + i * kRowsX + bl * D + 4 * d4);
+    if (xk_is_x0) {
+      const float4 w = *reinterpret_cast<const float4 *>(dXks + i * kRowsX + bl * D + 4 * d4);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    float4 *dst = reinterpret_cast<float4 *>(dX0 + (b * m + i) * D + 4 * d4);
+    if (accumulate_dx0) {
+      const float4 o = *dst;
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *dst = v;
+  }
+  if (!xk_is_x0 && dXk != nullptr) {
+    for (int t = tid; t < epb * H * D4; t += 256) {
+      const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
+      const int64_t b = b0 + bl;
+      if (b >= B) continue;
+      *reinterpret_cast<float4 *>(dXk + b * dxk_bstride + (int64_t)j * D + 4 * d4) =
+          *reinterpret_cast<const float4 *>(dXks + j * kRowsX + bl * D + 4 * d4);
+    }
+  }
+}
+
+size_t cin_dx_smem(int m, int H, int NT) {
+  const int Np = 32 * NT;
+  return (size_t)(2 * (m + 1 + cin_He(H)) * kRowsX + 2 * 32 * (Np + 4)) * sizeof(float) +
+         (size_t)cin_Kp(m, H) * sizeof(int2);
+}
+
+// dW partial: part[s][k'][n] = sum over the split's rows p of Z[p][k'] * dM[p][n].
+// MFMA with the rows as the reduction dimension: A = Z^T (formed in registers from the
+// [row][field] LDS images), B = dM rows.  A wave owns 4 k'-tiles x NT n-tiles.
+constexpr int kRC = 64;   // rows per staged chunk
+constexpr int kKT = 4;    // k'-tiles per wave
+template <int NT>
+__global__ __launch_bounds__(256, 1) void cin_dw_kernel(
+    const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride,
+    const float *__restrict__ dM, int64_t B, int m, int H, int D, int chunks_per_split,
+    float *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int Np = 32 * NT;
+  const int He = cin_He(H);
+  const int Kp = cin_Kp(m, H);
+  const int ld0 = (m + 1) | 1, ldk = He | 1;
+  float *X0T = smem;                 // [64][ld0]  (column m is zero)
+  float *XkT = X0T + kRC * ld0;      // [64][ldk]
+  float *dMs = XkT + kRC * ldk;      // [64][Np], n = nt*32+cc stored at cc*NT+nt
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+  const int group = blockIdx.x, split = blockIdx.y;
+  const int64_t rows_total = B * D;
+  const int64_t chunk0 = (int64_t)split * chunks_per_split;
+
+  int iq[kKT], jq[kKT];
+#pragma unroll
+  for (int q = 0; q < kKT; ++q) {
+    const int kp = (group * 4 * kKT + wave * kKT + q) * 32 + c;
+    const int i = kp / He, j = kp - i * He;
+    const bool ok = kp < Kp && i < m && j < H;
+    iq[q] = ok ? i : m;
+    jq[q] = ok ? j : 0;
+  }
+  f32x16 acc[kKT][NT];
+#pragma unroll
+  for (int q = 0; q < kKT; ++q)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][nt][r] = 0.f;
+
+  const int D4 = D / 4;
+  const int n0f4 = kRC * m / 4;   // float4 of X0 per chunk (rows*m/4)
+  const int nkf4 = kRC * H / 4;
+  constexpr int DMF4 = kRC * Np / 4 / 256;  // float4 of dM per thread per chunk
+  for (int ci = 0; ci < chunks_per_split; ++ci) {
+    const int64_t r0 = (chunk0 + ci) * kRC;
+    if (r0 >= rows_total) break;
+    __syncthreads();  // previous chunk fully consumed
+    // ---- stage: X0T / XkT transposed images, dM rows (permuted columns) ----
+    for (int t = tid; t < n0f4; t += 256) {
+      // t -> (example-in-chunk bl, field i, d4); rows pl = bl*D + 4*d4 .. +3
+      const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+      const int pl = bl * D + 4 * d4;
+      const int64_t pgl = r0 + pl;
+      const int64_t b = pgl / D;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pgl < rows_total) v = *reinterpret_cast<const float4 *>(X0 + (b * m + i) * D + 4 * d4);
+      X0T[(pl + 0) * ld0 + i] = v.x; X0T[(pl + 1) * ld0 + i] = v.y;
+      X0T[(pl + 2) * ld0 + i] = v.z; X0T[(pl + 3) * ld0 + i] = v.w;
+    }
+    if (tid < kRC) X0T[tid * ld0 + m] = 0.f;
+    for (int t = tid; t < nkf4; t += 256) {
+      const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
+      const int pl = bl * D + 4 * d4;
+      const int64_t pgl = r0 + pl;
+      const int64_t b = pgl / D;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pgl < rows_total)
+        v = *reinterpret_cast<const float4 *>(Xk + b * xk_bstride + (int64_t)j * D + 4 * d4);
+      XkT[(pl + 0) * ldk + j] = v.x; XkT[(pl + 1) * ldk + j] = v.y;
+      XkT[(pl + 2) * ldk + j] = v.z; XkT[(pl + 3) * ldk + j] = v.w;
+    }
+#pragma unroll
+    for (int q = 0; q < DMF4; ++q) {
+      const int f = tid + q * 256, pl = f / (Np / 4), c4 = f - pl * (Np / 4);
+      const int64_t pgl = r0 + pl;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pgl < rows_total) v = *reinterpret_cast<const float4 *>(dM + pgl * Np + 4 * c4);
+      const int n = 4 * c4, nt = n >> 5, cc = n & 31;
+      float *dst = dMs + pl * Np + cc * NT + nt;
+      dst[0] = v.x; dst[NT] = v.y; dst[2 * NT] = v.z; dst[3 * NT] = v.w;
+    }
+    __syncthreads();
+    // ---- 32 MFMA steps over the 64 staged rows ----
+#pragma unroll 4
+    for (int t = 0; t < kRC / 2; ++t) {
+      const int pl = 2 * t + h;
+      float bv[NT];
+      const float *bp = dMs + pl * Np + c * NT;
+      if constexpr (NT == 4) {
+        const float4 t4 = *reinterpret_cast<const float4 *>(bp);
+        bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
+      } else if constexpr (NT == 2) {
+        const float2 t2 = *reinterpret_cast<const float2 *>(bp);
+        bv[0] = t2.x; bv[1] = t2.y;
+      } else {
+        bv[0] = bp[0];
+      }
+#pragma unroll
+      for (int q = 0; q < kKT; ++q) {
+        const float a = X0T[pl * ld0 + iq[q]] * XkT[pl * ldk + jq[q]];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[nt], acc[q][nt], 0, 0, 0);
+      }
+    }
+  }
+  // ---- partial slab: part[split][k'][n] ----
+#pragma unroll
+  for (int q = 0; q < kKT; ++q) {
+    const int tile = group * 4 * kKT + wave * kKT + q;
+    if (tile * 32 >= Kp) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kp = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        part[((int64_t)split * Kp + kp) * Np + nt * 32 + c] = acc[q][nt][r];
+      }
+  }
+}
+
+size_t cin_dw_smem(int m, int H, int NT) {
+  return (size_t)(kRC * (((m + 1) | 1) + (cin_He(H) | 1) + 32 * NT)) * sizeof(float);
+}
+
+// dW[(i*H+j)][n] = sum_s part[s][i*He+j][n]
+__global__ void cin_dw_reduce_kernel(const float *__restrict__ part, int S, int m, int H, int N,
+                                     int Np, float *__restrict__ dW) {
+  const int He = cin_He(H), Kp = cin_Kp(m, H);
+  const int total = m * H * N;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int k = t / N, n = t - k * N;
+    const int i = k / H, j = k - i * H;
+    const int kp = i * He + j;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += part[((int64_t)s * Kp + kp) * Np + n];
+    dW[t] = acc;
+  }
+}
+
+int cin_pick_splits(int ngroups, int64_t chunks_total) {
+  int S = 256 / ngroups;
+  if (S < 1) S = 1;
+  if ((int64_t)S > chunks_total) S = (int)chunks_total;
+  return S < 1 ? 1 : S;
+}
+
 size_t cin_fwd_smem(int m, int H, int NT) {
   return (size_t)((m + 1) * kRows + cin_He(H) * kRows + 2 * 32 * 32 * NT) * sizeof(float);
 }
@@ -237,5 +587,88 @@ extern "C" int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bst
   if (NT == 1) RM_CIN_FWD(1) else if (NT == 2) RM_CIN_FWD(2) else RM_CIN_FWD(4)
 #undef RM_CIN_FWD
   RM_CHECK_LAUNCH("rm_cin_layer_fwd");
+  return RM_OK;
+}
+
+extern "C" int64_t rm_cin_bwd_workspace(int64_t B, int m, int H, int N, int D) {
+  const int NT = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
+  const int Np = 32 * NT, Kp = cin_Kp(m, H);
+  const int ngroups = (Kp / 32 + 4 * kKT - 1) / (4 * kKT);
+  const int64_t chunks_total = (B * D + kRC - 1) / kRC;
+  const int S = cin_pick_splits(ngroups, chunks_total > 0 ? chunks_total : 1);
+  return (int64_t)Kp * Np + B * D * Np + (int64_t)S * Kp * Np;
+}
+
+extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int xk_is_x0,
+                                const float *W, int act, const float *out, const float *d_hidden,
+                                int64_t dh_bstride, const float *g, const float *cin_w_direct,
+                                int pool_from, int64_t B, int m, int H, int N, int D, float *dX0,
+                                int accumulate_dx0, float *dXk, int64_t dxk_bstride, float *dW,
+                                float *dbias, float *workspace, int64_t workspace_floats,
+                                rm_stream_t stream) {
+  int rc = cin_check("rm_cin_layer_bwd", B, m, H, N, D);
+  if (rc != RM_OK) return rc;
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(kRC % D == 0, "rm_cin_layer_bwd: D=%d unsupported (must divide 64)", D);
+  RM_REQUIRE(X0 && Xk && W && out && g && dX0 && dW && dbias && workspace,
+             "rm_cin_layer_bwd: NULL argument");
+  RM_REQUIRE(pool_from >= 0 && pool_from <= N, "rm_cin_layer_bwd: bad pool_from");
+  RM_REQUIRE(pool_from == 0 || d_hidden, "rm_cin_layer_bwd: d_hidden needed when pool_from > 0");
+  RM_REQUIRE(pool_from == N || cin_w_direct, "rm_cin_layer_bwd: cin_w_direct needed");
+  RM_REQUIRE(xk_is_x0 || dXk, "rm_cin_layer_bwd: dXk needed unless Xk is X0");
+  RM_REQUIRE(!xk_is_x0 || H == m, "rm_cin_layer_bwd: xk_is_x0 needs H == m");
+  RM_REQUIRE(workspace_floats >= rm_cin_bwd_workspace(B, m, H, N, D),
+             "rm_cin_layer_bwd: workspace too small");
+  RM_REQUIRE(rm_aligned16(X0) && rm_aligned16(Xk) && rm_aligned16(dX0) && rm_aligned16(workspace) &&
+                 (!dXk || rm_aligned16(dXk)) && xk_bstride % 4 == 0 && dxk_bstride % 4 == 0,
+             "rm_cin_layer_bwd: 16-byte alignment required");
+  const int NT = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
+  const int Np = 32 * NT, Kp = cin_Kp(m, H);
+  float *Wq = workspace;
+  float *dM = Wq + (int64_t)Kp * Np;
+  float *part = dM + B * D * Np;
+  hipStream_t st = (hipStream_t)stream;
+
+  hipMemsetAsync(dbias, 0, sizeof(float) * N, st);
+  hipLaunchKernelGGL(cin_prep_bwd_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, Np, Wq);
+  {
+    const size_t smem = (size_t)(D * (Np + 1) + Np) * sizeof(float);
+    hipLaunchKernelGGL(cin_dm_kernel, dim3(rm_grid_cap(B, 256 * 8)), dim3(256), smem, st, out,
+                       d_hidden, dh_bstride, g, cin_w_direct, pool_from, act, B, N, Np, D, dM, dbias);
+  }
+  {
+    const size_t smem = cin_dx_smem(m, H, NT);
+    RM_REQUIRE(smem <= 160 * 1024, "rm_cin_layer_bwd: m=%d H=%d needs %zu B of LDS (> 160 KiB)", m, H, smem);
+    const int epb = kRowsX / D;
+    dim3 grid((unsigned)((B + epb - 1) / epb));
+#define RM_CIN_DX(NT_)                                                                        \
+  {                                                                                           \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dx_kernel<NT_>),             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);         \
+    hipLaunchKernelGGL((cin_dx_kernel<NT_>), grid, dim3(256), smem, st, X0, Xk, xk_bstride,   \
+                       xk_is_x0, Wq, dM, B, m, H, D, dX0, accumulate_dx0, dXk, dxk_bstride);  \
+  }
+    if (NT == 1) RM_CIN_DX(1) else if (NT == 2) RM_CIN_DX(2) else RM_CIN_DX(4)
+#undef RM_CIN_DX
+  }
+  {
+    const size_t smem = cin_dw_smem(m, H, NT);
+    const int ngroups = (Kp / 32 + 4 * kKT - 1) / (4 * kKT);
+    const int64_t chunks_total = (B * D + kRC - 1) / kRC;
+    const int S = cin_pick_splits(ngroups, chunks_total);
+    const int cps = (int)((chunks_total + S - 1) / S);
+    dim3 grid(ngroups, S);
+#define RM_CIN_DW(NT_)                                                                        \
+  {                                                                                           \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dw_kernel<NT_>),             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);         \
+    hipLaunchKernelGGL((cin_dw_kernel<NT_>), grid, dim3(256), smem, st, X0, Xk, xk_bstride,   \
+                       dM, B, m, H, D, cps, part);                                            \
+  }
+    if (NT == 1) RM_CIN_DW(1) else if (NT == 2) RM_CIN_DW(2) else RM_CIN_DW(4)
+#undef RM_CIN_DW
+    hipLaunchKernelGGL(cin_dw_reduce_kernel, dim3(256), dim3(256), 0, st, part, S, m, H, N, Np, dW);
+  }
+  RM_CHECK_LAUNCH("rm_cin_layer_bwd");
   return RM_OK;
 }

@@ -548,4 +548,134 @@ class DCNEngine(Engine):
         return total
 
 
-ENGINES = {"deepfm": DeepFMEngine, "dcn": DCNEngine}
+class XDeepFMEngine(Engine):
+    """xDeepFM._out (xDeepFM.py:47-104): embeddings without bias tables,
+    final = linear + cin + dnn.  CIN (layers.py:697-760) runs on the f32 MFMA, one
+    kernel per layer forward, three MFMA passes per layer backward (csrc/cin.hip)."""
+
+    model = "xdeepfm"
+    use_bias_tables = False
+
+    def __init__(self, spec, embedding_size, hp, task="classification", device="cuda"):
+        super().__init__(spec, embedding_size, hp, task, device)
+        dev = self.device
+        self.units = [int(u) for u in hp["cin_cross_layer_units"]]
+        assert len(self.units) > 0  # layers.py:656
+        self.cin_act = act_name(hp.get("cin_activation", "leaky_relu"))
+        keep = hp.get("cin_dropout")
+        if keep is not None and any(k < 1 for k in keep):
+            raise NotImplementedError("CIN dropout (keep < 1) is not supported by the HIP path yet")
+        self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
+                       hp.get("deep_activation", "leaky_relu"), dev)
+        m = self.F
+        self.Hs, self.pool_from, self.pool_col0 = [m], [], []
+        final = 0
+        for i, size in enumerate(self.units):
+            last = i == len(self.units) - 1
+            if not last and size % 2:
+                raise ValueError("CIN layer sizes before the last must be even (split in halves, layers.py:742-746)")
+            H = self.Hs[-1]
+            for nm, shape in ((f"cin_filter_{i}", (1, m * H, size)), (f"cin_bias_{i}", (size,))):
+                self.params[nm] = torch.zeros(shape, dtype=F32, device=dev)
+                self.grads[nm] = torch.zeros(shape, dtype=F32, device=dev)
+            self.pool_from.append(0 if last else size // 2)
+            self.pool_col0.append(final)
+            final += size if last else size // 2
+            self.Hs.append(size // 2)
+        self.P = final
+        for nm, shape in (("cin_w", (final, 1)), ("cin_w0", (1,))):
+            self.params[nm] = torch.zeros(shape, dtype=F32, device=dev)
+            self.grads[nm] = torch.zeros(shape, dtype=F32, device=dev)
+
+    def _alloc_model(self, B):
+        dev, m, D = self.device, self.F, self.D
+        self.maps = [torch.empty(B, n, D, dtype=F32, device=dev) for n in self.units]
+        self.dxk = [None] + [torch.empty(B, self.Hs[i], D, dtype=F32, device=dev)
+                             for i in range(1, len(self.units))]
+        self.pooled = torch.empty(B, self.P, dtype=F32, device=dev)
+        self.cin_logit = torch.empty(B, dtype=F32, device=dev)
+        fw = max(ops.cin_filter_workspace(m, self.Hs[i], n) for i, n in enumerate(self.units))
+        bw = max(ops.cin_bwd_workspace(B, m, self.Hs[i], n, D) for i, n in enumerate(self.units))
+        self.cin_fws = torch.empty(fw, dtype=F32, device=dev)
+        self.cin_bws = torch.empty(bw, dtype=F32, device=dev)
+
+    def _cin_fwd(self):
+        p = self.params
+        X0 = self.E
+        xk = X0
+        for i, n in enumerate(self.units):
+            ops.cin_layer_fwd(X0, xk, self.Hs[i], p[f"cin_filter_{i}"][0], p[f"cin_bias_{i}"],
+                              self.cin_act, self.maps[i], self.cin_fws, pooled=self.pooled,
+                              pool_col0=self.pool_col0[i], pool_from=self.pool_from[i])
+            xk = self.maps[i]
+        torch.mv(self.pooled, p["cin_w"].view(-1), out=self.cin_logit)
+        self.cin_logit.add_(p["cin_w0"])
+
+    def _branches_fwd(self, idx, dense, training, masks, lin_w):
+        hp = self.hp
+        m = (masks or {}) if training else {}
+        self._embed(idx, dense, False, m, lin_w)
+        self._cin_fwd()
+        n = len(hp["deep_hidden_units"])
+        keep = list(hp.get("deep_dropout", [1] * (n + 1))) if training else [1] * (n + 1)
+        self.dnn_logit = self.mlp.forward(self.E.view(-1, self.FD), dense if self.Dn else None, keep,
+                                          m.get("dnn"))
+        return [(self.lin_logit, 1.0), (self.cin_logit, 1.0), (self.dnn_logit, 1.0)]
+
+    def _branches_bwd(self, idx, dense, g, masks):
+        p, gr = self.params, self.grads
+        # DNN first: it STORES dLoss/dE into d_rows; every CIN layer then accumulates
+        self.mlp.backward(g, self.d_rows.view(-1, self.FD))
+        torch.mv(self.pooled.t(), g, out=gr["cin_w"].view(-1))
+        gr["cin_w0"].copy_(g.sum().view(1))
+        cw = p["cin_w"].view(-1)
+        L = len(self.units)
+        for i in range(L - 1, -1, -1):
+            n = self.units[i]
+            pf, c0 = self.pool_from[i], self.pool_col0[i]
+            ops.cin_layer_bwd(
+                self.E, self.E if i == 0 else self.maps[i - 1], self.Hs[i], p[f"cin_filter_{i}"][0],
+                self.cin_act, self.maps[i], g, self.d_rows, gr[f"cin_filter_{i}"][0],
+                gr[f"cin_bias_{i}"], self.cin_bws, xk_is_x0=(i == 0),
+                d_hidden=self.dxk[i + 1] if i + 1 < L else None,
+                cin_w_direct=cw[c0: c0 + n - pf], pool_from=pf, accumulate_dx0=True,
+                dXk=self.dxk[i] if i > 0 else None)
+        reg = self.hp.get("deep_l2_reg", 0.0)
+        if reg:
+            self.mlp.add_l2_grads(reg)
+        reg = self.hp.get("cin_l2_reg", 0.0)
+        if reg:
+            for i in range(L):
+                gr[f"cin_filter_{i}"].add_(p[f"cin_filter_{i}"], alpha=reg)
+            gr["cin_w"].add_(p["cin_w"], alpha=reg)
+
+    def _add_l2_model(self, total):
+        reg = self.hp.get("deep_l2_reg", 0.0)
+        if reg:
+            total = total + self.mlp.l2(reg)
+        reg = self.hp.get("cin_l2_reg", 0.0)
+        if reg:
+            ws = [self.params[f"cin_filter_{i}"] for i in range(len(self.units))] + [self.params["cin_w"]]
+            total = total + sum(reg * 0.5 * w.square().sum() for w in ws)
+        return total
+
+    def _dominant_kernel(self, idx, dense):
+        # the heaviest CIN forward layer on the f32 MFMA roofline
+        B, m, D = idx.shape[0], self.F, self.D
+        i = max(range(len(self.units)), key=lambda k: self.Hs[k] * self.units[k])
+        H, n = self.Hs[i], self.units[i]
+        xk = self.E if i == 0 else self.maps[i - 1]
+        p = self.params
+        self._embed(idx, dense, False, None)
+        self._cin_fwd()
+
+        def fn():
+            ops.cin_layer_fwd(self.E, xk, H, p[f"cin_filter_{i}"][0], p[f"cin_bias_{i}"],
+                              self.cin_act, self.maps[i], self.cin_fws, pooled=self.pooled,
+                              pool_col0=self.pool_col0[i], pool_from=self.pool_from[i])
+
+        return (f"cin_fwd_kernel<4> (rm_cin_layer_fwd, layer {i}: m={m} H={H} N={n})", fn,
+                2.0 * B * D * m * H * n, "mfma")
+
+
+ENGINES = {"deepfm": DeepFMEngine, "dcn": DCNEngine, "xdeepfm": XDeepFMEngine}

@@ -67,3 +67,61 @@ def test_cin_notebook_kat_on_gpu(hip_lib):
     assert out0[0, 0].tolist() == [36, 64, 100, 144]
     assert out1[0, 0].tolist() == [1728, 4096, 8000, 13824]
     assert pooled[0].tolist() == [344] * 8 + [27648] * 16
+
+
+@pytest.mark.parametrize("B,m,H,N,D,act,first,last", [
+    (5, 2, 2, 16, 4, "identity", True, True),
+    (33, 5, 5, 12, 8, "leaky_relu", True, False),
+    (21, 26, 26, 128, 16, "leaky_relu", True, False),
+    (21, 26, 64, 128, 16, "leaky_relu", False, True),
+    (17, 7, 3, 40, 16, "relu", False, False),
+    (9, 6, 25, 100, 32, "leaky_relu", False, True),
+    (6, 4, 8, 64, 64, "relu", False, False),
+    (70, 3, 3, 8, 16, "leaky_relu", True, False),   # several dX blocks and dW chunks
+])
+def test_cin_layer_bwd(hip_lib, B, m, H, N, D, act, first, last):
+    """autograd (float64) of the oracle's layer formula vs rm_cin_layer_bwd."""
+    from recman_amd import ops
+
+    g_ = torch.Generator().manual_seed(B * 7 + N)
+    X0 = torch.randn(B, m, D, generator=g_, dtype=torch.float64, requires_grad=True)
+    if first:
+        Xk = X0
+    else:
+        Xk = torch.randn(B, H, D, generator=g_, dtype=torch.float64, requires_grad=True)
+    W = (torch.randn(m * H, N, generator=g_, dtype=torch.float64) * 0.2).requires_grad_(True)
+    bias = (torch.randn(N, generator=g_, dtype=torch.float64) * 0.1).requires_grad_(True)
+    pool_from = 0 if last else N // 2
+    cw = torch.randn(N - pool_from, generator=g_, dtype=torch.float64)
+    gvec = torch.randn(B, generator=g_, dtype=torch.float64)
+    dh = torch.randn(B, pool_from, D, generator=g_, dtype=torch.float64) if pool_from else None
+    Z = torch.einsum("bid,bjd->bdij", X0, Xk).reshape(B, D, -1)
+    out = T.act_fn(act)(Z @ W + bias).transpose(1, 2)  # [B,N,D]
+    obj = (out[:, pool_from:].sum(-1) * cw * gvec[:, None]).sum()
+    if pool_from:
+        obj = obj + (out[:, :pool_from] * dh).sum()
+    obj.backward()
+
+    f = lambda t: t.detach().float().cuda().contiguous()
+    out_d = f(out)
+    dX0 = torch.full((B, m, D), 0.5, device="cuda")  # accumulate onto a known value
+    dXk = None if first else torch.empty(B, H, D, device="cuda")
+    dW = torch.empty(m * H, N, device="cuda")
+    dbias = torch.empty(N, device="cuda")
+    ws = torch.empty(ops.cin_bwd_workspace(B, m, H, N, D), device="cuda")
+    ops.cin_layer_bwd(f(X0), f(Xk), H, f(W), act, out_d, f(gvec), dX0, dW, dbias, ws,
+                      xk_is_x0=first, d_hidden=f(dh) if pool_from else None, cin_w_direct=f(cw),
+                      pool_from=pool_from, accumulate_dx0=True, dXk=dXk)
+    torch.cuda.synchronize()
+
+    def close(got, want, what):
+        want = want.double()
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= 2e-5 * scale, f"{what}: {err:.3e} (scale {scale:.3e})"
+
+    close(dX0 - 0.5, X0.grad, "dX0")
+    if not first:
+        close(dXk, Xk.grad, "dXk")
+    close(dW, W.grad, "dW")
+    close(dbias, bias.grad, "dbias")

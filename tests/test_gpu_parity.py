@@ -169,3 +169,13 @@ def test_error_reporting_is_loud(hip_lib):
         t = torch.zeros(4, 12).cuda()  # D = 12: G = 3 does not divide a wave
         ops.embed_fwd(torch.zeros(2, 2, dtype=torch.int64).cuda(), t,
                       torch.zeros(2, dtype=torch.int64).cuda(), E=torch.empty(2, 2, 12).cuda())
+
+
+@pytest.mark.parametrize("units,D", [((12, 10), 8), ((16,), 16), ((32, 32, 16), 16)])
+def test_xdeepfm_fwd_bwd_matches_oracle(hip_lib, units, D):
+    _check_model("xdeepfm", hip_lib, D=D, cin_units=units, scale=0.2)
+
+
+def test_xdeepfm_criteo_like_shape(hip_lib):
+    _check_model("xdeepfm", hip_lib, D=16, B=70, F=26, Dn=13, hidden=(32, 32), cin_units=(128, 128),
+                 scale=0.05)
