@@ -96,47 +96,54 @@ def algorithmic_bytes_embed_fwd(B, F, D, Dn, fm, lin):
     return B * per
 
 
-def cpu_baseline(w, hp, idx, dense, y, engine, sample, iters=5, warm=2):
+def cpu_baseline(w, hp, idx, dense, y, engine, budget_s=20.0):
     """The CPU PyTorch restatement (oracle/, kind "port") on the host cores, same
     inputs and weights, fwd+bwd, sparse embedding gradients (what TF's IndexedSlices
-    are with embedding_l2_reg = 0).  Bounded sample of the workload's batch."""
+    are with embedding_l2_reg = 0).  BOUNDED: a probe pass on 1024 examples sizes the
+    sample so that the timed passes take about `budget_s` seconds in total."""
     from oracle import th_layers as T
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
     spec = T.Spec(engine.spec.sparse_names, engine.spec.feat_sizes, engine.spec.dense_names)
     p = {k: v.detach().cpu() for k, v in engine.state_dict().items()}
-    idx_c, dense_c, y_c = idx[:sample].cpu(), dense[:sample].cpu(), y[:sample].cpu()
-    hp_c = dict(hp)
-    chunk = 4096 if w["model"] == "xdeepfm" else sample
+    B = idx.shape[0]
+    idx_c, dense_c, y_c = idx.cpu(), dense.cpu(), y.cpu()
+    chunk_max = 4096 if w["model"] == "xdeepfm" else 1 << 30
 
-    def step():
+    def step(sample):
         leaves = {k: v.requires_grad_(True) for k, v in p.items()}
         for v in leaves.values():
             v.grad = None
-        total = 0.0
         logits = []
-        for s in range(0, sample, chunk):
-            sl = slice(s, min(sample, s + chunk))
+        chunk = min(sample, chunk_max)
+        for s0 in range(0, sample, chunk):
+            sl = slice(s0, min(sample, s0 + chunk))
             loss, logit, _ = T.model_loss(w["model"], leaves, spec, idx_c[sl], dense_c[sl], y_c[sl],
-                                          hp_c, sparse_grad=True)
+                                          hp, sparse_grad=True)
             (loss * (sl.stop - sl.start) / sample).backward()
-            total += float(loss) * (sl.stop - sl.start) / sample
             logits.append(logit.detach().reshape(-1))
-        return total, torch.cat(logits)
+        return torch.cat(logits)
 
-    for _ in range(warm):
-        step()
+    step(min(B, 1024))
+    t0 = time.perf_counter()
+    step(min(B, 1024))
+    probe = time.perf_counter() - t0
+    iters = 3
+    sample = int(min(B, max(1024, 1024 * (budget_s / (iters + 1)) / max(probe, 1e-4))))
+    sample = max(1024, (sample // 1024) * 1024) if B >= 1024 else B
+    step(sample)
     ts = []
     for _ in range(iters):
         t0 = time.perf_counter()
-        _, logit = step()
+        logit = step(sample)
         ts.append(time.perf_counter() - t0)
     ts.sort()
     med = ts[len(ts) // 2]
-    return dict(value=sample / med, unit="examples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{sample} examples of the same batch, {iters} timed fwd+bwd passes (median), "
-                       f"oracle/th_layers.py, sparse embedding grads"
-                       + (f", CIN in chunks of {chunk}" if chunk != sample else "")), logit
+    return dict(value=round(sample / med, 1), unit="examples/s", cores=torch.get_num_threads(),
+                kind="port",
+                sample=f"first {sample} examples of the same batch, {iters} timed fwd+bwd passes "
+                       f"(median {med:.2f} s), oracle/th_layers.py on torch CPU, sparse embedding grads"
+                       + (f", CIN in chunks of {chunk_max}" if chunk_max < sample else "")), logit, sample
 
 
 def main():
@@ -236,8 +243,7 @@ def main():
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        sample = min(B, 16384 if w["model"] == "xdeepfm" else B)
-        base, logit_cpu = cpu_baseline(w, hp, idx, dense, y, engine, sample)
+        base, logit_cpu, sample = cpu_baseline(w, hp, idx, dense, y, engine)
         out["cpu_baseline"] = base
         engine.forward(idx[:sample].contiguous(), dense[:sample].contiguous(), training=True)
         err = float((engine.logit[:sample].cpu() - logit_cpu).abs().max())

@@ -105,8 +105,10 @@ int rm_scatter_add_rows(const int64_t *idx, const int64_t *field_off, const floa
                         const float *g_row, int64_t B, int F, int width, int64_t ld,
                         float *d_table, rm_stream_t stream);
 
-/* Dense part of the linear-layer backward: d_w_dense[j] = sum_b g[b]*dense[b,j],
- * d_w0 = sum_b g[b].  Deterministic two-stage reduction; workspace >= 256*(Dn+1) floats. */
+/* Weighted column sums: d_w_dense[j] = sum_b g[b]*dense[b,j] (j < Dn <= 1023),
+ * d_w0 = sum_b g[b].  The dense part of the linear-layer backward, and the gradient of
+ * every [*,1] output projection (d cin_w = pooled^T g, d dnn_w = a^T g).  Deterministic
+ * two-stage reduction; workspace >= 256*(Dn+1) floats; either output may be NULL. */
 int rm_linear_dense_bwd(const float *g, const float *dense, int64_t B, int Dn,
                         float *d_w_dense, float *d_w0, float *workspace, rm_stream_t stream);
 
@@ -128,6 +130,11 @@ int rm_logit_loss(const float *logit_a, float coef_a, const float *logit_b, floa
                   const int64_t *y, const float *y_f, int task, int64_t B, float *logit,
                   float *pred, float *dlogit, float *loss, float *workspace,
                   rm_stream_t stream);
+
+/* out[b] = sum_j X[b,j]*w[j] + w0[0]: the [*,1] output projections (dnn_w/dnn_w0,
+ * layers.py:606-609; cin_w/cin_w0, layers.py:757-760).  w0 may be NULL. */
+int rm_rowdot(const float *X, const float *w, const float *w0, int64_t B, int P, float *out,
+              rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * CrossNet (DCN v1, vector form), all L layers fused.

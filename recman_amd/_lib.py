@@ -30,6 +30,7 @@ SIGNATURES = {
     "rm_linear_dense_bwd": [P, P, I64, c_int, P, P, P, P],
     "rm_logit_loss": [P, c_float, P, c_float, P, c_float, P, c_float, P, P, c_int, I64, P, P, P,
                       P, P, P],
+    "rm_rowdot": [P, P, P, I64, c_int, P, P],
     "rm_cross_fwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P],
     "rm_cross_bwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P, P, P, P, P, P],
     "rm_cross_param_grads": [P, P, P, P, P, c_int, c_int, P, P, P, P],

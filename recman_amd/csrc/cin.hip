@@ -233,24 +233,31 @@ __global__ __launch_bounds__(256) void cin_dm_kernel(
   if (tid < N && dbias != nullptr) atomicAdd(dbias + tid, colsum[tid]);
 }
 
+// dX-kernel k' ordering: k' = i*Hp + j with Hp = H rounded up to 32, so that every
+// 32-row k'-tile has ONE i and a compile-time j per accumulator register.
+__host__ __device__ inline int cin_Hp(int H) { return H <= 32 ? 32 : (H <= 64 ? 64 : 128); }
+
 // Wq[k'][n] = W[(i*H+j)*N + n] (zero where padded): the A-operand source of the dX kernel.
 __global__ void cin_prep_bwd_kernel(const float *__restrict__ W, int m, int H, int N, int Np,
                                     float *__restrict__ Wq) {
-  const int He = cin_He(H), Kp = cin_Kp(m, H);
-  const int total = Kp * Np;
+  const int Hp = cin_Hp(H);
+  const int total = m * Hp * Np;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
     const int kp = t / Np, n = t - kp * Np;
-    const int i = kp / He, j = kp - i * He;
-    Wq[t] = (i < m && j < H && n < N) ? W[(int64_t)(i * H + j) * N + n] : 0.f;
+    const int i = kp / Hp, j = kp - i * Hp;
+    Wq[t] = (j < H && n < N) ? W[(int64_t)(i * H + j) * N + n] : 0.f;
   }
 }
 
 constexpr int kRowsX = 128;  // rows per dX block (4 waves x 32)
 
 // dZ^T tile [32 k'][32 rows] = W[k'][:] . dM[row][:]^T on the MFMA (A = filter chunk from
-// LDS, B = the lane's own dM row kept in registers), then contracted on the fly:
-//   dX0[i][row] += dZ * Xk[j][row],   dXk[j][row] += dZ * X0[i][row]     (LDS float atomics)
-template <int NT>
+// LDS, B = the lane's own dM row kept in registers), contracted on the fly IN REGISTERS:
+//   dX0[i][row] = sum_j dZ * Xk[j][row]   (scalar per lane per i; the two lane halves
+//                                          are added with one cross-lane move)
+//   dXk[j][row] += dZ * X0[i][row]        (JB*16 registers per lane, j static per register)
+// No LDS atomics: an earlier version contracted with ds_add_f32 and ran 8x slower.
+template <int NT, int JB>
 __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
     const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride, int xk_is_x0,
     const float *__restrict__ Wq, const float *__restrict__ dM, int64_t B, int m, int H, int D,
@@ -258,14 +265,11 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int Np = 32 * NT;
   constexpr int LDW = Np + 4;
-  const int He = cin_He(H);
-  const int Kp = cin_Kp(m, H);
-  float *X0s = smem;                         // [(m+1)][128]
-  float *Xks = X0s + (m + 1) * kRowsX;       // [He][128]
-  float *dX0s = Xks + He * kRowsX;           // [(m+1)][128]
-  float *dXks = dX0s + (m + 1) * kRowsX;     // [He][128]
-  float *Wt = dXks + He * kRowsX;            // [2][32][LDW]
-  int2 *tab = reinterpret_cast<int2 *>(Wt + 2 * 32 * LDW);  // [Kp] (i*128, j*128)
+  constexpr int Hp = 32 * JB;
+  float *X0s = smem;                         // [m][128]
+  float *Xks = X0s + m * kRowsX;             // [Hp][128] (rows >= H zero)
+  float *dX0s = Xks + Hp * kRowsX;           // [m][128]
+  float *Wt = dX0s + m * kRowsX;             // [2][32][LDW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
   const int epb = kRowsX / D;
   const int64_t b0 = (int64_t)blockIdx.x * epb;
@@ -278,22 +282,12 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
     const float4 v = b < B ? *reinterpret_cast<const float4 *>(X0 + (b * m + i) * D + 4 * d4) : z4;
     *reinterpret_cast<float4 *>(X0s + i * kRowsX + bl * D + 4 * d4) = v;
   }
-  for (int t = tid; t < epb * H * D4; t += 256) {
-    const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
+  for (int t = tid; t < epb * Hp * D4; t += 256) {
+    const int d4 = t % D4, j = (t / D4) % Hp, bl = t / (D4 * Hp);
     const int64_t b = b0 + bl;
-    const float4 v =
-        b < B ? *reinterpret_cast<const float4 *>(Xk + b * xk_bstride + (int64_t)j * D + 4 * d4) : z4;
+    const float4 v = (b < B && j < H)
+        ? *reinterpret_cast<const float4 *>(Xk + b * xk_bstride + (int64_t)j * D + 4 * d4) : z4;
     *reinterpret_cast<float4 *>(Xks + j * kRowsX + bl * D + 4 * d4) = v;
-  }
-  if (tid < kRowsX) {
-    X0s[m * kRowsX + tid] = 0.f;
-    if (He > H) Xks[H * kRowsX + tid] = 0.f;
-  }
-  for (int t = tid; t < (m + 1) * kRowsX; t += 256) dX0s[t] = 0.f;
-  for (int t = tid; t < He * kRowsX; t += 256) dXks[t] = 0.f;
-  for (int t = tid; t < Kp; t += 256) {
-    const int i = t / He, j = t - i * He;
-    tab[t] = make_int2((i < m ? i : m) * kRowsX, j * kRowsX);
   }
   // the lane's own dM row, in MFMA B-operand order: step s=4u+q <-> n = 8u + 4h + q
   const int prow = wave * 32 + c;
@@ -314,47 +308,70 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
   }
   __syncthreads();
 
-  const int ntiles = Kp / 32;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    float4 pf[F4];
-    if (kt + 1 < ntiles) {
+  // Xk values of this lane's (row, j) pairs and the dXk accumulators: register r of
+  // j-block jb <-> j = jb*32 + (r&3) + 8*(r>>2) + 4h
+  float xkr[JB][16], dxk[JB][16];
 #pragma unroll
-      for (int q = 0; q < F4; ++q) {
-        const int f = tid + q * 256, row = f / (Np / 4), c4 = f - row * (Np / 4);
-        pf[q] = *reinterpret_cast<const float4 *>(Wq + ((int64_t)(kt + 1) * 32 + row) * Np + 4 * c4);
-      }
-    }
-    const float *Wb = Wt + (kt & 1) * 32 * LDW;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int u = 0; u < Np / 8; ++u) {
-      const float4 a4 = *reinterpret_cast<const float4 *>(Wb + c * LDW + 8 * u + 4 * h);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, dm[4 * u + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, dm[4 * u + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, dm[4 * u + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, dm[4 * u + 3], acc, 0, 0, 0);
-    }
-    // acc[r] = dZ[row = prow][k' = kt*32 + (r&3) + 8*(r>>2) + 4h]
+  for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int kp = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int2 ij = tab[kp];
-      const float x0 = X0s[ij.x + prow], xk = Xks[ij.y + prow];
-      atomicAdd(dX0s + ij.x + prow, acc[r] * xk);
-      atomicAdd(dXks + ij.y + prow, acc[r] * x0);
+      xkr[jb][r] = Xks[(jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * kRowsX + prow];
+      dxk[jb][r] = 0.f;
     }
-    if (kt + 1 < ntiles) {
-      float *Wn = Wt + ((kt + 1) & 1) * 32 * LDW;
+
+  const int ntiles = m * JB;
+  int kt = 0;
+  for (int i = 0; i < m; ++i) {
+    const float x0v = X0s[i * kRowsX + prow];
+    float dx0 = 0.f;
 #pragma unroll
-      for (int q = 0; q < F4; ++q) {
-        const int f = tid + q * 256, row = f / (Np / 4), c4 = f - row * (Np / 4);
-        *reinterpret_cast<float4 *>(Wn + row * LDW + 4 * c4) = pf[q];
+    for (int jb = 0; jb < JB; ++jb, ++kt) {
+      float4 pf[F4];
+      if (kt + 1 < ntiles) {
+#pragma unroll
+        for (int q = 0; q < F4; ++q) {
+          const int f = tid + q * 256, row = f / (Np / 4), c4 = f - row * (Np / 4);
+          pf[q] = *reinterpret_cast<const float4 *>(Wq + ((int64_t)(kt + 1) * 32 + row) * Np + 4 * c4);
+        }
       }
+      const float *Wb = Wt + (kt & 1) * 32 * LDW;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < Np / 8; ++u) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(Wb + c * LDW + 8 * u + 4 * h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, dm[4 * u + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, dm[4 * u + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, dm[4 * u + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, dm[4 * u + 3], acc, 0, 0, 0);
+      }
+      // acc[r] = dZ[row = prow][(i, j = jb*32 + (r&3) + 8*(r>>2) + 4h)]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dx0 += acc[r] * xkr[jb][r];
+        dxk[jb][r] += acc[r] * x0v;
+      }
+      if (kt + 1 < ntiles) {
+        float *Wn = Wt + ((kt + 1) & 1) * 32 * LDW;
+#pragma unroll
+        for (int q = 0; q < F4; ++q) {
+          const int f = tid + q * 256, row = f / (Np / 4), c4 = f - row * (Np / 4);
+          *reinterpret_cast<float4 *>(Wn + row * LDW + 4 * c4) = pf[q];
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    dx0 += __shfl_xor(dx0, 32, 64);  // the two lane halves hold disjoint j sets
+    if (h == 0) dX0s[i * kRowsX + prow] = dx0;
   }
+  // dXk -> LDS (reusing the Xk image: every (j,row) is owned by exactly one lane)
+#pragma unroll
+  for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      Xks[(jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * kRowsX + prow] = dxk[jb][r];
+  __syncthreads();
 
   for (int t = tid; t < epb * m * D4; t += 256) {
     const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
@@ -362,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
     if (b >= B) continue;
     float4 v = *reinterpret_cast<const float4 *>(dX0s + i * kRowsX + bl * D + 4 * d4);
     if (xk_is_x0) {
-      const float4 w = *reinterpret_cast<const float4 *>(dXks + i * kRowsX + bl * D + 4 * d4);
+      const float4 w = *reinterpret_cast<const float4 *>(Xks + i * kRowsX + bl * D + 4 * d4);
       v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
     }
     float4 *dst = reinterpret_cast<float4 *>(dX0 + (b * m + i) * D + 4 * d4);
@@ -378,15 +395,14 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
       const int64_t b = b0 + bl;
       if (b >= B) continue;
       *reinterpret_cast<float4 *>(dXk + b * dxk_bstride + (int64_t)j * D + 4 * d4) =
-          *reinterpret_cast<const float4 *>(dXks + j * kRowsX + bl * D + 4 * d4);
+          *reinterpret_cast<const float4 *>(Xks + j * kRowsX + bl * D + 4 * d4);
     }
   }
 }
 
 size_t cin_dx_smem(int m, int H, int NT) {
   const int Np = 32 * NT;
-  return (size_t)(2 * (m + 1 + cin_He(H)) * kRowsX + 2 * 32 * (Np + 4)) * sizeof(float) +
-         (size_t)cin_Kp(m, H) * sizeof(int2);
+  return (size_t)((2 * m + cin_Hp(H)) * kRowsX + 2 * 32 * (Np + 4)) * sizeof(float);
 }
 
 // dW partial: part[s][k'][n] = sum over the split's rows p of Z[p][k'] * dM[p][n].
@@ -551,6 +567,7 @@ extern "C" int64_t rm_cin_filter_workspace(int m, int H, int N) {
 static int cin_check(const char *fn, int64_t B, int m, int H, int N, int D) {
   RM_REQUIRE(B >= 0 && m > 0 && H > 0 && N > 0 && D > 0, "%s: bad sizes", fn);
   RM_REQUIRE(N <= 128, "%s: N=%d unsupported (<= 128 filters per layer)", fn, N);
+  RM_REQUIRE(H <= 128, "%s: H=%d unsupported (<= 128 hidden maps)", fn, H);
   RM_REQUIRE(D % 4 == 0 && kRows % D == 0, "%s: D=%d unsupported (must divide 256, multiple of 4)", fn, D);
   return RM_OK;
 }
@@ -596,7 +613,7 @@ extern "C" int64_t rm_cin_bwd_workspace(int64_t B, int m, int H, int N, int D) {
   const int ngroups = (Kp / 32 + 4 * kKT - 1) / (4 * kKT);
   const int64_t chunks_total = (B * D + kRC - 1) / kRC;
   const int S = cin_pick_splits(ngroups, chunks_total > 0 ? chunks_total : 1);
-  return (int64_t)Kp * Np + B * D * Np + (int64_t)S * Kp * Np;
+  return (int64_t)m * cin_Hp(H) * Np + B * D * Np + (int64_t)S * Kp * Np;
 }
 
 extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int xk_is_x0,
@@ -625,7 +642,7 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
   const int NT = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
   const int Np = 32 * NT, Kp = cin_Kp(m, H);
   float *Wq = workspace;
-  float *dM = Wq + (int64_t)Kp * Np;
+  float *dM = Wq + (int64_t)m * cin_Hp(H) * Np;
   float *part = dM + B * D * Np;
   hipStream_t st = (hipStream_t)stream;
 
@@ -641,14 +658,22 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
     RM_REQUIRE(smem <= 160 * 1024, "rm_cin_layer_bwd: m=%d H=%d needs %zu B of LDS (> 160 KiB)", m, H, smem);
     const int epb = kRowsX / D;
     dim3 grid((unsigned)((B + epb - 1) / epb));
-#define RM_CIN_DX(NT_)                                                                        \
+#define RM_CIN_DX(NT_, JB_)                                                                   \
   {                                                                                           \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dx_kernel<NT_>),             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dx_kernel<NT_, JB_>),        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);         \
-    hipLaunchKernelGGL((cin_dx_kernel<NT_>), grid, dim3(256), smem, st, X0, Xk, xk_bstride,   \
-                       xk_is_x0, Wq, dM, B, m, H, D, dX0, accumulate_dx0, dXk, dxk_bstride);  \
+    hipLaunchKernelGGL((cin_dx_kernel<NT_, JB_>), grid, dim3(256), smem, st, X0, Xk,          \
+                       xk_bstride, xk_is_x0, Wq, dM, B, m, H, D, dX0, accumulate_dx0, dXk,    \
+                       dxk_bstride);                                                          \
   }
-    if (NT == 1) RM_CIN_DX(1) else if (NT == 2) RM_CIN_DX(2) else RM_CIN_DX(4)
+#define RM_CIN_DX_JB(NT_)                                                  \
+  {                                                                        \
+    if (JB == 1) RM_CIN_DX(NT_, 1) else if (JB == 2) RM_CIN_DX(NT_, 2)     \
+    else RM_CIN_DX(NT_, 4)                                                 \
+  }
+    const int JB = cin_Hp(H) / 32;  // 1, 2 or 4
+    if (NT == 1) RM_CIN_DX_JB(1) else if (NT == 2) RM_CIN_DX_JB(2) else RM_CIN_DX_JB(4)
+#undef RM_CIN_DX_JB
 #undef RM_CIN_DX
   }
   {

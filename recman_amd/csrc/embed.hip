@@ -168,41 +168,46 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(
   }
 }
 
-// d_w_dense[j] = sum_b g[b]*dense[b,j]; d_w0 = sum_b g[b].  Stage 1: one partial
-// per block; stage 2 (last launch) sums the partials in block order: deterministic.
-__global__ __launch_bounds__(kBlock) void linear_dense_bwd_stage1(
-    const float *__restrict__ g, const float *__restrict__ dense, int64_t B, int Dn,
-    float *__restrict__ partial) {
-  extern __shared__ float sm[];  // [4 waves][Dn+1]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int cols = Dn + 1;
-  for (int j = 0; j < cols; ++j) {
+// out[j] = sum_b g[b]*X[b,j] (j < P) and out0 = sum_b g[b].  Stage 1: coalesced along
+// the columns, one partial row [P+1] per block; stage 2: one wave per column sums the
+// partials in a fixed order -> deterministic.
+__global__ __launch_bounds__(kBlock) void colsum_w_stage1(const float *__restrict__ g,
+                                                          const float *__restrict__ X, int64_t B,
+                                                          int P, int Pp, float *__restrict__ partial) {
+  extern __shared__ float sm[];  // [kBlock]
+  const int col = threadIdx.x % Pp, rsub = threadIdx.x / Pp, rper = kBlock / Pp;
+  const int64_t rows_per_block = (B + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
+  for (int c0 = 0; c0 < P + 1; c0 += Pp) {
+    const int j = c0 + col;
     float acc = 0.f;
-    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride)
-      acc += j < Dn ? g[b] * dense[b * Dn + j] : g[b];
-    acc = rm_wave_sum(acc);
-    if (lane == 0) sm[wave * cols + j] = acc;
-  }
-  __syncthreads();
-  if (threadIdx.x < cols) {
-    float acc = 0.f;
-    for (int w = 0; w < kBlock / 64; ++w) acc += sm[w * cols + threadIdx.x];
-    partial[(int64_t)blockIdx.x * cols + threadIdx.x] = acc;
+    if (j <= P) {
+      for (int64_t r = r0 + rsub; r < r1; r += rper) acc += j < P ? g[r] * X[r * P + j] : g[r];
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (rsub == 0 && j <= P) {
+      float t = 0.f;
+      for (int q = 0; q < rper; ++q) t += sm[q * Pp + col];
+      partial[(int64_t)blockIdx.x * (P + 1) + j] = t;
+    }
+    __syncthreads();
   }
 }
 
-__global__ void linear_dense_bwd_stage2(const float *__restrict__ partial, int nblk, int Dn,
-                                        float *__restrict__ d_w_dense, float *__restrict__ d_w0) {
-  const int j = threadIdx.x;
-  const int cols = Dn + 1;
-  if (j >= cols) return;
+__global__ void colsum_w_stage2(const float *__restrict__ partial, int nblk, int P,
+                                float *__restrict__ out, float *__restrict__ out0) {
+  const int j = blockIdx.x;  // column, P = the sum of g
   float acc = 0.f;
-  for (int i = 0; i < nblk; ++i) acc += partial[(int64_t)i * cols + j];
-  if (j < Dn) {
-    if (d_w_dense != nullptr) d_w_dense[j] = acc;
-  } else if (d_w0 != nullptr) {
-    d_w0[0] = acc;
+  for (int i = threadIdx.x; i < nblk; i += 64) acc += partial[(int64_t)i * (P + 1) + j];
+  acc = rm_wave_sum(acc);
+  if (threadIdx.x == 0) {
+    if (j < P) {
+      if (out != nullptr) out[j] = acc;
+    } else if (out0 != nullptr) {
+      out0[0] = acc;
+    }
   }
 }
 
@@ -350,13 +355,15 @@ extern "C" int rm_scatter_add_rows(const int64_t *idx, const int64_t *field_off,
 extern "C" int rm_linear_dense_bwd(const float *g, const float *dense, int64_t B, int Dn,
                                    float *d_w_dense, float *d_w0, float *workspace,
                                    rm_stream_t stream) {
-  RM_REQUIRE(B >= 0 && Dn >= 0 && Dn <= 255, "rm_linear_dense_bwd: bad sizes (Dn <= 255)");
+  RM_REQUIRE(B >= 0 && Dn >= 0 && Dn <= 1023, "rm_linear_dense_bwd: bad sizes (Dn <= 1023)");
   RM_REQUIRE(g && workspace && (Dn == 0 || dense), "rm_linear_dense_bwd: NULL argument");
-  const int nblk = rm_grid_cap((B + kBlock - 1) / kBlock, 256);
+  int Pp = 1;
+  while (Pp < Dn + 1 && Pp < kBlock) Pp <<= 1;
+  const int nblk = rm_grid_cap((B + 255) / 256, 256);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(linear_dense_bwd_stage1, dim3(nblk), dim3(kBlock),
-                     (kBlock / 64) * (Dn + 1) * sizeof(float), st, g, dense, B, Dn, workspace);
-  hipLaunchKernelGGL(linear_dense_bwd_stage2, dim3(1), dim3(256), 0, st, workspace, nblk, Dn,
+  hipLaunchKernelGGL(colsum_w_stage1, dim3(nblk), dim3(kBlock), kBlock * sizeof(float), st, g,
+                     dense, B, Dn, Pp, workspace);
+  hipLaunchKernelGGL(colsum_w_stage2, dim3(Dn + 1), dim3(64), 0, st, workspace, nblk, Dn,
                      d_w_dense, d_w0);
   RM_CHECK_LAUNCH("rm_linear_dense_bwd");
   return RM_OK;

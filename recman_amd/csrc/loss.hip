@@ -64,7 +64,46 @@ __global__ void loss_finish_kernel(const float *__restrict__ partial, int n, flo
   if (threadIdx.x == 0) loss[0] = acc * invB;
 }
 
+// out[b] = sum_j X[b,j]*w[j] + w0 : 16 lanes per row, float4 loads when P % 4 == 0
+__global__ __launch_bounds__(kBlock) void rowdot_kernel(const float *__restrict__ X,
+                                                        const float *__restrict__ w,
+                                                        const float *__restrict__ w0, int64_t B,
+                                                        int P, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, ex = lane >> 4;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+  const float bias = w0 ? w0[0] : 0.f;
+  for (int64_t b0 = wave * 4; b0 < B; b0 += nwaves * 4) {
+    const int64_t b = b0 + ex;
+    const int64_t bb = b < B ? b : B - 1;
+    float acc = 0.f;
+    if ((P & 3) == 0) {
+      for (int j = sub * 4; j < P; j += 64) {
+        const float4 x = *reinterpret_cast<const float4 *>(X + bb * P + j);
+        const float4 ww = *reinterpret_cast<const float4 *>(w + j);
+        acc += x.x * ww.x + x.y * ww.y + x.z * ww.z + x.w * ww.w;
+      }
+    } else {
+      for (int j = sub; j < P; j += 16) acc += X[bb * P + j] * w[j];
+    }
+    acc = rm_group_sum<16>(acc);
+    if (b < B && sub == 0) out[b] = acc + bias;
+  }
+}
+
 }  // namespace
+
+extern "C" int rm_rowdot(const float *X, const float *w, const float *w0, int64_t B, int P,
+                         float *out, rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && P > 0, "rm_rowdot: bad sizes");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(X && w && out, "rm_rowdot: NULL argument");
+  RM_REQUIRE((P & 3) != 0 || (rm_aligned16(X) && rm_aligned16(w)), "rm_rowdot: unaligned");
+  hipLaunchKernelGGL(rowdot_kernel, dim3(rm_grid_cap((B + 15) / 16, 256 * 8)), dim3(kBlock), 0,
+                     (hipStream_t)stream, X, w, w0, B, P, out);
+  RM_CHECK_LAUNCH("rm_rowdot");
+  return RM_OK;
+}
 
 extern "C" int rm_logit_loss(const float *logit_a, float coef_a, const float *logit_b,
                              float coef_b, const float *logit_c, float coef_c,

@@ -91,6 +91,7 @@ class MLP:
             params[nm] = torch.zeros(shape, dtype=F32, device=device)
             grads[nm] = torch.zeros(shape, dtype=F32, device=device)
         self._B = None
+        self._ws = None
 
     def _alloc(self, B, device):
         if self._B == B:
@@ -134,7 +135,7 @@ class MLP:
             self._act_(a)
             if self.keep[i + 1] < 1 and self.masks[i + 1] is not None:
                 a.mul_(self.masks[i + 1] / self.keep[i + 1])
-        torch.addmm(p[f"{pre}dnn_w0"], self.a[-1], p[f"{pre}dnn_w"], out=self.out)
+        ops.rowdot(self.a[-1], p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"], self.out.view(B))
         return self.out.view(B)
 
     def backward(self, g, dxe):
@@ -143,8 +144,9 @@ class MLP:
         p, gr, pre = self.p, self.g, self.prefix
         n = len(self.hidden)
         g2 = g.view(-1, 1)
-        torch.mm(self.a[-1].t(), g2, out=gr[f"{pre}dnn_w"])
-        gr[f"{pre}dnn_w0"].copy_(g.sum().view(1))
+        if self._ws is None or self._ws.device != g.device:
+            self._ws = torch.empty(256 * 1024, dtype=F32, device=g.device)
+        ops.linear_dense_bwd(g, self.a[-1], gr[f"{pre}dnn_w"].view(-1), gr[f"{pre}dnn_w0"], self._ws)
         da = self.da[-1]
         torch.mm(g2, p[f"{pre}dnn_w"].t(), out=da)
         for i in range(n - 1, -1, -1):
@@ -248,7 +250,7 @@ class Engine:
         self.pred = torch.empty(B, dtype=F32, device=dev)
         self.dlogit = torch.empty(B, dtype=F32, device=dev)
         self.loss = torch.zeros(1, dtype=F32, device=dev)
-        self.ws = torch.empty(max(1024, 256 * (self.Dn + 1)), dtype=F32, device=dev)
+        self.ws = torch.empty(256 * 1024, dtype=F32, device=dev)
         self._alloc_model(B)
 
     def _alloc_model(self, B):
@@ -608,8 +610,7 @@ class XDeepFMEngine(Engine):
                               self.cin_act, self.maps[i], self.cin_fws, pooled=self.pooled,
                               pool_col0=self.pool_col0[i], pool_from=self.pool_from[i])
             xk = self.maps[i]
-        torch.mv(self.pooled, p["cin_w"].view(-1), out=self.cin_logit)
-        self.cin_logit.add_(p["cin_w0"])
+        ops.rowdot(self.pooled, p["cin_w"].view(-1), p["cin_w0"], self.cin_logit)
 
     def _branches_fwd(self, idx, dense, training, masks, lin_w):
         hp = self.hp
@@ -626,8 +627,7 @@ class XDeepFMEngine(Engine):
         p, gr = self.params, self.grads
         # DNN first: it STORES dLoss/dE into d_rows; every CIN layer then accumulates
         self.mlp.backward(g, self.d_rows.view(-1, self.FD))
-        torch.mv(self.pooled.t(), g, out=gr["cin_w"].view(-1))
-        gr["cin_w0"].copy_(g.sum().view(1))
+        ops.linear_dense_bwd(g, self.pooled, gr["cin_w"].view(-1), gr["cin_w0"], self.ws)
         cw = p["cin_w"].view(-1)
         L = len(self.units)
         for i in range(L - 1, -1, -1):

@@ -87,6 +87,8 @@ def linear_dense_bwd(g, dense, d_w_dense, d_w0, workspace):
     Dn = 0 if dense is None else dense.shape[1]
     if workspace.numel() < 256 * (Dn + 1):
         raise ValueError("linear_dense_bwd: workspace too small")
+    if Dn > 1023:
+        raise ValueError("linear_dense_bwd: at most 1023 columns")
     _lib.call(
         "rm_linear_dense_bwd", _chk(g, "g", F32, (B,)),
         _chk(dense, "dense", F32, (B, Dn), allow_none=True), B, Dn,
@@ -217,3 +219,11 @@ def cin_layer_bwd(X0, Xk, H, W, act, out, g, dX0, dW, dbias, workspace, *, xk_is
         _chk(dXk, "dXk", F32, allow_none=True), 0 if dXk is None else dXk.shape[1] * D,
         _chk(dW, "dW", F32, (m * H, N)), _chk(dbias, "dbias", F32, (N,)),
         _chk(workspace, "workspace", F32), workspace.numel(), _stream())
+
+
+def rowdot(X, w, w0, out):
+    """out[b] = X[b,:] . w + w0 (the [*,1] output projections)."""
+    B, P_ = X.shape
+    _lib.call("rm_rowdot", _chk(X, "X", F32), _chk(w, "w", F32, (P_,)),
+              _chk(w0, "w0", F32, (1,), allow_none=True), B, P_, _chk(out, "out", F32, (B,)),
+              _stream())
