@@ -190,6 +190,36 @@ class MLP:
         self.g[nm].add_(self.p[nm], alpha=reg)
 
 
+def init_reference(engine, seed=2019):
+    """Initial values with the reference's distributions (TF's RNG stream itself cannot
+    be reproduced): embedding tables, DNN and CIN weights truncated-normal glorot
+    (utils.py:180-183; layers.py:99-101,536,551,567,666), cin_w glorot-uniform
+    (layers.py:690), everything else zeros (layers.py:109,321,327,544,561,574,676,695).
+    Cross-net vectors (absent from the reference): glorot-normal weights, zero biases."""
+    import math
+
+    g = torch.Generator(device=engine.device).manual_seed(int(seed))
+
+    def tn(t, fan_in, fan_out):
+        std = math.sqrt(2.0 / (fan_in + fan_out))
+        torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std, generator=g)
+
+    for name, t in engine.params.items():
+        if name.endswith("_feat_embed") or name.endswith("_weights") or name == "dnn_w":
+            tn(t, t.shape[0], t.shape[1])
+        elif name.startswith("cin_filter_"):
+            tn(t, t.shape[1], t.shape[2])
+        elif name == "cin_w":
+            b = math.sqrt(6.0 / (t.shape[0] + t.shape[1]))
+            t.uniform_(-b, b, generator=g)
+        elif name in ("cross_w",):
+            tn(t, t.shape[1], 1)
+        elif name == "cross_w_out":
+            tn(t, t.shape[0], 1)
+        else:
+            t.zero_()
+
+
 class Engine:
     """Shared storage + the embedding / linear / loss plumbing.  Subclasses add the
     model-specific branches and define `_branches_fwd` / `_branches_bwd`."""

@@ -1,0 +1,211 @@
+"""Base estimator: batching, fit / predict / evaluate with the reference's signatures
+(recman/tf/core/DeepModel.py:21-228), driving a recman_amd engine on the GPU.
+
+Differences from the reference, all deliberate and documented:
+  * the DataFrame is encoded ONCE per call and kept on the GPU (the reference re-encodes
+    every mini-batch on the host, DeepModel.py:190-202 / inputs.py:53-58);
+  * `len(y) // batch_size + 1` batches as in the reference (DeepModel.py:49,188), but the
+    trailing EMPTY batch that appears when len % batch_size == 0 is skipped (the
+    reference would feed it and turn every variable into NaN);
+  * strict_reference=True reproduces two reference quirks: evaluation inside fit() runs
+    with dropout active (DeepModel.py:103-111) and a new optimizer is built for every
+    batch (xDeepFM.py:121-126); the default evaluates without dropout and keeps the
+    optimizer state.
+"""
+import logging
+from time import time
+
+import numpy as np
+import torch
+from sklearn.base import BaseEstimator, TransformerMixin
+from sklearn.utils import check_random_state
+
+from .. import engine as eng
+from ..optim import Optimizer
+from .inputs import DataInputs, FeatureDictionary
+
+log = logging.getLogger(__name__)
+
+
+class DeepModel(BaseEstimator, TransformerMixin):
+    model = None  # "deepfm" | "dcn" | "xdeepfm"
+
+    def __init__(self, feat_dict: FeatureDictionary, hparams: dict, metrics, epoch, batch_size=64,
+                 random_seed=2019, task="classification", strict_reference=False, device="cuda"):
+        assert task in ["classification", "regression"], (
+            "target can be either 'classification' for classification task or 'regression' "
+            "for regression task")  # DeepModel.py:31-34
+        self.task = task
+        self.feat_dict = feat_dict
+        self.hparams = dict(hparams)
+        self.epoch = epoch
+        self.batch_size = batch_size
+        self.random_seed = random_seed
+        self.metrics = metrics
+        self.strict_reference = strict_reference
+        self.device = device
+        self._engine = None
+        self._opt = None
+
+    # ------------------------------------------------------------------ engine
+    def _build(self):
+        if self._engine is not None:
+            return self._engine
+        fd = self.feat_dict
+        fd.check_supported()
+        spec = eng.FeatureSpec([f.name for f in fd.embedding_feats],
+                               [f.feat_size for f in fd.embedding_feats],
+                               [f.name for f in fd.dense_feats])
+        hp = dict(self.hparams)
+        hp["strict_reference"] = self.strict_reference
+        e = eng.ENGINES[self.model](spec, hp["embedding_size"], hp, task=self.task, device=self.device)
+        eng.init_reference(e, self.random_seed)
+        self._engine = e
+        self._opt = Optimizer(hp.get("optimizer", "adam"), hp.get("learning_rate", 1e-3))
+        return e
+
+    @property
+    def variables(self):
+        """name -> tensor with the reference's variable names (DeepModel.py:43)."""
+        return self._build().params
+
+    def _encode(self, X, y=None):
+        inp = DataInputs().load(self.feat_dict, X, y)
+        dev = self._build().device
+        idx = torch.from_numpy(np.ascontiguousarray(inp.idx)).to(dev)
+        dense = torch.from_numpy(np.ascontiguousarray(inp.dense)).to(dev)
+        yt = None
+        if y is not None:
+            ya = np.asarray(y)
+            yt = torch.from_numpy(ya.astype(np.int64 if self.task == "classification" else np.float32)).to(dev)
+        return idx, dense, yt
+
+    def _manual_weights(self):
+        """Concatenated per-feature manual weights in linear-feature order
+        (layers.py:338-345), or None when no feature has any."""
+        fd = self.feat_dict
+        feats = fd.sparse_feats + fd.dense_feats  # utils.py:31-36
+        if not any(getattr(f, "_weights", None) for f in feats):
+            return None
+        w = np.concatenate([np.asarray(f.weights, dtype=np.float64).reshape(-1) for f in feats])
+        return torch.from_numpy(w.astype(np.float32))
+
+    # ------------------------------------------------------------------ predict
+    @staticmethod
+    def get_batch(X, y, batch_size, index):
+        start = index * batch_size
+        end = min(start + batch_size, len(y))
+        return X[start:end], y[start:end]
+
+    def _predict_encoded(self, idx, dense, training):
+        e = self._build()
+        n = idx.shape[0]
+        out = np.empty((n,), dtype=np.float32)
+        mw = None if training else self._manual_weights()
+        total_batch = n // self.batch_size + 1  # DeepModel.py:49
+        for bi in range(total_batch):
+            s, t = bi * self.batch_size, min((bi + 1) * self.batch_size, n)
+            if t <= s:
+                continue
+            masks = self._dropout_masks(t - s) if training else None
+            _, pred = e.forward(idx[s:t].contiguous(), dense[s:t].contiguous(), training=training,
+                                masks=masks, manual_weights=mw)
+            out[s:t] = pred.cpu().numpy()
+        return out
+
+    def predict(self, X, training=False, batch_number_to_show_progress=50):
+        idx, dense, _ = self._encode(X)
+        return self._predict_encoded(idx, dense, training)
+
+    def evaluate(self, X, y, training=False, batch_number_to_show_progress=50):
+        pred = self.predict(X, training, batch_number_to_show_progress)
+        return [metric(y, pred) for metric in self.metrics]
+
+    # ---------------------------------------------------------------------- fit
+    def _dropout_masks(self, B):
+        """0/1 keep masks for the configured keep-probabilities (tf.nn.dropout,
+        layers.py:461,466,589,602), drawn on the GPU."""
+        e = self._build()
+        hp, dev = e.hp, e.device
+        masks = {}
+        n = len(hp.get("deep_hidden_units", ()))
+        keep = hp.get("deep_dropout")
+        if keep is not None and any(k < 1 for k in keep) and getattr(e, "mlp", None) is not None:
+            dims = [e.FD + e.Dn] + list(hp["deep_hidden_units"])
+            masks["dnn"] = [(torch.rand(B, d, device=dev) < k).float() if k < 1 else None
+                            for d, k in zip(dims, keep)]
+        fk = hp.get("fm_dropout")
+        if fk is not None and any(k < 1 for k in fk) and e.model == "deepfm":
+            mb = (torch.rand(B, e.F, device=dev) < fk[0]).float() / fk[0] if fk[0] < 1 else None
+            me = (torch.rand(B, e.F, e.D, device=dev) < fk[1]).float() / fk[1] if fk[1] < 1 else None
+            masks["fm"] = (mb, me)
+        return masks or None
+
+    def fit_on_batch(self, X, y):
+        idx, dense, yt = self._encode(X, y)
+        return self._fit_encoded(idx, dense, yt)
+
+    def _fit_encoded(self, idx, dense, yt):
+        e = self._build()
+        if idx.shape[0] == 0:
+            return None
+        loss = e.fwd_bwd(idx, dense, yt, masks=self._dropout_masks(idx.shape[0]))
+        if self.strict_reference:
+            self._opt.reset()  # a NEW optimizer every batch (xDeepFM.py:121-126)
+        self._opt.step(e.params, e.dense_grads(idx))
+        return loss
+
+    def _eval_at_epoch(self, enc_train, y_train, enc_valid=None, y_valid=None, start_time=None, epoch=0):
+        training = bool(self.strict_reference)  # DeepModel.py:103-111 evaluates with training=True
+        tr = [m(y_train, self._predict_encoded(enc_train[0], enc_train[1], training)) for m in self.metrics]
+        va = None
+        if enc_valid is not None:
+            va = [m(y_valid, self._predict_encoded(enc_valid[0], enc_valid[1], training)) for m in self.metrics]
+        log.info("[%d] train-result=%s%s [%.1f s]", epoch, [round(float(r), 4) for r in tr],
+                 "" if va is None else ", valid-result=%s" % [round(float(r), 4) for r in va],
+                 time() - (start_time or time()))
+        return tr, va
+
+    def fit(self, X_train, y_train, X_valid=None, y_valid=None, random_seed_for_mini_batch=True,
+            tb_logger=None, epoch_callback=None, show_progress=False,
+            batch_number_to_show_progress=50):
+        assert X_train is not None or y_train is not None  # DeepModel.py:153
+        y_train = np.asarray(y_train)
+        idx, dense, yt = self._encode(X_train, y_train)
+        enc_valid = None
+        if X_valid is not None and y_valid is not None:
+            vi, vd, _ = self._encode(X_valid)
+            enc_valid = (vi, vd)
+        eval_results = self._eval_at_epoch((idx, dense), y_train, enc_valid, y_valid, time())
+        n = len(y_train)
+        for epoch in range(1, self.epoch + 1):
+            start = time()
+            seed = np.random.randint(1, 2019) if random_seed_for_mini_batch else self.random_seed
+            # sklearn.utils.shuffle(X, random_state=seed) (DeepModel.py:182-187): the same
+            # permutation, applied to the encoded arrays instead of the DataFrame
+            perm = np.arange(n)
+            check_random_state(seed).shuffle(perm)
+            pt = torch.from_numpy(perm).to(idx.device)
+            idx, dense, yt = idx[pt], dense[pt], yt[pt]
+            y_train = y_train[perm]
+            total_batch = n // self.batch_size + 1  # DeepModel.py:188
+            for i in range(total_batch):
+                s, t = i * self.batch_size, min((i + 1) * self.batch_size, n)
+                if t <= s:
+                    continue  # the reference's trailing empty batch
+                self._fit_encoded(idx[s:t].contiguous(), dense[s:t].contiguous(), yt[s:t].contiguous())
+                if i % batch_number_to_show_progress == 0:
+                    log.info(f"Fit: {(i + 1)}/{total_batch} has been completed")
+            eval_results = self._eval_at_epoch((idx, dense), y_train, enc_valid, y_valid, start, epoch)
+            if epoch_callback:
+                epoch_callback(model=self, eval_results=eval_results, df_all=X_train[:1])
+        return None  # the reference's fit returns None
+
+    # --------------------------------------------------------------- checkpoint
+    def save(self, path):
+        """state_dict with the reference's variable names (tf.train.Checkpoint(**variables),
+        BestModelFinder.py:57-68)."""
+        torch.save({k: v.cpu() for k, v in self._build().state_dict().items()}, path)
+
+    def restore(self, path="ckpt_model.pt"):
+        self._build().load_params(torch.load(path, weights_only=True))

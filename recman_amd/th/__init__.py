@@ -1,0 +1,13 @@
+"""The `recman.th`-shaped surface: the PyTorch backend the reference leaves as an empty
+stub (recman/th/layers.py is 0 bytes, recman/th/DeepFM.py:12-13 is `pass`), here backed
+by hand-written gfx950 kernels.  Same class names, constructor arguments and
+fit()/predict()/evaluate() signatures as recman/tf/core."""
+from .DCN import DCN
+from .DeepFM import DeepFM
+from .DeepModel import DeepModel
+from .inputs import DataInputs, DenseFeat, FeatureDictionary, ResilientLabelEncoder, SparseFeat
+from .xDeepFM import xDeepFM
+from . import hparams
+
+__all__ = ["DCN", "DeepFM", "DeepModel", "xDeepFM", "DataInputs", "DenseFeat", "FeatureDictionary",
+           "ResilientLabelEncoder", "SparseFeat", "hparams"]

@@ -1,0 +1,212 @@
+"""Feature descriptors and encoders: raw DataFrame columns -> int64 indices / float32
+values, the producers of the `idx [B,F]` / `dense [B,Dn]` arrays the kernels consume.
+
+Mirrors recman/tf/inputs.py (FeatureDictionary :8-43, DataInputs :46-90,
+ResilientLabelEncoder :116-145, SparseFeat :148-210, DenseFeat :281-322) without any
+TensorFlow type.  Re-designed for throughput: the reference re-encodes every mini-batch
+with pandas `isin` + `apply(LabelEncoder.transform)`; here a column is encoded in one
+vectorised pass (sorted-class search) and a whole dataset is encoded ONCE per fit().
+Indices are bit-identical to the reference's for string columns (tests/test_inputs.py
+checks against oracle/inputs_ref.py).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import pandas as pd
+from sklearn.preprocessing import StandardScaler
+
+NULL_VAL = "-----"
+
+
+class ResilientLabelEncoder:
+    """inputs.py:116-145.  classes_ = [null_val] + sorted(unique(X)); unseen -> 0.
+
+    Reference quirk: for an INTEGER column the reference's classes_
+    becomes a string array and every id encodes to 0.  strict_reference=True
+    reproduces that; the default encodes integers by value (useful behaviour)."""
+
+    def __init__(self, null_val=NULL_VAL, strict_reference=False):
+        self.null_val = null_val
+        self.strict_reference = strict_reference
+        self.classes_ = None
+        self._sorted = None
+        self._numeric = False
+
+    def fit(self, X, y=None):
+        vals = np.asarray(X)
+        if vals.dtype.kind in "OUS":
+            uniq = np.array(sorted(set(vals.tolist())), dtype=object)
+            self._numeric = False
+        else:
+            uniq = np.unique(vals)
+            self._numeric = True
+        self._sorted = uniq
+        self.classes_ = np.concatenate((np.array([self.null_val], dtype=object), uniq.astype(object)))
+        return self
+
+    def transform(self, X):
+        if self._sorted is None:
+            raise RuntimeError("ResilientLabelEncoder.transform before fit")
+        vals = np.asarray(X)
+        if self._numeric and self.strict_reference:
+            return np.zeros((len(vals), 1), dtype=np.int64)
+        if self._numeric != (vals.dtype.kind not in "OUS"):
+            # type mismatch between fit and transform: nothing can match (as `isin` in the reference)
+            return np.zeros((len(vals), 1), dtype=np.int64)
+        if self._numeric:
+            pos = np.searchsorted(self._sorted, vals)
+            pos_c = np.minimum(pos, len(self._sorted) - 1) if len(self._sorted) else pos
+            hit = (pos < len(self._sorted)) & (self._sorted[pos_c] == vals) if len(self._sorted) else np.zeros(len(vals), bool)
+            return np.where(hit, pos + 1, 0).astype(np.int64).reshape(-1, 1)
+        codes = pd.Categorical(vals, categories=self._sorted).codes.astype(np.int64)
+        return (codes + 1).reshape(-1, 1)  # code -1 (unseen) -> 0, the null class
+
+    def fit_transform(self, X, y=None):
+        return self.fit(X, y).transform(X)
+
+    def inverse_transform(self, y):
+        return self.classes_[np.asarray(y).reshape(-1)]
+
+
+class SparseFeat:
+    """inputs.py:148-210.  feat_size = cardinality + 1 (slot 0 = null/unknown, :166)."""
+
+    def __init__(self, name, feat_size, weights=None, dtype=None, encoder=None, description=None):
+        self.name = name
+        self.dtype = dtype
+        self.description = description
+        self.encoder = encoder if encoder else ResilientLabelEncoder()
+        self.feat_size = feat_size + 1
+        self._weights = weights
+        self._weights_cache = None
+
+    @property
+    def weights(self):
+        """Manual per-class boosts added to the linear weights at predict time
+        (inputs.py:170-182, layers.py:338-345)."""
+        if self._weights:
+            if self._weights_cache is None:
+                ids = self.encoder.transform(list(self._weights.keys())) if self.encoder else np.array(
+                    list(self._weights.keys()))
+                w = np.zeros((self.feat_size,))
+                for i, val in zip(np.asarray(ids).flatten(), self._weights.values()):
+                    w[i] = val
+                self._weights_cache = w
+            return self._weights_cache
+        return np.zeros((self.feat_size,))
+
+    def set_weights(self, val):
+        self._weights = val
+        self._weights_cache = None
+
+    def get_shape(self, for_tf=True):
+        return None if for_tf else -1, 1
+
+    def initialize(self, X):
+        if self.encoder:
+            self.encoder.fit(X)
+
+    def __call__(self, x):
+        if self.encoder:
+            x = self.encoder.transform(x)
+        return np.asarray(x).astype(np.int64).reshape(-1, 1)
+
+    def decode(self, x):
+        return self.encoder.inverse_transform(x) if self.encoder else x
+
+    def __repr__(self):
+        return f"SparseFeat({self.name}, {self.feat_size})"
+
+
+class DenseFeat:
+    """inputs.py:281-322: float32 cast -> sklearn scaler -> float32 [B,1].  (The reference's
+    default argument `scaler=StandardScaler()` is one shared instance, :287; here every
+    feature gets its own.)"""
+
+    def __init__(self, name, weights=None, dtype=None, scaler=None, description=None):
+        self.name = name
+        self.dtype = dtype
+        self.description = description
+        self.scaler = scaler if scaler is not None else StandardScaler()
+        self.feat_size = 1
+        self._weights = weights
+
+    @property
+    def weights(self):
+        return [self._weights if self._weights is not None else 0]
+
+    def get_shape(self, for_tf=True):
+        return None if for_tf else -1, 1
+
+    def initialize(self, X):
+        if self.scaler:
+            self.scaler.fit(np.asarray(X).reshape(-1, 1))
+
+    def __call__(self, x):
+        x = np.array(x, dtype=np.float32)
+        if self.scaler:
+            x = self.scaler.transform(x.reshape(-1, 1))
+        return np.asarray(x).astype(np.float32).reshape(-1, 1)
+
+    def __repr__(self):
+        return f"DenseFeat({self.name}, {self.feat_size})"
+
+
+class FeatureDictionary(OrderedDict):
+    """inputs.py:8-43.  Insertion order defines the field axis of E (and therefore the
+    row order of the CIN filters): embedding_feats are the non-dense features in order."""
+
+    @property
+    def embedding_feats(self):
+        return [f for f in self.values() if not isinstance(f, DenseFeat)]
+
+    @property
+    def sparse_feats(self):
+        return [f for f in self.values() if isinstance(f, SparseFeat)]
+
+    @property
+    def dense_feats(self):
+        return [f for f in self.values() if isinstance(f, DenseFeat)]
+
+    def initialize(self, X):
+        for feat in self.values():
+            feat.initialize(X[feat.name])
+
+    def check_supported(self):
+        bad = [f for f in self.values() if not isinstance(f, (SparseFeat, DenseFeat))]
+        if bad:
+            raise NotImplementedError(
+                f"features {[f.name for f in bad]}: only SparseFeat and DenseFeat are on the HIP "
+                "path (multi-valued / value-weighted features are SURVEY.md section 8f items)")
+
+
+class DataInputs(dict):
+    """inputs.py:46-90: name -> encoded array (+ 'y'), plus the packed arrays the kernels
+    take: idx int64 [B,F] (embedding_feats order) and dense float32 [B,Dn]."""
+
+    def load(self, feat_dict, X, y=None):
+        for feat in feat_dict.values():
+            self[feat.name] = feat(X[feat.name])
+        if y is not None:
+            self["y"] = np.asarray(y)
+        sparse = feat_dict.embedding_feats
+        dense = feat_dict.dense_feats
+        n = len(X)
+        self.idx = (np.concatenate([self[f.name] for f in sparse], axis=1) if sparse
+                    else np.zeros((n, 0), np.int64))
+        self.dense = (np.concatenate([self[f.name] for f in dense], axis=1).astype(np.float32)
+                      if dense else np.zeros((n, 0), np.float32))
+        return self
+
+    @property
+    def y(self):
+        return self["y"]
+
+    def dense_inputs(self, feat_dict):
+        return [self[f.name] for f in feat_dict.dense_feats]
+
+    def sparse_inputs(self, feat_dict):
+        return [self[f.name] for f in feat_dict.sparse_feats]
+
+    def embedding_inputs(self, feat_dict):
+        return [self[f.name] for f in feat_dict.embedding_feats]

@@ -1,0 +1,159 @@
+"""GPU: the drop-in model classes (constructors + fit/predict/evaluate) on the ml-100k
+golden slice (BASELINE config 1 shape: DeepFM, emb_dim 8, batch 256), against a CPU
+training loop built from the oracle (same initial weights, batches and optimizer)."""
+import math
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+from sklearn.metrics import log_loss, roc_auc_score
+from sklearn.preprocessing import MinMaxScaler
+
+from oracle import th_layers as T
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ml100k_slice.npz"))
+
+
+def ml_frame():
+    df = pd.DataFrame({c: GOLD["raw_" + c] for c in
+                       ["user_id", "item_id", "gender", "occupation", "zip", "timestamp", "age"]})
+    for c in ["gender", "occupation", "zip"]:
+        df[c] = df[c].astype(object)
+    df["label"] = GOLD["label"]
+    return df
+
+
+def ml_features(df):
+    from recman_amd.th import DenseFeat, FeatureDictionary, SparseFeat
+
+    fd = FeatureDictionary()
+    for c in ["user_id", "item_id", "gender", "occupation", "zip"]:
+        fd[c] = SparseFeat(name=c, feat_size=len(np.unique(df[c].values)))
+    for c in ["timestamp", "age"]:
+        fd[c] = DenseFeat(name=c, scaler=MinMaxScaler())
+    fd.initialize(df)
+    return fd
+
+
+def keras_adam_cpu(params, grads, state, t, lr):
+    for k, g in grads.items():
+        m, v = state.setdefault(k, (torch.zeros_like(g), torch.zeros_like(g)))
+        m.mul_(0.9).add_(g, alpha=0.1)
+        v.mul_(0.999).addcmul_(g, g, value=0.001)
+        lr_t = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        params[k] = params[k] - lr_t * m / (v.sqrt() + 1e-7)
+
+
+def oracle_fit(model, p, spec, idx, dense, y, hp, batch_size, epochs, seed, lr):
+    from sklearn.utils import check_random_state
+
+    p = {k: v.clone() for k, v in p.items()}
+    state, t, n = {}, 0, len(y)
+    for _ in range(epochs):
+        perm = np.arange(n)
+        check_random_state(seed).shuffle(perm)
+        idx, dense, y = idx[perm], dense[perm], y[perm]
+        for s in range(0, n, batch_size):
+            sl = slice(s, min(n, s + batch_size))
+            _, _, _, g = T.fwd_bwd(model, p, spec, torch.from_numpy(idx[sl]), torch.from_numpy(dense[sl]),
+                                   torch.from_numpy(y[sl]), hp)
+            t += 1
+            keras_adam_cpu(p, g, state, t, lr)
+    return p
+
+
+@pytest.mark.parametrize("cls_name", ["DeepFM", "DCN", "xDeepFM"])
+def test_fit_predict_matches_oracle_training_loop(hip_lib, cls_name):
+    import recman_amd.th as th
+
+    df = ml_frame()
+    fd = ml_features(df)
+    common = dict(epoch=2, batch_size=256, random_seed=2019)
+    if cls_name == "DeepFM":
+        m = th.DeepFM(fd, embedding_size=8, deep_dropout=(1, 1, 1), learning_rate=0.01, **common)
+        model, hp = "deepfm", dict(m.hparams)
+    elif cls_name == "DCN":
+        m = th.DCN(fd, embedding_size=8, deep_dropout=(1, 1, 1), learning_rate=0.01, cross_layer_num=3,
+                   deep_l2_reg=1e-5, cross_layer_l2_reg=1e-5, **common)
+        model, hp = "dcn", dict(m.hparams)
+    else:
+        hpx = {"embedding_size": 8, "deep_dropout": (1, 1, 1), "cin_cross_layer_units": [16, 16],
+               "cin_dropout": [1, 1, 1], "learning_rate": 0.01}
+        m = th.xDeepFM(fd, hpx, metrics=(roc_auc_score,), **common)
+        model, hp = "xdeepfm", dict(m.hparams)
+    e = m._build()
+    p0 = {k: v.cpu() for k, v in e.state_dict().items()}
+    spec = T.Spec(e.spec.sparse_names, e.spec.feat_sizes, e.spec.dense_names)
+    inp = th.DataInputs().load(fd, df, df["label"].values)
+    idx, dense, y = torch.from_numpy(inp.idx), torch.from_numpy(inp.dense), torch.from_numpy(inp.y)
+
+    pred0 = m.predict(df)
+    want0 = T.prediction(T.MODELS[model][0](p0, spec, idx, dense, hp, training=False)).numpy()
+    assert pred0.shape == (1024,) and pred0.dtype == np.float32
+    assert np.abs(pred0 - want0).max() < 1e-6
+
+    ret = m.fit(df, df["label"].values, random_seed_for_mini_batch=False)
+    assert ret is None  # the reference's fit returns None (DeepModel.py:141-228)
+    p1 = oracle_fit(model, p0, spec, idx.numpy(), dense.numpy(), y.numpy(), hp, 256, 2, 2019, 0.01)
+    p1 = {k: torch.as_tensor(v) for k, v in p1.items()}
+    pred1 = m.predict(df)
+    want1 = T.prediction(T.MODELS[model][0](p1, spec, idx, dense, hp, training=False)).numpy()
+    assert np.abs(pred1 - want1).max() < 2e-4, np.abs(pred1 - want1).max()
+    assert np.abs(pred1 - pred0).max() > 1e-3  # it did train
+    res = m.evaluate(df, df["label"].values)
+    assert len(res) == len(m.metrics) and all(np.isfinite(r) for r in res)
+    # state_dict carries the reference's variable names
+    names = set(e.state_dict())
+    assert {"user_id_feat_embed", "linear_w", "linear_w0", "dnn_layer_0_weights", "dnn_w0"} <= names
+    if model == "deepfm":
+        assert "zip_feat_bias" in names
+    if model == "xdeepfm":
+        assert {"cin_filter_0", "cin_bias_1", "cin_w", "cin_w0"} <= names
+
+
+def test_predict_adds_manual_feature_weights(hip_lib):
+    # layers.py:338-345: training=False adds feat.weights to the linear weights
+    import recman_amd.th as th
+
+    df = ml_frame()
+    fd = ml_features(df)
+    m = th.DeepFM(fd, embedding_size=8, deep_dropout=(1, 1, 1), epoch=1, batch_size=256)
+    base = m.predict(df)
+    fd["gender"].set_weights({"M": -5})
+    boosted = m.predict(df)
+    men = (df["gender"].values == "M")
+    z0, z1 = np.log(base / (1 - base)), np.log(boosted / (1 - boosted))
+    assert np.allclose((z1 - z0)[men], -5, atol=1e-3) and np.allclose((z1 - z0)[~men], 0, atol=1e-3)
+    assert np.allclose(m.predict(df, training=True), base, atol=1e-6)  # training=True: no boosts
+
+
+def test_save_restore_roundtrip(hip_lib, tmp_path):
+    import recman_amd.th as th
+
+    df = ml_frame()
+    fd = ml_features(df)
+    m = th.DeepFM(fd, embedding_size=8, deep_dropout=(1, 1, 1), epoch=1, batch_size=256)
+    m.fit(df, df["label"].values, random_seed_for_mini_batch=False)
+    a = m.predict(df)
+    path = str(tmp_path / "ckpt.pt")
+    m.save(path)
+    m2 = th.DeepFM(fd, embedding_size=8, deep_dropout=(1, 1, 1), epoch=1, batch_size=256, random_seed=7)
+    assert np.abs(m2.predict(df) - a).max() > 1e-4
+    m2.restore(path)
+    assert np.array_equal(m2.predict(df), a)
+
+
+def test_training_with_dropout_runs_and_learns(hip_lib):
+    import recman_amd.th as th
+
+    df = ml_frame()
+    fd = ml_features(df)
+    m = th.DeepFM(fd, embedding_size=8, epoch=3, batch_size=128, learning_rate=0.01,
+                  fm_dropout=(0.9, 0.9))  # default deep_dropout (0.8, 0.8, 0.8)
+    before = log_loss(df["label"].values, m.predict(df).astype(np.float64))
+    m.fit(df, df["label"].values)
+    after = log_loss(df["label"].values, m.predict(df).astype(np.float64))
+    assert after < before
