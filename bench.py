@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent for indices (0 = uniform)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the row-sharded engine even at world size 1 (rehearsal)")
     return ap.parse_args()
 
 
@@ -160,7 +162,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
@@ -171,7 +173,8 @@ def main():
                            [f"I{j + 1}" for j in range(w["Dn"])])
     hp = dict(w["hp"], embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=0.0, cin_l2_reg=0.0,
               cross_layer_l2_reg=0.0)
-    if world > 1:
+    sharded = world > 1 or a.force_sharded
+    if sharded:
         from recman_amd import dist as rdist
 
         engine = rdist.make_sharded_engine(w["model"], spec, w["D"], hp, dev, rank, world)
@@ -184,7 +187,7 @@ def main():
         return engine.fwd_bwd(idx, dense, y)
 
     # ---- optional hipGraph capture of the whole step (launch-bound otherwise) ----
-    use_graph = not a.no_graph and world == 1
+    use_graph = not a.no_graph and not sharded  # the exchange needs host-side split sizes
     graph = None
     step()
     torch.cuda.synchronize()
@@ -226,7 +229,7 @@ def main():
     value = world * B * a.steps / elapsed
 
     # ---- roofline of the dominant hand-written kernel, HIP events on its stream ----
-    roof = engine.roofline_probe(idx, dense, y, iters=max(10, min(a.steps, 50)))
+    roof = None if sharded else engine.roofline_probe(idx, dense, y, iters=max(10, min(a.steps, 50)))
 
     out = {
         "metric": "examples/sec fwd+bwd, Criteo-shape batch %d" % B,
@@ -239,10 +242,11 @@ def main():
                    "indices": "uniform" if a.zipf == 0 else f"zipf({a.zipf})",
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
                    "hipgraph": graph is not None,
-                   "table": "replicated" if world == 1 else f"row-sharded mod {world}"},
+                   "table": f"row-sharded mod {world}, fused [D+4] rows, all_to_all over xGMI" if sharded
+                   else "single GPU"},
         "roofline": roof,
     }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and not sharded and not a.no_cpu_baseline:
         base, logit_cpu, sample = cpu_baseline(w, hp, idx, dense, y, engine)
         out["cpu_baseline"] = base
         engine.forward(idx[:sample].contiguous(), dense[:sample].contiguous(), training=True)

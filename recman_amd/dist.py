@@ -1,0 +1,231 @@
+"""Row-sharded embedding table across the GPUs of one node (new design: the reference
+is single-process, single-device - SURVEY.md section 8e).
+
+Layout: all per-field tables are one concatenated table; global row r lives on rank
+r % W at local row r // W (cyclic, so Zipf-hot rows spread evenly).  A sharded row is
+FUSED: [D embedding floats | FM bias | linear weight | pad] = D+4 floats, so one
+exchange carries everything a lookup needs.  The batch stays data-parallel.
+
+One step (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI):
+  fwd  route (bucket the B*F occurrences by owner)          - index arithmetic only
+       all_to_all of counts, then of local row ids          - 8 B per occurrence
+       owner-side gather (rm_gather_rows)                   - HIP
+       all_to_all of the rows back                          - (D+4)*4 B per occurrence
+       un-route into (b,f) order (rm_permute_rows)          - HIP
+       FM / linear / DNN / CIN / cross exactly as on one GPU, on the gathered rows
+  bwd  gradient rows [dE | g | g | 0] routed the same way, all_to_all to the owners:
+       each owner ends with IndexedSlices (local row ids, rows) for ITS shard;
+       dense parameters: one flat all_reduce.
+There is no collective in the dense compute; xGMI is a full mesh, so the all_to_all
+uses all 7 links of a GPU at once.
+
+The routing/exchange logic below is device- and backend-agnostic torch code (it is the
+same on gloo/CPU, where tests/test_dist.py runs it with world_size 2); the row gather and
+permutation are injected callables - HIP kernels in the product, plain indexing only in
+the tests.
+"""
+import torch
+import torch.distributed as dist
+
+import os
+
+PAD = 4  # bias, linear weight, 2 floats of padding: fused row width D + 4 (16-byte multiple)
+# RECMAN_FORCE_COLLECTIVES=1: issue the all_to_all / all_reduce calls even at world size 1
+# (rehearses the RCCL path on a single GPU)
+FORCE = os.environ.get("RECMAN_FORCE_COLLECTIVES", "0") == "1"
+
+
+def shard_rows(R, rank, world):
+    """Number of global rows r in [0, R) with r % world == rank."""
+    return (R - rank + world - 1) // world
+
+
+def route(global_rows, world):
+    """global_rows int64 [n] -> (order, counts, local_rows_sorted).
+    `order` sorts the occurrences by owner (stable); bucketed position i holds occurrence
+    order[i]; counts[w] = occurrences owned by rank w."""
+    owner = global_rows % world
+    order = torch.argsort(owner, stable=True)
+    counts = torch.bincount(owner, minlength=world)
+    local = (global_rows // world)[order]
+    return order, counts, local
+
+
+class RowExchange:
+    """The all_to_all plumbing of one batch: built once per batch from its indices, used
+    for the forward row fetch and the backward gradient push."""
+
+    def __init__(self, global_rows, world, group=None):
+        self.world, self.group = world, group
+        self.n = global_rows.numel()
+        self.order, counts, self.send_ids = route(global_rows.reshape(-1), world)
+        self.coll = world > 1 or (FORCE and dist.is_initialized())
+        if self.coll:
+            recv_counts = torch.empty_like(counts)
+            dist.all_to_all_single(recv_counts, counts, group=group)
+            self.send_counts = counts.tolist()  # host sync: split sizes must be host-side
+            self.recv_counts = recv_counts.tolist()
+            self.recv_ids = torch.empty(sum(self.recv_counts), dtype=global_rows.dtype,
+                                        device=global_rows.device)
+            dist.all_to_all_single(self.recv_ids, self.send_ids, self.recv_counts, self.send_counts,
+                                   group=group)
+        else:
+            self.send_counts = self.recv_counts = [self.n]
+            self.recv_ids = self.send_ids
+
+    def fetch(self, owner_rows):
+        """owner_rows [len(recv_ids), W]: the rows this rank serves, in recv_ids order ->
+        [n, W] rows for this rank's occurrences, in BUCKETED order (use `order` to un-route)."""
+        if not self.coll:
+            return owner_rows
+        out = torch.empty(self.n, owner_rows.shape[1], dtype=owner_rows.dtype, device=owner_rows.device)
+        dist.all_to_all_single(out, owner_rows, self.send_counts, self.recv_counts, group=self.group)
+        return out
+
+    def push(self, bucketed_rows):
+        """bucketed_rows [n, W] (this rank's per-occurrence gradient rows in bucketed order)
+        -> [len(recv_ids), W]: the gradient rows for the local rows recv_ids of this shard."""
+        if not self.coll:
+            return bucketed_rows
+        out = torch.empty(len(self.recv_ids), bucketed_rows.shape[1], dtype=bucketed_rows.dtype,
+                          device=bucketed_rows.device)
+        dist.all_to_all_single(out, bucketed_rows, self.recv_counts, self.send_counts, group=self.group)
+        return out
+
+
+class ShardedTable:
+    """This rank's shard [R_local, D+4] of the fused table + the lookup / gradient routing."""
+
+    def __init__(self, R, D, rank, world, device, gather_fn, permute_fn, group=None):
+        self.R, self.D, self.W = R, D, D + PAD
+        self.rank, self.world, self.group = rank, world, group
+        self.shard = torch.zeros(shard_rows(R, rank, world), self.W, dtype=torch.float32, device=device)
+        self.gather_fn, self.permute_fn = gather_fn, permute_fn
+
+    def load_global(self, table, bias=None, lin=None):
+        """Fills the shard from full-size arrays (tests / small tables): row r -> rank r % W."""
+        sl = slice(self.rank, self.R, self.world)
+        self.shard[:, : self.D] = table[sl].to(self.shard.device)
+        if bias is not None:
+            self.shard[:, self.D] = bias[sl].to(self.shard.device)
+        if lin is not None:
+            self.shard[:, self.D + 1] = lin[sl].to(self.shard.device)
+
+    def lookup(self, global_rows):
+        """global_rows int64 [n] (occurrence order) -> (rows [n, D+4] in occurrence order,
+        the RowExchange to reuse in the backward)."""
+        ex = RowExchange(global_rows, self.world, self.group)
+        served = torch.empty(len(ex.recv_ids), self.W, dtype=torch.float32, device=self.shard.device)
+        self.gather_fn(self.shard, ex.recv_ids, served)
+        bucketed = ex.fetch(served)
+        rows = torch.empty(ex.n, self.W, dtype=torch.float32, device=self.shard.device)
+        # rows[order[i]] = bucketed[i]
+        self.permute_fn(bucketed, ex.order, rows, True)
+        return rows, ex
+
+    def push_grads(self, ex, grad_rows):
+        """grad_rows [n, D+4] in occurrence order -> (local row ids, gradient rows) for this
+        shard: IndexedSlices, duplicates not merged."""
+        bucketed = torch.empty_like(grad_rows)
+        self.permute_fn(grad_rows, ex.order, bucketed, False)  # bucketed[i] = grad_rows[order[i]]
+        return ex.recv_ids, ex.push(bucketed)
+
+
+def allreduce_dense(grads, world, group=None):
+    """One flat all_reduce (sum / world) over every dense-parameter gradient."""
+    if world == 1 and not (FORCE and dist.is_initialized()):
+        return
+    keys = sorted(grads)
+    flat = torch.cat([grads[k].reshape(-1) for k in keys])
+    dist.all_reduce(flat, group=group)
+    flat.div_(world)
+    off = 0
+    for k in keys:
+        n = grads[k].numel()
+        grads[k].copy_(flat[off: off + n].view_as(grads[k]))
+        off += n
+
+
+def hip_gather(table, rows, out):
+    from . import ops
+
+    ops.gather_rows(table, rows, out)
+
+
+def hip_permute(src, slot, dst, inverse):
+    from . import ops
+
+    ops.permute_rows(src, slot, dst, inverse=inverse)
+
+
+def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
+    """An engine whose embedding table is row-sharded over `world` ranks (bench.py --gpus N)."""
+    from . import engine as eng
+
+    base = eng.ENGINES[model]
+
+    class Sharded(base):
+        sharded = True
+
+        def __init__(self):
+            self._shard_args = (rank, world, group)
+            super().__init__(spec, D, hp, device=device)
+
+        def _alloc_tables(self):
+            dev = self.device
+            R = self.spec.rows
+            self.st = ShardedTable(R, self.D, rank, world, dev, hip_gather, hip_permute, group)
+            self.table = self.st.shard  # [R_local, D+4] fused rows
+            self.bias_table = None
+            self.linear_w = torch.zeros(self.Dn, dtype=torch.float32, device=dev)  # dense part only
+            self.field_off = torch.tensor(self.spec.offsets(), dtype=torch.int64, device=dev)
+            self.lin_off = self.field_off
+            self.params["table_shard"] = self.st.shard
+            self.params["linear_w_dense"] = self.linear_w
+
+        def _alloc(self, B):
+            first = self._B != B
+            super()._alloc(B)
+            if first:
+                F = self.F
+                self._iota = (torch.arange(B, device=self.device, dtype=torch.int64) * F).view(B, 1).expand(B, F).contiguous()
+                self._foff = torch.arange(F, device=self.device, dtype=torch.int64)
+                self.grad_rows = torch.zeros(B * F, self.D + PAD, dtype=torch.float32, device=self.device)
+
+        def _embed(self, idx, dense, want_fm, masks, lin_w=None):
+            from . import ops
+
+            m = masks or {}
+            fm_masks = m.get("fm", (None, None))
+            g_rows = (idx + self.field_off).reshape(-1)
+            self.rows, self.ex = self.st.lookup(g_rows)
+            W = self.D + PAD
+            flat = self.rows.view(-1)
+            ops.embed_fwd(
+                self._iota, self.rows, self._foff, table_ld=W, D=self.D,
+                bias_table=flat[self.D:] if want_fm else None, bias_ld=W,
+                lin_w=flat[self.D + 1:] if self.use_linear else None, lin_ld=W, lin_off=self._foff,
+                lin_w_dense=self.linear_w if (self.use_linear and self.Dn) else None,
+                lin_w0=self.params["linear_w0"] if self.use_linear else None,
+                dense=dense if (self.use_linear and self.Dn) else None,
+                mask_b=fm_masks[0] if want_fm else None, mask_e=fm_masks[1] if want_fm else None,
+                E=self.E, fm_sum=self.fm_sum if want_fm else None,
+                fm_logit=self.fm_logit if want_fm else None,
+                lin_logit=self.lin_logit if self.use_linear else None)
+
+        def fwd_bwd(self, idx, dense, y, masks=None):
+            loss = super().fwd_bwd(idx, dense, y, masks)
+            # gradient rows [dE | g_fm | g_lin | 0 0] -> owners
+            B = idx.shape[0]
+            gr = self.grad_rows
+            gr[:, : self.D] = self.d_rows.view(-1, self.D)
+            g_occ = self.dlogit.view(B, 1).expand(B, self.F).reshape(-1)
+            if self._has_fm():
+                gr[:, self.D] = g_occ
+            if self.use_linear:
+                gr[:, self.D + 1] = g_occ
+            self.shard_grad_ids, self.shard_grad_rows = self.st.push_grads(self.ex, gr)
+            allreduce_dense(self.grads, world, group)
+            return loss
+
+    return Sharded()

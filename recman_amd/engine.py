@@ -236,7 +236,19 @@ class Engine:
         F, R, Dn = spec.F, spec.rows, spec.Dn
         self.F, self.Dn, self.FD = F, Dn, F * self.D
         self.params, self.grads = {}, {}
-        # --- HBM layout: one [R, D] table, one [R] bias table, one linear vector ---
+        self._alloc_tables()
+        self.params["linear_w0"] = torch.zeros(1, dtype=F32, device=dev)
+        self.grads["linear_w0"] = torch.zeros(1, dtype=F32, device=dev)
+        self.grads["linear_w_dense"] = torch.zeros(Dn, dtype=F32, device=dev)
+        self._B = None
+        self.use_linear = True
+
+    def _alloc_tables(self):
+        """HBM layout: one [R, D] table, one [R] bias table, one linear vector; the
+        reference's per-feature variables are views (recman_amd/dist.py overrides this
+        with the row-sharded fused layout)."""
+        spec, dev, Dn = self.spec, self.device, self.Dn
+        R = spec.rows
         self.table = torch.zeros(R, self.D, dtype=F32, device=dev)
         self.bias_table = torch.zeros(R, dtype=F32, device=dev) if self.use_bias_tables else None
         self.linear_w = torch.zeros(R + Dn, dtype=F32, device=dev)  # utils.py:31-36 order
@@ -248,11 +260,6 @@ class Engine:
             if self.use_bias_tables:
                 self.params[f"{name}_feat_bias"] = self.bias_table[off: off + V].view(V, 1)
         self.params["linear_w"] = self.linear_w.view(-1, 1)
-        self.params["linear_w0"] = torch.zeros(1, dtype=F32, device=dev)
-        self.grads["linear_w0"] = torch.zeros(1, dtype=F32, device=dev)
-        self.grads["linear_w_dense"] = torch.zeros(Dn, dtype=F32, device=dev)
-        self._B = None
-        self.use_linear = True
 
     # ------------------------------------------------------------------ storage
     def load_params(self, params):

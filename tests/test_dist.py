@@ -1,0 +1,99 @@
+"""CPU: the row-sharded table logic - fake-rank simulation (pure index arithmetic,
+bit-exact) and a real 2-process gloo run of lookup / gradient push / dense all-reduce."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from recman_amd import dist as rd
+
+
+def cpu_gather(table, rows, out):
+    out.copy_(table[rows])
+
+
+def cpu_permute(src, slot, dst, inverse):
+    if inverse:
+        dst[slot] = src
+    else:
+        dst.copy_(src[slot])
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_fake_rank_routing_is_a_bit_exact_permutation(world):
+    g = torch.Generator().manual_seed(world)
+    R, D = 1000 + world, 8
+    table = torch.randn(R, D, generator=g)
+    shards = [table[r::world] for r in range(world)]
+    assert [s.shape[0] for s in shards] == [rd.shard_rows(R, r, world) for r in range(world)]
+    rows = torch.randint(0, R, (777,), generator=g)
+    rows[:50] = rows[0]  # heavy duplicates
+    order, counts, local = rd.route(rows, world)
+    assert int(counts.sum()) == 777 and torch.equal(torch.sort(order).values, torch.arange(777))
+    # owner-side gather per bucket, then un-route
+    pieces, off = [], 0
+    for w in range(world):
+        ids = local[off: off + int(counts[w])]
+        assert bool(((rows[order][off: off + int(counts[w])] % world) == w).all())
+        pieces.append(shards[w][ids])
+        off += int(counts[w])
+    bucketed = torch.cat(pieces)
+    out = torch.empty(777, D)
+    out[order] = bucketed
+    assert torch.equal(out, table[rows])
+
+
+def test_world_one_table_roundtrip():
+    g = torch.Generator().manual_seed(0)
+    R, D = 50, 4
+    full = torch.randn(R, D, generator=g)
+    st = rd.ShardedTable(R, D, 0, 1, "cpu", cpu_gather, cpu_permute)
+    st.load_global(full, bias=torch.arange(R).float(), lin=-torch.arange(R).float())
+    rows = torch.randint(0, R, (33,), generator=g)
+    got, ex = st.lookup(rows)
+    assert torch.equal(got[:, :D], full[rows])
+    assert torch.equal(got[:, D], rows.float()) and torch.equal(got[:, D + 1], -rows.float())
+    ids, grows = st.push_grads(ex, got)
+    dense = torch.zeros(R, D + rd.PAD).index_add_(0, ids, grows)
+    want = torch.zeros(R, D + rd.PAD).index_add_(0, rows, got)
+    assert torch.allclose(dense, want)
+
+
+def _worker(rank, world, port, R, D, n):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.randn(R, D, generator=torch.Generator().manual_seed(123))
+        bias = torch.arange(R).float()
+        st = rd.ShardedTable(R, D, rank, world, "cpu", cpu_gather, cpu_permute)
+        st.load_global(full, bias=bias)
+        all_rows = [torch.randint(0, R, (n + 7 * r,), generator=torch.Generator().manual_seed(10 + r))
+                    for r in range(world)]
+        rows = all_rows[rank]
+        got, ex = st.lookup(rows)
+        assert torch.equal(got[:, :D], full[rows]), "lookup mismatch"
+        assert torch.equal(got[:, D], bias[rows])
+        # gradient push: every rank sends grad = f(its rows); the owner must receive the sum
+        grads = [torch.cat([full[rw] * (r + 1), torch.ones(len(rw), rd.PAD)], 1) for r, rw in enumerate(all_rows)]
+        ids, grows = st.push_grads(ex, grads[rank])
+        mine = torch.zeros(st.shard.shape[0], D + rd.PAD, dtype=torch.float64).index_add_(0, ids, grows.double())
+        want = torch.zeros(R, D + rd.PAD, dtype=torch.float64)
+        for rw, gr in zip(all_rows, grads):
+            want.index_add_(0, rw, gr.double())
+        assert torch.allclose(mine, want[rank::world], atol=1e-9), "gradient push mismatch"
+        # dense all-reduce (mean over ranks)
+        gd = {"b": torch.full((3,), float(rank + 1)), "a": torch.full((2, 2), float(10 * (rank + 1)))}
+        rd.allreduce_dense(gd, world)
+        mean = sum(range(1, world + 1)) / world
+        assert torch.allclose(gd["b"], torch.full((3,), mean)) and torch.allclose(gd["a"], torch.full((2, 2), 10 * mean))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_lookup_push_allreduce(world):
+    port = 29500 + os.getpid() % 2000 + world
+    mp.spawn(_worker, args=(world, port, 301, 8, 200), nprocs=world, join=True)

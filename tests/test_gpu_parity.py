@@ -179,3 +179,41 @@ def test_xdeepfm_fwd_bwd_matches_oracle(hip_lib, units, D):
 def test_xdeepfm_criteo_like_shape(hip_lib):
     _check_model("xdeepfm", hip_lib, D=16, B=70, F=26, Dn=13, hidden=(32, 32), cin_units=(128, 128),
                  scale=0.05)
+
+
+@pytest.mark.parametrize("model,kw", [("deepfm", {}), ("dcn", dict(cross_layers=3, scale=0.15)),
+                                       ("xdeepfm", dict(cin_units=(16, 8), scale=0.2))])
+def test_row_sharded_engine_world1_equals_plain_engine(hip_lib, model, kw):
+    """The multi-GPU code path (fused sharded rows -> gather -> un-route -> FM/linear on the
+    gathered rows -> gradient rows pushed to the owner) at world size 1, on the real kernels."""
+    from recman_amd import dist as rd
+    from recman_amd import engine as eng
+
+    spec, p, idx, dense, y, hp = make_case(model, B=45, D=16, **kw)
+    hp = dict(hp, embedding_l2_reg=0.0, linear_l2_reg=0.0)
+    e = _engine(model, spec, 16, hp, p)
+    idx_d, dense_d, y_d = idx.cuda(), dense.cuda(), y.cuda()
+    loss = e.fwd_bwd(idx_d, dense_d, y_d).clone()
+    gd = e.dense_grads(idx_d)
+    espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names)
+    s = rd.make_sharded_engine(model, espec, 16, hp, torch.device("cuda"), 0, 1)
+    s.load_params({k: v for k, v in p.items() if k in s.params})
+    full = torch.cat([p[f"{n}_feat_embed"] for n in spec.sparse_names])
+    bias = torch.cat([p[f"{n}_feat_bias"].reshape(-1) for n in spec.sparse_names]) if model == "deepfm" else None
+    R = full.shape[0]
+    s.st.load_global(full, bias=bias, lin=p["linear_w"].reshape(-1)[:R])
+    s.linear_w.copy_(p["linear_w"].reshape(-1)[R:])
+    loss_s = s.fwd_bwd(idx_d, dense_d, y_d)
+    _close(s.logit, e.logit, rtol=0, atol=1e-6, what="logit")
+    _close(loss_s, loss, what="loss")
+    ids, rows = s.shard_grad_ids, s.shard_grad_rows
+    D = 16
+    dt = torch.zeros(R, D + rd.PAD, device="cuda").index_add_(0, ids, rows)
+    want_t = torch.cat([gd[f"{n}_feat_embed"] for n in spec.sparse_names])
+    _close(dt[:, :D], want_t, what="table grad")
+    _close(dt[:, D + 1], gd["linear_w"].reshape(-1)[:R], what="linear grad")
+    if model == "deepfm":
+        _close(dt[:, D], torch.cat([gd[f"{n}_feat_bias"].reshape(-1) for n in spec.sparse_names]), what="bias grad")
+    for k in s.grads:
+        if k in gd:
+            _close(s.grads[k], gd[k], what=f"grad {k}")
