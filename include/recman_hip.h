@@ -131,6 +131,31 @@ int rm_logit_loss(const float *logit_a, float coef_a, const float *logit_b, floa
                   float *pred, float *dlogit, float *loss, float *workspace,
                   rm_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Skinny DNN (every hidden width <= 32, 1..3 hidden layers, FD+Dn <= 448), fused on the
+ * f32 MFMA.  Replaces DNNCombiner + DNN.__call__ (layers.py:494-501, 576-609) and their
+ * gradient for the reference-default deep_hidden_units (32, 32) (DeepFM.py:37,
+ * hparams/xDeepFM.py:27); wider MLPs (DCN's [400,400]) go to rocBLAS/hipBLASLt.
+ *   x = [xe | xd] (never concatenated); W[0] [FD+Dn, H0], W[l] [H_{l-1}, H_l], bias[l] [H_l];
+ *   w_out [H_last], w0_out [1];  host arrays H / W / bias / h_out / dh / dW have NL entries.
+ * rm_mlp_fwd: h_out[l] [B,32] (post-activation, columns >= H_l zero), logit [B].
+ * rm_mlp_bwd: g [B] = dLoss/dlogit; writes dLoss/dxe into d_rows [B,FD]; when fm_sum
+ *   (S [B,D] from rm_embed_fwd) is given the FM second-order gradient g*(S - E) is added
+ *   (xe is E: the whole DeepFM row gradient in one pass, no rm_embed_bwd launch);
+ *   dh[l] [B,32] = dLoss/d(pre-activation of layer l); dW[l] = weight gradients (the bias
+ *   gradients are the column sums of dh[l]: rm_linear_dense_bwd).
+ *   workspace: rm_mlp_bwd_workspace(FD, Dn) floats. */
+int rm_mlp_supported(int FD, int Dn, int NL, const int *H);
+int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
+               const float *const *W, const float *const *bias, const float *w_out,
+               const float *w0_out, int act, int64_t B, float *const *h_out, float *logit,
+               rm_stream_t stream);
+int64_t rm_mlp_bwd_workspace(int FD, int Dn);
+int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
+               const float *const *W, const float *w_out, int act, int64_t B, const float *g,
+               const float *const *h, const float *fm_sum, int D, float *d_rows,
+               float *const *dh, float *const *dW, float *workspace, rm_stream_t stream);
+
 /* out[b] = sum_j X[b,j]*w[j] + w0[0]: the [*,1] output projections (dnn_w/dnn_w0,
  * layers.py:606-609; cin_w/cin_w0, layers.py:757-760).  w0 may be NULL. */
 int rm_rowdot(const float *X, const float *w, const float *w0, int64_t B, int P, float *out,

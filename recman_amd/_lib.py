@@ -30,6 +30,9 @@ SIGNATURES = {
     "rm_linear_dense_bwd": [P, P, I64, c_int, P, P, P, P],
     "rm_logit_loss": [P, c_float, P, c_float, P, c_float, P, c_float, P, P, c_int, I64, P, P, P,
                       P, P, P],
+    "rm_mlp_supported": [c_int, c_int, c_int, P],
+    "rm_mlp_fwd": [P, P, c_int, c_int, c_int, P, P, P, P, P, c_int, I64, P, P, P],
+    "rm_mlp_bwd": [P, P, c_int, c_int, c_int, P, P, P, c_int, I64, P, P, P, c_int, P, P, P, P, P],
     "rm_rowdot": [P, P, P, I64, c_int, P, P],
     "rm_cross_fwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P],
     "rm_cross_bwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P, P, P, P, P, P],
@@ -47,6 +50,7 @@ SIGNATURES = {
 SIGNATURES_I64 = {
     "rm_cin_filter_workspace": [c_int, c_int, c_int],
     "rm_cin_bwd_workspace": [I64, c_int, c_int, c_int, c_int],
+    "rm_mlp_bwd_workspace": [c_int, c_int],
 }
 
 

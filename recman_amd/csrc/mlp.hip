@@ -1,0 +1,506 @@
+// Skinny MLP ("DNN", recman/tf/core/layers.py:576-609) for hidden widths <= 32, fused
+// on the f32-input MFMA.  hipBLASLt's kernels for N = 32 outputs ran the three GEMMs of
+// the reference-default (32,32) MLP at ~800 us per step (profiles/r01_p1); the work is
+// ~2 GFLOP and one pass over x, i.e. HBM-bound at ~25 us.
+//
+// Orientation: everything is computed TRANSPOSED, h^T[unit][example], so that a wave's
+// 32x32 accumulator has the example on the lane and the 16 units u(r,h) = (r&3)+8(r>>2)+4h
+// in the registers.  That accumulator is then directly the B operand of the next layer's
+// MFMA (k index = unit): layers 1.. and the whole dh chain of the backward never leave
+// registers.  x = [xe | xd] (never concatenated in memory) is staged per wave through a
+// private LDS chunk of 32 examples x 64 k (full 256-byte lines from HBM); W0 sits in LDS.
+#include "rm_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kLDX = 68;   // x chunk row stride (64 + 4 pad: conflict-free b128 reads)
+constexpr int kMaxNL = 3;
+
+__device__ __forceinline__ int unit_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ float actf(float v, int act) {
+  if (act == RM_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ float actg(float o, int act) {
+  if (act == RM_ACT_RELU) return o > 0.f ? 1.f : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return o > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+
+struct MlpW {
+  const float *W[kMaxNL];  // W[0] [K,H0], W[l] [H_{l-1}, H_l]
+  const float *b[kMaxNL];
+  int H[kMaxNL];
+};
+
+// loads the lane's 8 float4 of a 32-example x 64-k chunk of x = [xe | xd]
+__device__ __forceinline__ void load_chunk(float4 (&v)[8], const float *__restrict__ xe,
+                                           const float *__restrict__ xd, int FD, int Dn, int64_t B,
+                                           int64_t ex0, int k0, int lane) {
+  const int c4 = lane & 15;
+  const int k = k0 + 4 * c4;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = (lane >> 4) + 4 * q;
+    int64_t b = ex0 + row;
+    b = b < B ? b : B - 1;
+    if (k + 3 < FD) {
+      v[q] = *reinterpret_cast<const float4 *>(xe + b * FD + k);
+    } else {
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = k + e;
+        t[e] = (kk >= FD && kk < FD + Dn) ? xd[b * Dn + (kk - FD)] : 0.f;
+      }
+      v[q] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+  }
+}
+
+__device__ __forceinline__ void store_chunk(float *xs, const float4 (&v)[8], int lane) {
+  const int c4 = lane & 15;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = (lane >> 4) + 4 * q;
+    *reinterpret_cast<float4 *>(xs + row * kLDX + 4 * c4) = v[q];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// forward: all layers + output projection in one kernel
+// ---------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(512) void mlp_fwd_kernel(
+    const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn, MlpW w,
+    const float *__restrict__ w_out, const float *__restrict__ w0_out, int act, int64_t B,
+    float *__restrict__ h0, float *__restrict__ h1, float *__restrict__ h2,
+    float *__restrict__ logit) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = FD + Dn;
+  const int Kp = ((K + 63) / 64) * 64;
+  const int LDW = Kp + 4;
+  float *W0t = smem;                         // [32][LDW]: W0t[u][k] = W0[k][u]
+  float *WA = W0t + 32 * LDW;                // [NL-1][16][2][32]: W_l[u(s,h)][c]
+  float *bs = WA + (NL - 1) * 1024;          // [NL][32] biases, then [32] w_out
+  float *xs_all = bs + (NL + 1) * 32;        // [8 waves][32][kLDX]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+
+  for (int t = tid; t < 32 * Kp; t += 512) {
+    const int u = t / Kp, k = t - u * Kp;
+    W0t[u * LDW + k] = (k < K && u < w.H[0]) ? w.W[0][(int64_t)k * w.H[0] + u] : 0.f;
+  }
+#pragma unroll
+  for (int l = 1; l < NL; ++l)
+    for (int t = tid; t < 1024; t += 512) {
+      const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
+      const int ku = unit_of(s, hh);
+      WA[(l - 1) * 1024 + t] =
+          (ku < w.H[l - 1] && cc < w.H[l]) ? w.W[l][ku * w.H[l] + cc] : 0.f;
+    }
+  for (int t = tid; t < (NL + 1) * 32; t += 512) {
+    const int l = t >> 5, u = t & 31;
+    float v = 0.f;
+    if (l < NL) v = u < w.H[l] ? w.b[l][u] : 0.f;
+    else v = u < w.H[NL - 1] ? w_out[u] : 0.f;
+    bs[t] = v;
+  }
+  __syncthreads();
+
+  float *xs = xs_all + wave * 32 * kLDX;
+  const int nch = Kp / 64;
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
+    const int64_t ex0 = tile * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 pf[8];
+    load_chunk(pf, xe, xd, FD, Dn, B, ex0, 0, lane);
+    for (int ch = 0; ch < nch; ++ch) {
+      store_chunk(xs, pf, lane);
+      if (ch + 1 < nch) load_chunk(pf, xe, xd, FD, Dn, B, ex0, (ch + 1) * 64, lane);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(W0t + c * LDW + ch * 64 + 8 * u + 4 * h);
+        const float4 b4 = *reinterpret_cast<const float4 *>(xs + c * kLDX + 8 * u + 4 * h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      }
+    }
+    const int64_t b = ex0 + c;
+    const bool valid = b < B;
+    float hv[16];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (l > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WA[(l - 1) * 1024 + (s * 2 + h) * 32 + c],
+                                                     hv[s], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hv[r] = actf(acc[r] + bs[l * 32 + unit_of(r, h)], act);
+      float *hp = l == 0 ? h0 : (l == 1 ? h1 : h2);
+      if (valid && hp != nullptr) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<float4 *>(hp + b * 32 + 8 * gq + 4 * h) =
+              make_float4(hv[4 * gq], hv[4 * gq + 1], hv[4 * gq + 2], hv[4 * gq + 3]);
+      }
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part += hv[r] * bs[NL * 32 + unit_of(r, h)];
+    part += __shfl_xor(part, 32, 64);
+    if (valid && h == 0) logit[b] = part + (w0_out ? w0_out[0] : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward: dh chain in registers, dX (+ FM term) -> d_rows, dW0 accumulated on the MFMA
+// ---------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(
+    const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn, MlpW w,
+    const float *__restrict__ w_out, int act, int64_t B, const float *__restrict__ g,
+    const float *__restrict__ h0, const float *__restrict__ h1, const float *__restrict__ h2,
+    const float *__restrict__ fm_sum, int D, float *__restrict__ d_rows, float *__restrict__ dh0,
+    float *__restrict__ dh1, float *__restrict__ dh2, float *__restrict__ dW0_part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = FD + Dn;
+  const int Kp = ((K + 63) / 64) * 64;
+  constexpr int LDR = 36;
+  float *W0r = smem;                         // [Kp][36]: W0r[k][u] = W0[k][u]
+  float *WB = W0r + Kp * LDR;                // [NL-1][16][2][32]: W_l[c][u(s,h)]
+  float *wo = WB + (NL - 1) * 1024;          // [32] w_out
+  float *xs_all = wo + 32;                   // [4 waves][32][kLDX]
+  float *dT_all = xs_all + 4 * 32 * kLDX;    // [4 waves][32][33]: dh0 as [example][unit]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+
+  for (int t = tid; t < Kp * 32; t += 256) {
+    const int k = t >> 5, u = t & 31;
+    W0r[k * LDR + u] = (k < K && u < w.H[0]) ? w.W[0][(int64_t)k * w.H[0] + u] : 0.f;
+  }
+#pragma unroll
+  for (int l = 1; l < NL; ++l)
+    for (int t = tid; t < 1024; t += 256) {
+      const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
+      const int ku = unit_of(s, hh);  // unit of layer l (the reduction index)
+      WB[(l - 1) * 1024 + t] =
+          (cc < w.H[l - 1] && ku < w.H[l]) ? w.W[l][cc * w.H[l] + ku] : 0.f;
+    }
+  if (tid < 32) wo[tid] = tid < w.H[NL - 1] ? w_out[tid] : 0.f;
+  __syncthreads();
+
+  float *xs = xs_all + wave * 32 * kLDX;
+  float *dT = dT_all + wave * 32 * 33;
+  const int nch = Kp / 64;
+  const int nkt = Kp / 32;
+  f32x16 accw[14];  // dW0 partial: up to 14 k-tiles (Kp <= 448)
+#pragma unroll
+  for (int t = 0; t < 14; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[t][r] = 0.f;
+
+  const int64_t ntiles = (B + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t ex0 = tile * 32;
+    const int64_t b = ex0 + c;
+    const bool valid = b < B;
+    const int64_t bb = valid ? b : B - 1;
+    float4 pf[8];
+    load_chunk(pf, xe, xd, FD, Dn, B, ex0, 0, lane);
+    const float gb = valid ? g[bb] : 0.f;
+    // ---- dh chain ----
+    float dh[16];
+    {
+      const float *hl = NL == 1 ? h0 : (NL == 2 ? h1 : h2);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const float4 hv = *reinterpret_cast<const float4 *>(hl + bb * 32 + 8 * gq + 4 * h);
+        dh[4 * gq + 0] = gb * wo[8 * gq + 4 * h + 0] * actg(hv.x, act);
+        dh[4 * gq + 1] = gb * wo[8 * gq + 4 * h + 1] * actg(hv.y, act);
+        dh[4 * gq + 2] = gb * wo[8 * gq + 4 * h + 2] * actg(hv.z, act);
+        dh[4 * gq + 3] = gb * wo[8 * gq + 4 * h + 3] * actg(hv.w, act);
+      }
+    }
+#pragma unroll
+    for (int l = NL - 1; l >= 1; --l) {
+      float *dout = l == 1 ? dh1 : dh2;
+      if (valid) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<float4 *>(dout + b * 32 + 8 * gq + 4 * h) =
+              make_float4(dh[4 * gq], dh[4 * gq + 1], dh[4 * gq + 2], dh[4 * gq + 3]);
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[(l - 1) * 1024 + (s * 2 + h) * 32 + c], dh[s],
+                                                   acc, 0, 0, 0);
+      const float *hprev = l == 1 ? h0 : h1;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const float4 hv = *reinterpret_cast<const float4 *>(hprev + bb * 32 + 8 * gq + 4 * h);
+        dh[4 * gq + 0] = acc[4 * gq + 0] * actg(hv.x, act);
+        dh[4 * gq + 1] = acc[4 * gq + 1] * actg(hv.y, act);
+        dh[4 * gq + 2] = acc[4 * gq + 2] * actg(hv.z, act);
+        dh[4 * gq + 3] = acc[4 * gq + 3] * actg(hv.w, act);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<float4 *>(dh0 + b * 32 + 8 * gq + 4 * h) =
+            make_float4(dh[4 * gq], dh[4 * gq + 1], dh[4 * gq + 2], dh[4 * gq + 3]);
+    }
+    // dh0 as [example][unit] for the dW0 product (B operand: lane = unit)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dT[c * 33 + unit_of(r, h)] = valid ? dh[r] : 0.f;
+
+    // ---- sweep x: dX tiles (-> d_rows) and dW0 tiles ----
+    for (int ch = 0; ch < nch; ++ch) {
+      store_chunk(xs, pf, lane);
+      if (ch + 1 < nch) load_chunk(pf, xe, xd, FD, Dn, B, ex0, (ch + 1) * 64, lane);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int kb = ch * 64 + kt * 32;
+        if (kb < FD) {  // dX only for the embedding part of x
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(W0r + (kb + c) * LDR + 8 * gq + 4 * h);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, dh[4 * gq + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, dh[4 * gq + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, dh[4 * gq + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, dh[4 * gq + 3], acc, 0, 0, 0);
+          }
+          // acc[r] = dX[example c][k = kb + u(r,h)]
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int k = kb + 8 * gq + 4 * h;
+            if (k < FD && valid) {
+              float4 o = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+              if (fm_sum != nullptr) {
+                const float4 e = *reinterpret_cast<const float4 *>(xs + c * kLDX + kt * 32 + 8 * gq + 4 * h);
+                const float4 s4 = *reinterpret_cast<const float4 *>(fm_sum + b * D + (k % D));
+                o.x += gb * (s4.x - e.x); o.y += gb * (s4.y - e.y);
+                o.z += gb * (s4.z - e.z); o.w += gb * (s4.w - e.w);
+              }
+              *reinterpret_cast<float4 *>(d_rows + b * FD + k) = o;
+            }
+          }
+        }
+        // dW0[kb + c'][unit] += sum_ex x[ex][kb + c'] * dh0[ex][unit]
+        // accw is indexed by a compile-time t (registers); the wave-uniform branch picks the tile
+        const int ktg = ch * 2 + kt;
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+          if (t == ktg) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+              accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * s + h) * kLDX + kt * 32 + c],
+                                                            dT[(2 * s + h) * 33 + c], accw[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- block reduction of the dW0 partials through LDS, then one slab per block ----
+  __syncthreads();
+  float *red = smem;  // [Kp][32] (reuses W0r: Kp*32 <= Kp*36)
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int t = 0; t < 14; ++t) {
+        if (t < nkt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int idx = (t * 32 + unit_of(r, h)) * 32 + c;
+            red[idx] = (wv == 0 ? 0.f : red[idx]) + accw[t][r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int t = tid; t < Kp * 32; t += 256) dW0_part[(int64_t)blockIdx.x * Kp * 32 + t] = red[t];
+}
+
+// dW0[k][u] = sum_blocks part[blk][k][u]   (k < K, u < H0)
+__global__ void mlp_dw0_reduce_kernel(const float *__restrict__ part, int nblk, int K, int Kp, int H0,
+                                      float *__restrict__ dW0) {
+  const int total = K * H0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int k = t / H0, u = t - k * H0;
+    float acc = 0.f;
+    for (int i = 0; i < nblk; ++i) acc += part[((int64_t)i * Kp + k) * 32 + u];
+    dW0[t] = acc;
+  }
+}
+
+// out[p][q] = sum_b X[b][p] * Y[b][q]  for tiny P, Q <= 32 with row stride 32 (the dW_l of
+// the hidden layers: h_{l-1}^T dh_l).  Two-stage, deterministic.
+__global__ __launch_bounds__(256) void xty32_stage1(const float *__restrict__ X,
+                                                    const float *__restrict__ Y, int64_t B,
+                                                    float *__restrict__ part) {
+  __shared__ float xs[64][33], ys[64][33];
+  const int tid = threadIdx.x;
+  const int p = tid >> 3, q0 = (tid & 7) * 4;  // thread owns out[p][q0..q0+3]
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int64_t rows_per_block = (B + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
+  for (int64_t rb = r0; rb < r1; rb += 64) {
+    __syncthreads();
+    for (int t = tid; t < 64 * 32; t += 256) {
+      const int rr = t >> 5, cc = t & 31;
+      const int64_t row = rb + rr;
+      xs[rr][cc] = row < r1 ? X[row * 32 + cc] : 0.f;
+      ys[rr][cc] = row < r1 ? Y[row * 32 + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int rr = 0; rr < 64; ++rr) {
+      const float xv = xs[rr][p];
+      a0 += xv * ys[rr][q0]; a1 += xv * ys[rr][q0 + 1];
+      a2 += xv * ys[rr][q0 + 2]; a3 += xv * ys[rr][q0 + 3];
+    }
+  }
+  float *o = part + (int64_t)blockIdx.x * 1024 + p * 32 + q0;
+  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+}
+
+__global__ void xty32_stage2(const float *__restrict__ part, int nblk, int P, int Q,
+                             float *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P * Q) return;
+  const int p = t / Q, q = t - p * Q;
+  float acc = 0.f;
+  for (int i = 0; i < nblk; ++i) acc += part[(int64_t)i * 1024 + p * 32 + q];
+  out[t] = acc;
+}
+
+size_t mlp_fwd_smem(int K, int NL) {
+  const int Kp = ((K + 63) / 64) * 64;
+  return (size_t)(32 * (Kp + 4) + (NL - 1) * 1024 + (NL + 1) * 32 + 8 * 32 * kLDX) * sizeof(float);
+}
+size_t mlp_bwd_smem(int K, int NL) {
+  const int Kp = ((K + 63) / 64) * 64;
+  return (size_t)(Kp * 36 + (NL - 1) * 1024 + 32 + 4 * 32 * kLDX + 4 * 32 * 33) * sizeof(float);
+}
+
+int mlp_check(const char *fn, int FD, int Dn, int NL, const int *H) {
+  RM_REQUIRE(NL >= 1 && NL <= kMaxNL, "%s: %d hidden layers unsupported (1..3)", fn, NL);
+  for (int l = 0; l < NL; ++l)
+    RM_REQUIRE(H[l] >= 1 && H[l] <= 32, "%s: hidden width %d unsupported (<= 32)", fn, H[l]);
+  RM_REQUIRE(FD >= 0 && Dn >= 0 && FD % 4 == 0 && FD + Dn >= 1 && FD + Dn <= 448,
+             "%s: input width %d+%d unsupported (FD %% 4 == 0, FD+Dn <= 448)", fn, FD, Dn);
+  return RM_OK;
+}
+
+}  // namespace
+
+extern "C" int rm_mlp_supported(int FD, int Dn, int NL, const int *H) {
+  if (NL < 1 || NL > kMaxNL || FD % 4 != 0 || FD + Dn < 1 || FD + Dn > 448) return 0;
+  for (int l = 0; l < NL; ++l)
+    if (H[l] < 1 || H[l] > 32) return 0;
+  return 1;
+}
+
+extern "C" int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
+                          const float *const *W, const float *const *bias, const float *w_out,
+                          const float *w0_out, int act, int64_t B, float *const *h_out,
+                          float *logit, rm_stream_t stream) {
+  int rc = mlp_check("rm_mlp_fwd", FD, Dn, NL, H);
+  if (rc != RM_OK) return rc;
+  if (B == 0) return RM_OK;
+  RM_REQUIRE((FD == 0 || (xe && rm_aligned16(xe))) && (Dn == 0 || xd) && W && bias && w_out && logit &&
+                 h_out, "rm_mlp_fwd: NULL or unaligned argument");
+  MlpW w;
+  for (int l = 0; l < kMaxNL; ++l) {
+    w.W[l] = l < NL ? W[l] : nullptr;
+    w.b[l] = l < NL ? bias[l] : nullptr;
+    w.H[l] = l < NL ? H[l] : 0;
+  }
+  const size_t smem = mlp_fwd_smem(FD + Dn, NL);
+  const int64_t ntiles = (B + 31) / 32;
+  dim3 grid((unsigned)rm_grid_cap((ntiles + 7) / 8, 256));
+  hipStream_t st = (hipStream_t)stream;
+  float *h0 = h_out[0], *h1 = NL > 1 ? h_out[1] : nullptr, *h2 = NL > 2 ? h_out[2] : nullptr;
+#define RM_MLP_FWD(NL_)                                                                        \
+  {                                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwd_kernel<NL_>),             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);          \
+    hipLaunchKernelGGL((mlp_fwd_kernel<NL_>), grid, dim3(512), smem, st, xe, xd, FD, Dn, w,    \
+                       w_out, w0_out, act, B, h0, h1, h2, logit);                              \
+  }
+  if (NL == 1) RM_MLP_FWD(1) else if (NL == 2) RM_MLP_FWD(2) else RM_MLP_FWD(3)
+#undef RM_MLP_FWD
+  RM_CHECK_LAUNCH("rm_mlp_fwd");
+  return RM_OK;
+}
+
+extern "C" int64_t rm_mlp_bwd_workspace(int FD, int Dn) {
+  const int Kp = ((FD + Dn + 63) / 64) * 64;
+  return (int64_t)256 * Kp * 32 + 256 * 1024;
+}
+
+extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
+                          const float *const *W, const float *w_out, int act, int64_t B,
+                          const float *g, const float *const *h, const float *fm_sum, int D,
+                          float *d_rows, float *const *dh, float *const *dW, float *workspace,
+                          rm_stream_t stream) {
+  int rc = mlp_check("rm_mlp_bwd", FD, Dn, NL, H);
+  if (rc != RM_OK) return rc;
+  if (B == 0) return RM_OK;
+  RM_REQUIRE((FD == 0 || (xe && rm_aligned16(xe))) && (Dn == 0 || xd) && W && w_out && g && h && dh &&
+                 dW && workspace && (FD == 0 || (d_rows && rm_aligned16(d_rows))),
+             "rm_mlp_bwd: NULL or unaligned argument");
+  RM_REQUIRE(!fm_sum || (D > 0 && D % 4 == 0 && rm_aligned16(fm_sum)), "rm_mlp_bwd: bad fm_sum / D");
+  MlpW w;
+  for (int l = 0; l < kMaxNL; ++l) {
+    w.W[l] = l < NL ? W[l] : nullptr;
+    w.b[l] = nullptr;
+    w.H[l] = l < NL ? H[l] : 0;
+  }
+  const int K = FD + Dn, Kp = ((K + 63) / 64) * 64;
+  const size_t smem = mlp_bwd_smem(K, NL);
+  const int64_t ntiles = (B + 31) / 32;
+  const int nblk = rm_grid_cap((ntiles + 3) / 4, 256);
+  hipStream_t st = (hipStream_t)stream;
+  float *part = workspace;
+  float *part2 = workspace + (int64_t)256 * Kp * 32;
+#define RM_MLP_BWD(NL_)                                                                          \
+  {                                                                                              \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_kernel<NL_>),               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
+    hipLaunchKernelGGL((mlp_bwd_kernel<NL_>), dim3(nblk), dim3(256), smem, st, xe, xd, FD, Dn, w, \
+                       w_out, act, B, g, h[0], NL > 1 ? h[1] : nullptr, NL > 2 ? h[2] : nullptr, \
+                       fm_sum, D, d_rows, dh[0], NL > 1 ? dh[1] : nullptr,                       \
+                       NL > 2 ? dh[2] : nullptr, part);                                          \
+  }
+  if (NL == 1) RM_MLP_BWD(1) else if (NL == 2) RM_MLP_BWD(2) else RM_MLP_BWD(3)
+#undef RM_MLP_BWD
+  hipLaunchKernelGGL(mlp_dw0_reduce_kernel, dim3(64), dim3(256), 0, st, part, nblk, K, Kp, H[0], dW[0]);
+  for (int l = 1; l < NL; ++l) {
+    hipLaunchKernelGGL(xty32_stage1, dim3(256), dim3(256), 0, st, h[l - 1], dh[l], B, part2);
+    hipLaunchKernelGGL(xty32_stage2, dim3(4), dim3(256), 0, st, part2, 256, H[l - 1], H[l], dW[l]);
+  }
+  RM_CHECK_LAUNCH("rm_mlp_bwd");
+  return RM_OK;
+}

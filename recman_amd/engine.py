@@ -92,11 +92,21 @@ class MLP:
             grads[nm] = torch.zeros(shape, dtype=F32, device=device)
         self._B = None
         self._ws = None
+        # hand-written fused f32-MFMA path for skinny MLPs (csrc/mlp.hip); wider ones
+        # (DCN's [400,400]) are library GEMMs
+        self.fused_ok = bool(FD % 4 == 0 and ops.mlp_supported(FD, Dn, self.hidden))
+        self.fused = False
 
     def _alloc(self, B, device):
         if self._B == B:
             return
         self._B = B
+        if self.fused_ok:
+            self.hb = [torch.zeros(B, 32, dtype=F32, device=device) for _ in self.hidden]
+            self.dhb = [torch.zeros(B, 32, dtype=F32, device=device) for _ in self.hidden]
+            self.fws = torch.empty(ops.mlp_bwd_workspace(self.FD, self.Dn), dtype=F32, device=device)
+            self.ones = torch.ones(B, dtype=F32, device=device)
+            self.tmp32 = torch.empty(32, dtype=F32, device=device)
         self.a = [torch.empty(B, h, dtype=F32, device=device) for h in self.hidden]
         self.da = [torch.empty(B, h, dtype=F32, device=device) for h in self.hidden]
         self.out = torch.empty(B, 1, dtype=F32, device=device)
@@ -118,6 +128,14 @@ class MLP:
         self.keep = keep if keep is not None else [1] * (n + 1)
         self.masks = masks if masks is not None else [None] * (n + 1)
         self.xe, self.xd = xe, xd
+        dropping = any(k < 1 and mk is not None for k, mk in zip(self.keep, self.masks))
+        self.fused = self.fused_ok and not dropping
+        if self.fused:
+            ops.mlp_fwd(xe, xd if self.Dn else None,
+                        [p[f"{pre}dnn_layer_{i}_weights"] for i in range(n)],
+                        [p[f"{pre}dnn_layer_{i}_bias"] for i in range(n)], p[f"{pre}dnn_w"].view(-1),
+                        p[f"{pre}dnn_w0"], self.act, self.hb, self.out.view(B))
+            return self.out.view(B)
         if self.keep[0] < 1 and self.masks[0] is not None:
             m = self.masks[0] / self.keep[0]
             xe = xe * m[:, : self.FD]
@@ -138,11 +156,24 @@ class MLP:
         ops.rowdot(self.a[-1], p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"], self.out.view(B))
         return self.out.view(B)
 
-    def backward(self, g, dxe):
+    def backward(self, g, dxe, fm_sum=None):
         """g [B] = dLoss/dlogit; writes dLoss/dxe into dxe [B,FD] and the parameter
-        gradients into self.g.  (No gradient is needed for the dense inputs.)"""
+        gradients into self.g.  (No gradient is needed for the dense inputs.)
+        fm_sum [B,D]: also add the FM second-order gradient g*(S - E) (fused path only;
+        returns True when it was added)."""
         p, gr, pre = self.p, self.g, self.prefix
         n = len(self.hidden)
+        if self.fused:
+            Ws = [p[f"{pre}dnn_layer_{i}_weights"] for i in range(n)]
+            ops.mlp_bwd(self.xe, self.xd if self.Dn else None, Ws, p[f"{pre}dnn_w"].view(-1), self.act,
+                        g, self.hb, dxe, self.dhb, [gr[f"{pre}dnn_layer_{i}_weights"] for i in range(n)],
+                        self.fws, fm_sum=fm_sum)
+            for i in range(n):  # bias gradients: column sums of dh_i
+                ops.linear_dense_bwd(self.ones, self.dhb[i], self.tmp32, None, self.fws)
+                gr[f"{pre}dnn_layer_{i}_bias"].copy_(self.tmp32[: self.hidden[i]])
+            ops.linear_dense_bwd(g, self.hb[-1], self.tmp32, gr[f"{pre}dnn_w0"], self.fws)
+            gr[f"{pre}dnn_w"].view(-1).copy_(self.tmp32[: self.hidden[-1]])
+            return fm_sum is not None
         g2 = g.view(-1, 1)
         if self._ws is None or self._ws.device != g.device:
             self._ws = torch.empty(256 * 1024, dtype=F32, device=g.device)
@@ -176,6 +207,7 @@ class MLP:
                 torch.mm(self.a[i - 1].t(), da, out=gW)
                 torch.mm(da, W.t(), out=self.da[i - 1])
                 da = self.da[i - 1]
+        return False
 
     def l2(self, reg):
         ws = [self.p[f"{self.prefix}dnn_layer_{i}_weights"] for i in range(len(self.hidden))]
@@ -481,16 +513,19 @@ class DeepFMEngine(Engine):
         m = masks or {}
         fm_masks = m.get("fm", (None, None))
         dE_up = None
-        if self.use_deep:
-            self.mlp.backward(g, self.d_rows.view(-1, self.FD))
-            dE_up = self.d_rows
+        fm_done = False
         self.d_bias = None
+        if self.use_deep:
+            # fused path: the FM gradient g*(S - E) rides along in the MLP backward
+            fuse_fm = self.use_fm and fm_masks[0] is None and fm_masks[1] is None
+            fm_done = self.mlp.backward(g, self.d_rows.view(-1, self.FD),
+                                        fm_sum=self.fm_sum if fuse_fm else None)
+            dE_up = self.d_rows
         if self.use_fm and fm_masks[0] is not None:
             self.d_bias = torch.empty(idx.shape[0], self.F, dtype=F32, device=self.device)
-        ops.embed_bwd(self.d_rows, E=self.E if self.use_fm else None,
-                      fm_sum=self.fm_sum if self.use_fm else None, dE_up=dE_up,
-                      g_fm=g if self.use_fm else None, mask_b=fm_masks[0], mask_e=fm_masks[1],
-                      d_bias=self.d_bias)
+        if self.use_fm and not fm_done:
+            ops.embed_bwd(self.d_rows, E=self.E, fm_sum=self.fm_sum, dE_up=dE_up, g_fm=g,
+                          mask_b=fm_masks[0], mask_e=fm_masks[1], d_bias=self.d_bias)
         if self.use_deep:
             reg = self.hp.get("deep_l2_reg", 0.0)
             if reg:

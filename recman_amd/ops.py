@@ -3,6 +3,8 @@ reference raises Python asserts before any arithmetic, layers.py:49,85,458,521-5
 raw pointers and sizes across the boundary, kernels enqueued on torch's current
 stream.  torch is plumbing here: device memory and streams, nothing else.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -227,3 +229,53 @@ def rowdot(X, w, w0, out):
     _lib.call("rm_rowdot", _chk(X, "X", F32), _chk(w, "w", F32, (P_,)),
               _chk(w0, "w0", F32, (1,), allow_none=True), B, P_, _chk(out, "out", F32, (B,)),
               _stream())
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def mlp_supported(FD, Dn, hidden):
+    return bool(_lib.lib().rm_mlp_supported(FD, Dn, len(hidden), _int_array(hidden)))
+
+
+def mlp_bwd_workspace(FD, Dn):
+    return int(_lib.lib().rm_mlp_bwd_workspace(FD, Dn))
+
+
+def mlp_fwd(xe, xd, Ws, bs, w_out, w0_out, act, h_out, logit):
+    """Fused skinny-MLP forward.  Ws[l] / bs[l]: layer weights; h_out[l] [B,32]."""
+    B, FD = xe.shape
+    Dn = 0 if xd is None else xd.shape[1]
+    H = [W.shape[1] for W in Ws]
+    for l, W in enumerate(Ws):
+        _chk(W, f"W[{l}]", F32, (FD + Dn if l == 0 else H[l - 1], H[l]))
+        _chk(bs[l], f"bias[{l}]", F32, (H[l],))
+        _chk(h_out[l], f"h_out[{l}]", F32, (B, 32))
+    _lib.call("rm_mlp_fwd", _chk(xe, "xe", F32), _chk(xd, "xd", F32, (B, Dn), allow_none=True), FD,
+              Dn, len(Ws), _int_array(H), _ptr_array(Ws), _ptr_array(bs),
+              _chk(w_out, "w_out", F32, (H[-1],)), _chk(w0_out, "w0_out", F32, (1,)), ACT_IDS[act], B,
+              _ptr_array(h_out), _chk(logit, "logit", F32, (B,)), _stream())
+
+
+def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None):
+    B, FD = xe.shape
+    Dn = 0 if xd is None else xd.shape[1]
+    H = [W.shape[1] for W in Ws]
+    for l, W in enumerate(Ws):
+        _chk(W, f"W[{l}]", F32, (FD + Dn if l == 0 else H[l - 1], H[l]))
+        _chk(dW[l], f"dW[{l}]", F32, tuple(W.shape))
+        _chk(h[l], f"h[{l}]", F32, (B, 32))
+        _chk(dh[l], f"dh[{l}]", F32, (B, 32))
+    if workspace.numel() < mlp_bwd_workspace(FD, Dn):
+        raise ValueError("mlp_bwd: workspace too small")
+    D = 0 if fm_sum is None else fm_sum.shape[1]
+    _lib.call("rm_mlp_bwd", _chk(xe, "xe", F32), _chk(xd, "xd", F32, (B, Dn), allow_none=True), FD,
+              Dn, len(Ws), _int_array(H), _ptr_array(Ws), _chk(w_out, "w_out", F32, (H[-1],)),
+              ACT_IDS[act], B, _chk(g, "g", F32, (B,)), _ptr_array(h),
+              _chk(fm_sum, "fm_sum", F32, allow_none=True), D, _chk(d_rows, "d_rows", F32, (B, FD)),
+              _ptr_array(dh), _ptr_array(dW), _chk(workspace, "workspace", F32), _stream())
