@@ -142,8 +142,9 @@ int rm_logit_loss(const float *logit_a, float coef_a, const float *logit_b, floa
  * rm_mlp_bwd: g [B] = dLoss/dlogit; writes dLoss/dxe into d_rows [B,FD]; when fm_sum
  *   (S [B,D] from rm_embed_fwd) is given the FM second-order gradient g*(S - E) is added
  *   (xe is E: the whole DeepFM row gradient in one pass, no rm_embed_bwd launch);
- *   dh[l] [B,32] = dLoss/d(pre-activation of layer l); dW[l] = weight gradients (the bias
- *   gradients are the column sums of dh[l]: rm_linear_dense_bwd).
+ *   dh[l] [B,32] = dLoss/d(pre-activation of layer l); dW[l] / db[l] = weight / bias
+ *   gradients, d_w_out [H_last], d_w0_out [1] = gradients of the output projection
+ *   (db, d_w_out, d_w0_out may be NULL).  Deterministic (no float atomics).
  *   workspace: rm_mlp_bwd_workspace(FD, Dn) floats. */
 int rm_mlp_supported(int FD, int Dn, int NL, const int *H);
 int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
@@ -154,7 +155,8 @@ int64_t rm_mlp_bwd_workspace(int FD, int Dn);
 int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
                const float *const *W, const float *w_out, int act, int64_t B, const float *g,
                const float *const *h, const float *fm_sum, int D, float *d_rows,
-               float *const *dh, float *const *dW, float *workspace, rm_stream_t stream);
+               float *const *dh, float *const *dW, float *const *db, float *d_w_out,
+               float *d_w0_out, float *workspace, rm_stream_t stream);
 
 /* out[b] = sum_j X[b,j]*w[j] + w0[0]: the [*,1] output projections (dnn_w/dnn_w0,
  * layers.py:606-609; cin_w/cin_w0, layers.py:757-760).  w0 may be NULL. */

@@ -109,6 +109,95 @@ __global__ __launch_bounds__(kBlock) void embed_fwd_kernel(
   }
 }
 
+// Fused-row variant: the table row is [D embedding floats | bias | linear weight | pad]
+// with a power-of-two stride LD >= D + 4, so ONE aligned line per lookup carries all
+// three values (measured, tools/bench_embed.py: separate 4-byte bias / linear gathers
+// cost as much as the 64-byte row gather itself - the gather is bound by line requests,
+// not bytes).  G = LD/4 lanes own an example; lanes sub < GE = D/4 hold the embedding
+// slices, lane sub == GE holds (bias, lin, -, -), lanes above it issue no load.
+template <int G, int GE, bool MASK>
+__global__ __launch_bounds__(kBlock) void embed_fwd_fused_kernel(
+    const int64_t *__restrict__ idx, const float *__restrict__ table,
+    const int64_t *__restrict__ field_off, const float *__restrict__ lin_w_dense,
+    const float *__restrict__ lin_w0, const float *__restrict__ dense, int Dn,
+    const float *__restrict__ mask_b, const float *__restrict__ mask_e, int64_t B, int F,
+    int want_bias, int want_lin, float *__restrict__ E, float *__restrict__ fm_sum,
+    float *__restrict__ fm_logit, float *__restrict__ lin_logit) {
+  constexpr int EPW = 64 / G;
+  constexpr int D = 4 * GE;
+  constexpr int LD = 4 * G;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % G;
+  const int ex = lane / G;
+  const bool emb = sub < GE;
+  const bool side = sub == GE && (want_bias || want_lin);
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+
+  for (int64_t b0 = wave * EPW; b0 < B; b0 += nwaves * EPW) {
+    const int64_t b = b0 + ex;
+    const bool valid = b < B;
+    const int64_t bb = valid ? b : B - 1;
+    const int64_t *ip = idx + bb * F;
+    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ss = 0.f, y1 = 0.f, lin = 0.f;
+    for (int f0 = 0; f0 < F; f0 += kUnroll) {
+      int64_t r[kUnroll];
+      float4 v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int f = f0 + u < F ? f0 + u : F - 1;
+        r[u] = ip[f];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int f = f0 + u < F ? f0 + u : F - 1;
+        const int64_t row = field_off[f] + r[u];
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (emb || side) v[u] = *reinterpret_cast<const float4 *>(table + row * LD + sub * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int f = f0 + u;
+        if (f < F) {
+          if (emb) {
+            if (E != nullptr && valid)
+              *reinterpret_cast<float4 *>(E + (bb * F + f) * D + sub * 4) = v[u];
+            float4 m = v[u];
+            if (MASK && mask_e != nullptr) {
+              const float4 mk =
+                  *reinterpret_cast<const float4 *>(mask_e + (bb * F + f) * D + sub * 4);
+              m.x *= mk.x; m.y *= mk.y; m.z *= mk.z; m.w *= mk.w;
+            }
+            S.x += m.x; S.y += m.y; S.z += m.z; S.w += m.w;
+            ss += m.x * m.x + m.y * m.y + m.z * m.z + m.w * m.w;
+          } else if (side) {
+            float bv = v[u].x;
+            if (MASK && mask_b != nullptr) bv *= mask_b[bb * F + f];
+            y1 += bv;
+            lin += v[u].y;
+          }
+        }
+      }
+    }
+    if (fm_sum != nullptr && valid && emb) *reinterpret_cast<float4 *>(fm_sum + bb * D + sub * 4) = S;
+    float part = emb ? S.x * S.x + S.y * S.y + S.z * S.z + S.w * S.w - ss : 0.f;
+    part = rm_group_sum<G>(part);
+    y1 = rm_group_sum<G>(y1);
+    lin = rm_group_sum<G>(lin);
+    if (valid && sub == 0) {
+      if (fm_logit != nullptr) fm_logit[bb] = (want_bias ? y1 : 0.f) + 0.5f * part;
+      if (lin_logit != nullptr) {
+        float l = want_lin ? lin : 0.f;
+        if (dense != nullptr)
+          for (int j = 0; j < Dn; ++j) l += dense[bb * Dn + j] * lin_w_dense[j];
+        if (lin_w0 != nullptr) l += lin_w0[0];
+        lin_logit[bb] = l;
+      }
+    }
+  }
+}
+
 // Backward: purely elementwise over the [B, F*D/4] float4 grid once S is saved.
 template <bool MASK>
 __global__ __launch_bounds__(kBlock) void embed_bwd_kernel(
@@ -281,11 +370,46 @@ extern "C" int rm_embed_fwd(const int64_t *idx, const float *table, int64_t tabl
   RM_REQUIRE(!(lin_logit && dense) || lin_w_dense, "rm_embed_fwd: dense given without lin_w_dense");
   RM_REQUIRE(Dn >= 0, "rm_embed_fwd: Dn < 0");
   const int G = D / 4;
+  hipStream_t st = (hipStream_t)stream;
+  const bool mask = mask_b != nullptr || mask_e != nullptr;
+  // fused-row layout: bias at column D and linear weight at column D+1 of the row itself
+  {
+    const bool pow2 = table_ld >= D + 4 && table_ld <= 256 && (table_ld & (table_ld - 1)) == 0;
+    const bool bias_in_row = !bias_table || (bias_table == table + D && bias_ld == table_ld);
+    const bool lin_in_row = !lin_w || (lin_w == table + D + 1 && lin_ld == table_ld && lin_off == field_off);
+    if (pow2 && bias_in_row && lin_in_row && table_ld == 2 * D && (bias_table || lin_w)) {
+      const int GF = (int)table_ld / 4;
+      const int epwf = 64 / GF;
+      const int64_t wavesf = (B + epwf - 1) / epwf;
+      dim3 gridf(rm_grid_cap((wavesf + 3) / 4, 256 * 16));
+      const int wb = bias_table != nullptr, wl = lin_w != nullptr;
+#define RM_EMBED_FUSED(GF_, GE_)                                                                  \
+  if (mask)                                                                                       \
+    hipLaunchKernelGGL((embed_fwd_fused_kernel<GF_, GE_, true>), gridf, dim3(kBlock), 0, st, idx, \
+                       table, field_off, lin_w_dense, lin_w0, dense, Dn, mask_b, mask_e, B, F, wb, \
+                       wl, E, fm_sum, fm_logit, lin_logit);                                       \
+  else                                                                                            \
+    hipLaunchKernelGGL((embed_fwd_fused_kernel<GF_, GE_, false>), gridf, dim3(kBlock), 0, st, idx, \
+                       table, field_off, lin_w_dense, lin_w0, dense, Dn, mask_b, mask_e, B, F, wb, \
+                       wl, E, fm_sum, fm_logit, lin_logit);
+      bool done = true;
+      if (GF == 2) { RM_EMBED_FUSED(2, 1) }
+      else if (GF == 4) { RM_EMBED_FUSED(4, 2) }
+      else if (GF == 8) { RM_EMBED_FUSED(8, 4) }
+      else if (GF == 16) { RM_EMBED_FUSED(16, 8) }
+      else if (GF == 32) { RM_EMBED_FUSED(32, 16) }
+      else if (GF == 64) { RM_EMBED_FUSED(64, 32) }
+      else done = false;
+#undef RM_EMBED_FUSED
+      if (done) {
+        RM_CHECK_LAUNCH("rm_embed_fwd");
+        return RM_OK;
+      }
+    }
+  }
   const int epw = 64 / G;
   const int64_t waves = (B + epw - 1) / epw;
   dim3 grid(rm_grid_cap((waves + 3) / 4, 256 * 16));
-  hipStream_t st = (hipStream_t)stream;
-  const bool mask = mask_b != nullptr || mask_e != nullptr;
 #define RM_EMBED_CASE(g)                                                                       \
   case g:                                                                                      \
     launch_embed_fwd<g>(mask, grid, st, idx, table, table_ld, field_off, bias_table, bias_ld,  \

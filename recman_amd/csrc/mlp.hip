@@ -341,58 +341,116 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(
   for (int t = tid; t < Kp * 32; t += 256) dW0_part[(int64_t)blockIdx.x * Kp * 32 + t] = red[t];
 }
 
-// dW0[k][u] = sum_blocks part[blk][k][u]   (k < K, u < H0)
-__global__ void mlp_dw0_reduce_kernel(const float *__restrict__ part, int nblk, int K, int Kp, int H0,
-                                      float *__restrict__ dW0) {
-  const int total = K * H0;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-    const int k = t / H0, u = t - k * H0;
-    float acc = 0.f;
-    for (int i = 0; i < nblk; ++i) acc += part[((int64_t)i * Kp + k) * 32 + u];
-    dW0[t] = acc;
-  }
+// dW0[k][u] = sum_blocks part[blk][k][u]   (k < K, u < H0): one wave per output,
+// fixed summation order -> deterministic
+__global__ __launch_bounds__(256) void mlp_dw0_reduce_kernel(const float *__restrict__ part, int nblk,
+                                                             int K, int Kp, int H0,
+                                                             float *__restrict__ dW0) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= K * H0) return;
+  const int k = t / H0, u = t - k * H0;
+  float acc = 0.f;
+  for (int i = lane; i < nblk; i += 64) acc += part[((int64_t)i * Kp + k) * 32 + u];
+  acc = rm_wave_sum(acc);
+  if (lane == 0) dW0[t] = acc;
 }
 
-// out[p][q] = sum_b X[b][p] * Y[b][q]  for tiny P, Q <= 32 with row stride 32 (the dW_l of
-// the hidden layers: h_{l-1}^T dh_l).  Two-stage, deterministic.
-__global__ __launch_bounds__(256) void xty32_stage1(const float *__restrict__ X,
-                                                    const float *__restrict__ Y, int64_t B,
-                                                    float *__restrict__ part) {
-  __shared__ float xs[64][33], ys[64][33];
+// Every remaining (tiny) gradient of the MLP in ONE pass over h_l / dh_l / g:
+//   dW_l = h_{l-1}^T dh_l (l >= 1), db_l = colsum(dh_l), d w_out = h_last^T g, d w0 = sum g.
+// Per-block partial layout: [(NL-1) x 1024 | NL x 32 | 32 | 1], padded to kSgStride.
+constexpr int kSgStride = 2 * 1024 + 3 * 32 + 32 + 32;
+template <int NL>
+__global__ __launch_bounds__(256) void mlp_small_grads_stage1(
+    const float *__restrict__ h0, const float *__restrict__ h1, const float *__restrict__ h2,
+    const float *__restrict__ d0, const float *__restrict__ d1, const float *__restrict__ d2,
+    const float *__restrict__ g, int64_t B, float *__restrict__ part) {
+  __shared__ float hs[NL][64][33], ds[NL][64][33], gs[64];
   const int tid = threadIdx.x;
-  const int p = tid >> 3, q0 = (tid & 7) * 4;  // thread owns out[p][q0..q0+3]
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int p = tid >> 3, q0 = (tid & 7) * 4;  // dW_l[p][q0..q0+3]
+  float aw[NL > 1 ? NL - 1 : 1][4];
+#pragma unroll
+  for (int l = 0; l < (NL > 1 ? NL - 1 : 1); ++l) aw[l][0] = aw[l][1] = aw[l][2] = aw[l][3] = 0.f;
+  float av = 0.f;  // threads 0..32*NL-1: db_l[q]; next 32: d w_out[q]; next 1: sum g
   const int64_t rows_per_block = (B + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
+  const float *hp[3] = {h0, h1, h2};
+  const float *dp[3] = {d0, d1, d2};
   for (int64_t rb = r0; rb < r1; rb += 64) {
     __syncthreads();
     for (int t = tid; t < 64 * 32; t += 256) {
       const int rr = t >> 5, cc = t & 31;
       const int64_t row = rb + rr;
-      xs[rr][cc] = row < r1 ? X[row * 32 + cc] : 0.f;
-      ys[rr][cc] = row < r1 ? Y[row * 32 + cc] : 0.f;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        hs[l][rr][cc] = row < r1 ? hp[l][row * 32 + cc] : 0.f;
+        ds[l][rr][cc] = row < r1 ? dp[l][row * 32 + cc] : 0.f;
+      }
     }
+    if (tid < 64) gs[tid] = rb + tid < r1 ? g[rb + tid] : 0.f;
     __syncthreads();
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
 #pragma unroll 8
-    for (int rr = 0; rr < 64; ++rr) {
-      const float xv = xs[rr][p];
-      a0 += xv * ys[rr][q0]; a1 += xv * ys[rr][q0 + 1];
-      a2 += xv * ys[rr][q0 + 2]; a3 += xv * ys[rr][q0 + 3];
+      for (int rr = 0; rr < 64; ++rr) {
+        const float xv = hs[l - 1][rr][p];
+        aw[l - 1][0] += xv * ds[l][rr][q0]; aw[l - 1][1] += xv * ds[l][rr][q0 + 1];
+        aw[l - 1][2] += xv * ds[l][rr][q0 + 2]; aw[l - 1][3] += xv * ds[l][rr][q0 + 3];
+      }
+    }
+    if (tid < 32 * NL) {
+      const int l = tid >> 5, q = tid & 31;
+      for (int rr = 0; rr < 64; ++rr) av += ds[l][rr][q];
+    } else if (tid < 32 * NL + 32) {
+      const int q = tid - 32 * NL;
+      for (int rr = 0; rr < 64; ++rr) av += gs[rr] * hs[NL - 1][rr][q];
+    } else if (tid == 32 * NL + 32) {
+      for (int rr = 0; rr < 64; ++rr) av += gs[rr];
     }
   }
-  float *o = part + (int64_t)blockIdx.x * 1024 + p * 32 + q0;
-  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  float *o = part + (int64_t)blockIdx.x * kSgStride;
+#pragma unroll
+  for (int l = 1; l < NL; ++l) {
+    float *ow = o + (l - 1) * 1024 + p * 32 + q0;
+    ow[0] = aw[l - 1][0]; ow[1] = aw[l - 1][1]; ow[2] = aw[l - 1][2]; ow[3] = aw[l - 1][3];
+  }
+  if (tid <= 32 * NL + 32) o[2 * 1024 + tid] = av;
 }
 
-__global__ void xty32_stage2(const float *__restrict__ part, int nblk, int P, int Q,
-                             float *__restrict__ out) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P * Q) return;
-  const int p = t / Q, q = t - p * Q;
+// one wave per output: out index space = [(NL-1)*1024 dW | NL*32 db | 32 dw_out | 1 dw0]
+struct SgOut {
+  float *dW[kMaxNL];  // dW[l] for l >= 1 ([H_{l-1}, H_l])
+  float *db[kMaxNL];
+  float *dw_out, *dw0;
+  int H[kMaxNL];
+};
+__global__ __launch_bounds__(256) void mlp_small_grads_stage2(const float *__restrict__ part, int nblk,
+                                                              int NL, SgOut o) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nW = (NL - 1) * 1024, nv = 32 * NL + 33;
+  if (t >= nW + nv) return;
+  const int src = t < nW ? t : 2 * 1024 + (t - nW);
   float acc = 0.f;
-  for (int i = 0; i < nblk; ++i) acc += part[(int64_t)i * 1024 + p * 32 + q];
-  out[t] = acc;
+  for (int i = lane; i < nblk; i += 64) acc += part[(int64_t)i * kSgStride + src];
+  acc = rm_wave_sum(acc);
+  if (lane != 0) return;
+  if (t < nW) {
+    const int l = 1 + t / 1024, pq = t % 1024, p = pq >> 5, q = pq & 31;
+    if (p < o.H[l - 1] && q < o.H[l]) o.dW[l][p * o.H[l] + q] = acc;
+  } else {
+    const int v = t - nW;
+    if (v < 32 * NL) {
+      const int l = v >> 5, q = v & 31;
+      if (q < o.H[l] && o.db[l]) o.db[l][q] = acc;
+    } else if (v < 32 * NL + 32) {
+      const int q = v - 32 * NL;
+      if (q < o.H[NL - 1] && o.dw_out) o.dw_out[q] = acc;
+    } else if (o.dw0) {
+      o.dw0[0] = acc;
+    }
+  }
 }
 
 size_t mlp_fwd_smem(int K, int NL) {
@@ -457,14 +515,14 @@ extern "C" int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int 
 
 extern "C" int64_t rm_mlp_bwd_workspace(int FD, int Dn) {
   const int Kp = ((FD + Dn + 63) / 64) * 64;
-  return (int64_t)256 * Kp * 32 + 256 * 1024;
+  return (int64_t)256 * Kp * 32 + 256 * kSgStride;
 }
 
 extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
                           const float *const *W, const float *w_out, int act, int64_t B,
                           const float *g, const float *const *h, const float *fm_sum, int D,
-                          float *d_rows, float *const *dh, float *const *dW, float *workspace,
-                          rm_stream_t stream) {
+                          float *d_rows, float *const *dh, float *const *dW, float *const *db,
+                          float *d_w_out, float *d_w0_out, float *workspace, rm_stream_t stream) {
   int rc = mlp_check("rm_mlp_bwd", FD, Dn, NL, H);
   if (rc != RM_OK) return rc;
   if (B == 0) return RM_OK;
@@ -496,10 +554,31 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
   }
   if (NL == 1) RM_MLP_BWD(1) else if (NL == 2) RM_MLP_BWD(2) else RM_MLP_BWD(3)
 #undef RM_MLP_BWD
-  hipLaunchKernelGGL(mlp_dw0_reduce_kernel, dim3(64), dim3(256), 0, st, part, nblk, K, Kp, H[0], dW[0]);
-  for (int l = 1; l < NL; ++l) {
-    hipLaunchKernelGGL(xty32_stage1, dim3(256), dim3(256), 0, st, h[l - 1], dh[l], B, part2);
-    hipLaunchKernelGGL(xty32_stage2, dim3(4), dim3(256), 0, st, part2, 256, H[l - 1], H[l], dW[l]);
+  hipLaunchKernelGGL(mlp_dw0_reduce_kernel, dim3((K * H[0] + 3) / 4), dim3(256), 0, st, part, nblk, K,
+                     Kp, H[0], dW[0]);
+  {
+    SgOut o;
+    for (int l = 0; l < kMaxNL; ++l) {
+      o.dW[l] = (l >= 1 && l < NL) ? dW[l] : nullptr;
+      o.db[l] = (l < NL && db) ? db[l] : nullptr;
+      o.H[l] = l < NL ? H[l] : 0;
+    }
+    o.dw_out = d_w_out;
+    o.dw0 = d_w0_out;
+    const float *h1p = NL > 1 ? h[1] : nullptr, *h2p = NL > 2 ? h[2] : nullptr;
+    const float *d1p = NL > 1 ? dh[1] : nullptr, *d2p = NL > 2 ? dh[2] : nullptr;
+    const int sblk = 256;
+    if (NL == 1)
+      hipLaunchKernelGGL((mlp_small_grads_stage1<1>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
+                         dh[0], d1p, d2p, g, B, part2);
+    else if (NL == 2)
+      hipLaunchKernelGGL((mlp_small_grads_stage1<2>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
+                         dh[0], d1p, d2p, g, B, part2);
+    else
+      hipLaunchKernelGGL((mlp_small_grads_stage1<3>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
+                         dh[0], d1p, d2p, g, B, part2);
+    const int nout = (NL - 1) * 1024 + 32 * NL + 33;
+    hipLaunchKernelGGL(mlp_small_grads_stage2, dim3((nout + 3) / 4), dim3(256), 0, st, part2, sblk, NL, o);
   }
   RM_CHECK_LAUNCH("rm_mlp_bwd");
   return RM_OK;

@@ -176,12 +176,11 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
             R = self.spec.rows
             self.st = ShardedTable(R, self.D, rank, world, dev, hip_gather, hip_permute, group)
             self.table = self.st.shard  # [R_local, D+4] fused rows
-            self.bias_table = None
-            self.linear_w = torch.zeros(self.Dn, dtype=torch.float32, device=dev)  # dense part only
+            self.linear_w_dense = torch.zeros(self.Dn, dtype=torch.float32, device=dev)
             self.field_off = torch.tensor(self.spec.offsets(), dtype=torch.int64, device=dev)
             self.lin_off = self.field_off
             self.params["table_shard"] = self.st.shard
-            self.params["linear_w_dense"] = self.linear_w
+            self.params["linear_w_dense"] = self.linear_w_dense
 
         def _alloc(self, B):
             first = self._B != B
@@ -205,7 +204,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
                 self._iota, self.rows, self._foff, table_ld=W, D=self.D,
                 bias_table=flat[self.D:] if want_fm else None, bias_ld=W,
                 lin_w=flat[self.D + 1:] if self.use_linear else None, lin_ld=W, lin_off=self._foff,
-                lin_w_dense=self.linear_w if (self.use_linear and self.Dn) else None,
+                lin_w_dense=self.linear_w_dense if (self.use_linear and self.Dn) else None,
                 lin_w0=self.params["linear_w0"] if self.use_linear else None,
                 dense=dense if (self.use_linear and self.Dn) else None,
                 mask_b=fm_masks[0] if want_fm else None, mask_e=fm_masks[1] if want_fm else None,

@@ -167,12 +167,9 @@ class MLP:
             Ws = [p[f"{pre}dnn_layer_{i}_weights"] for i in range(n)]
             ops.mlp_bwd(self.xe, self.xd if self.Dn else None, Ws, p[f"{pre}dnn_w"].view(-1), self.act,
                         g, self.hb, dxe, self.dhb, [gr[f"{pre}dnn_layer_{i}_weights"] for i in range(n)],
-                        self.fws, fm_sum=fm_sum)
-            for i in range(n):  # bias gradients: column sums of dh_i
-                ops.linear_dense_bwd(self.ones, self.dhb[i], self.tmp32, None, self.fws)
-                gr[f"{pre}dnn_layer_{i}_bias"].copy_(self.tmp32[: self.hidden[i]])
-            ops.linear_dense_bwd(g, self.hb[-1], self.tmp32, gr[f"{pre}dnn_w0"], self.fws)
-            gr[f"{pre}dnn_w"].view(-1).copy_(self.tmp32[: self.hidden[-1]])
+                        self.fws, fm_sum=fm_sum,
+                        db=[gr[f"{pre}dnn_layer_{i}_bias"] for i in range(n)],
+                        d_w_out=gr[f"{pre}dnn_w"].view(-1), d_w0_out=gr[f"{pre}dnn_w0"])
             return fm_sum is not None
         g2 = g.view(-1, 1)
         if self._ws is None or self._ws.device != g.device:
@@ -276,34 +273,74 @@ class Engine:
         self.use_linear = True
 
     def _alloc_tables(self):
-        """HBM layout: one [R, D] table, one [R] bias table, one linear vector; the
-        reference's per-feature variables are views (recman_amd/dist.py overrides this
-        with the row-sharded fused layout)."""
-        spec, dev, Dn = self.spec, self.device, self.Dn
+        """HBM layout: ONE table of fused rows [R, LD], LD = 2*D floats (a power of two, so a
+        row never straddles a 128-byte line): columns 0..D-1 the embedding, column D the FM
+        bias-table entry, column D+1 the sparse linear weight, the rest padding.  One line
+        fetch per lookup serves all three (tools/bench_embed.py: as separate tables the two
+        4-byte gathers cost as much as the row gather).  The reference's per-feature
+        variables are strided views of it; `linear_w` is assembled by state_dict().
+        (recman_amd/dist.py overrides this with the row-sharded layout.)"""
+        spec, dev, Dn, D = self.spec, self.device, self.Dn, self.D
         R = spec.rows
-        self.table = torch.zeros(R, self.D, dtype=F32, device=dev)
-        self.bias_table = torch.zeros(R, dtype=F32, device=dev) if self.use_bias_tables else None
-        self.linear_w = torch.zeros(R + Dn, dtype=F32, device=dev)  # utils.py:31-36 order
+        self.LD = 2 * D
+        self.rows = torch.zeros(R, self.LD, dtype=F32, device=dev)
+        self.table = self.rows
+        self.linear_w_dense = torch.zeros(Dn, dtype=F32, device=dev)
         offs = spec.offsets()
         self.field_off = torch.tensor(offs, dtype=I64, device=dev)
         self.lin_off = self.field_off  # sparse one-hot blocks share the table's row numbering
         for name, off, V in zip(spec.sparse_names, offs, spec.feat_sizes):
-            self.params[f"{name}_feat_embed"] = self.table[off: off + V]
+            self.params[f"{name}_feat_embed"] = self.rows[off: off + V, :D]
             if self.use_bias_tables:
-                self.params[f"{name}_feat_bias"] = self.bias_table[off: off + V].view(V, 1)
-        self.params["linear_w"] = self.linear_w.view(-1, 1)
+                self.params[f"{name}_feat_bias"] = self.rows[off: off + V, D: D + 1]
+        self.params["linear_w_sparse"] = self.rows[:, D + 1]
+        self.params["linear_w_dense"] = self.linear_w_dense
+
+    def storage(self):
+        """The distinct parameter buffers (for initialisers that fill storage in place)."""
+        seen, out = set(), []
+        for t in self.params.values():
+            base = t if t._base is None else t._base
+            if base.data_ptr() not in seen:
+                seen.add(base.data_ptr())
+                out.append(base)
+        return out
 
     # ------------------------------------------------------------------ storage
     def load_params(self, params):
         """Copies a name -> tensor dict (reference variable names) into the engine."""
+        R = self.spec.rows
         for k, v in params.items():
+            v = torch.as_tensor(v).to(self.device, F32)
+            if k == "linear_w":  # [sum V_f + Dn, 1]: one-hot blocks first, dense columns last
+                v = v.reshape(-1)
+                self.params["linear_w_sparse"].copy_(v[:R])
+                self.params["linear_w_dense"].copy_(v[R:])
+                continue
             if k not in self.params:
                 raise KeyError(f"unknown variable {k!r}")
             dst = self.params[k]
-            dst.copy_(torch.as_tensor(v).to(dst.device, F32).reshape(dst.shape))
+            dst.copy_(v.reshape(dst.shape))
 
     def state_dict(self):
-        return {k: v.detach().clone() for k, v in self.params.items()}
+        """name -> tensor under the reference's variable names (contiguous copies)."""
+        out = {}
+        for k, v in self.params.items():
+            if k in ("linear_w_sparse", "linear_w_dense"):
+                continue
+            out[k] = v.detach().clone().contiguous()
+        if "linear_w_sparse" in self.params:
+            out["linear_w"] = torch.cat([self.params["linear_w_sparse"].detach().reshape(-1),
+                                         self.params["linear_w_dense"].detach().reshape(-1)]).view(-1, 1)
+        return out
+
+    def to_reference_names(self, d):
+        """Merges the internal linear_w_sparse / linear_w_dense entries into `linear_w`."""
+        d = dict(d)
+        if "linear_w_sparse" in d:
+            d["linear_w"] = torch.cat([d.pop("linear_w_sparse").reshape(-1),
+                                       d.pop("linear_w_dense").reshape(-1)]).view(-1, 1)
+        return d
 
     def _alloc(self, B):
         if self._B == B:
@@ -327,20 +364,30 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def _embed(self, idx, dense, want_fm, masks, lin_w=None):
+        """lin_w: optional (sparse [R], dense [Dn]) override of the linear weights (predict
+        with manual feature weights); then the linear term is gathered from that separate
+        array instead of the row."""
         m = masks or {}
         fm_masks = m.get("fm", (None, None))
-        lw = self.linear_w if lin_w is None else lin_w
-        ops.embed_fwd(
-            idx, self.table, self.field_off,
-            bias_table=self.bias_table if want_fm else None,
-            lin_w=lw if self.use_linear else None, lin_off=self.lin_off,
-            lin_w_dense=lw[self.spec.rows:] if (self.use_linear and self.Dn) else None,
-            lin_w0=self.params["linear_w0"] if self.use_linear else None,
+        D = self.D
+        common = dict(
             dense=dense if (self.use_linear and self.Dn) else None,
+            lin_w0=self.params["linear_w0"] if self.use_linear else None,
             mask_b=fm_masks[0] if want_fm else None, mask_e=fm_masks[1] if want_fm else None,
             E=self.E, fm_sum=self.fm_sum if want_fm else None,
             fm_logit=self.fm_logit if want_fm else None,
             lin_logit=self.lin_logit if self.use_linear else None)
+        if lin_w is None:
+            ops.embed_fwd(idx, self.rows, self.field_off, D=D, table_ld=self.LD,
+                          bias_col=D if (want_fm and self.use_bias_tables) else None,
+                          lin_col=D + 1 if self.use_linear else None,
+                          lin_w_dense=self.linear_w_dense if (self.use_linear and self.Dn) else None,
+                          **common)
+        else:
+            ops.embed_fwd(idx, self.rows, self.field_off, D=D, table_ld=self.LD,
+                          bias_col=D if (want_fm and self.use_bias_tables) else None,
+                          lin_w=lin_w[0] if self.use_linear else None, lin_off=self.lin_off,
+                          lin_w_dense=lin_w[1] if (self.use_linear and self.Dn) else None, **common)
 
     def forward(self, idx, dense=None, training=False, masks=None, manual_weights=None):
         """-> (logit [B], pred [B]).  training=False disables dropout and (as the
@@ -348,7 +395,10 @@ class Engine:
         self._alloc(idx.shape[0])
         lin_w = None
         if manual_weights is not None:
-            lin_w = self.linear_w + manual_weights.to(self.device, F32)
+            mw = manual_weights.to(self.device, F32).reshape(-1)
+            R = self.spec.rows
+            lin_w = ((self.params["linear_w_sparse"] + mw[:R]).contiguous(),
+                     self.linear_w_dense + mw[R:])
         branches = self._branches_fwd(idx, dense, training, masks, lin_w)
         ops.logit_loss(branches, task=self.task, logit=self.logit, pred=self.pred)
         return self.logit, self.pred
@@ -377,10 +427,11 @@ class Engine:
         total = loss
         reg = hp.get("embedding_l2_reg", 0.0)
         if reg:
-            total = total + reg * 0.5 * self.table.square().sum()
+            total = total + reg * 0.5 * self.rows[:, : self.D].square().sum()
         reg = hp.get("linear_l2_reg", 0.0)
         if reg and self.use_linear:
-            total = total + reg * 0.5 * self.linear_w.square().sum()
+            total = total + reg * 0.5 * (self.params["linear_w_sparse"].square().sum()
+                                         + self.linear_w_dense.square().sum())
         return self._add_l2_model(total)
 
     def _add_l2_model(self, total):
@@ -427,21 +478,23 @@ class Engine:
                 "hbm")
 
     # ----------------------------------------------- dense views of the sparse grads
-    def dense_grads(self, idx):
+    def dense_grads(self, idx, reference_names=False):
         """Densifies the sparse gradients of the last fwd_bwd (scatter-add with float
-        atomics) and adds the l2 terms: name -> tensor, the shapes of state_dict().
-        What TF's IndexedSlices + dense l2 gradient add up to (layers.py:188-193)."""
-        hp = self.hp
-        out = {k: v.clone() for k, v in self.grads.items() if k != "linear_w_dense"}
-        d_table = torch.zeros_like(self.table)
+        atomics) and adds the l2 terms: name -> tensor with the keys / shapes of self.params
+        (or of state_dict() with reference_names=True).  What TF's IndexedSlices + dense l2
+        gradient add up to (layers.py:188-193)."""
+        hp, D = self.hp, self.D
+        out = {k: v.clone() for k, v in self.grads.items()}
+        R = self.spec.rows
+        d_table = torch.zeros(R, D, dtype=F32, device=self.device)
         ops.scatter_add_rows(d_table, idx, self.field_off, rows=self.d_rows)
         reg = hp.get("embedding_l2_reg", 0.0)
         if reg:
-            d_table.add_(self.table, alpha=reg)
+            d_table.add_(self.rows[:, :D], alpha=reg)
         offs = self.spec.offsets()
         d_bias = None
         if self.use_bias_tables:
-            d_bias = torch.zeros_like(self.bias_table)
+            d_bias = torch.zeros(R, dtype=F32, device=self.device)
             if self._has_fm():
                 if getattr(self, "d_bias", None) is not None:
                     ops.scatter_add_rows(d_bias, idx, self.field_off, rows=self.d_bias, width=1,
@@ -452,19 +505,19 @@ class Engine:
             out[f"{name}_feat_embed"] = d_table[off: off + V]
             if d_bias is not None:
                 out[f"{name}_feat_bias"] = d_bias[off: off + V].view(V, 1)
-        d_lin = torch.zeros_like(self.linear_w)
+        d_lin = torch.zeros(R, dtype=F32, device=self.device)
         if self.use_linear:
             ops.scatter_add_rows(d_lin, idx, self.lin_off, g_row=self.dlogit)
-            if self.Dn:
-                d_lin[self.spec.rows:] = self.grads["linear_w_dense"]
             reg = hp.get("linear_l2_reg", 0.0)
             if reg:
-                d_lin.add_(self.linear_w, alpha=reg)
+                d_lin.add_(self.params["linear_w_sparse"], alpha=reg)
+                out["linear_w_dense"] = out["linear_w_dense"] + reg * self.linear_w_dense
         else:
             out["linear_w0"] = torch.zeros_like(self.grads["linear_w0"])
-        out["linear_w"] = d_lin.view(-1, 1)
+            out["linear_w_dense"] = torch.zeros_like(self.grads["linear_w_dense"])
+        out["linear_w_sparse"] = d_lin
         self._dense_grads_model(out)
-        return out
+        return self.to_reference_names(out) if reference_names else out
 
     def _dense_grads_model(self, out):
         pass

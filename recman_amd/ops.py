@@ -34,19 +34,26 @@ def _chk(t, name, dtype, shape=None, allow_none=False):
 
 def embed_fwd(idx, table, field_off, *, bias_table=None, bias_ld=1, lin_w=None, lin_ld=1,
               lin_off=None, lin_w_dense=None, lin_w0=None, dense=None, mask_b=None, mask_e=None,
-              E=None, fm_sum=None, fm_logit=None, lin_logit=None, table_ld=None, D=None):
+              E=None, fm_sum=None, fm_logit=None, lin_logit=None, table_ld=None, D=None,
+              bias_col=None, lin_col=None):
     """Gather + FM + linear forward (see rm_embed_fwd in include/recman_hip.h).
-    `table` is [R, table_ld]; D defaults to table.shape[1]."""
+    `table` is [R, table_ld]; D defaults to table.shape[1].  bias_col / lin_col: the FM
+    bias / sparse linear weight live in that column of the table row itself (fused rows)."""
     B, F = idx.shape
     ld = table.shape[1] if table_ld is None else table_ld
     D = table.shape[1] if D is None else D
     Dn = 0 if dense is None else dense.shape[1]
+    tp = _chk(table, "table", F32)
+    fo = _chk(field_off, "field_off", I64, (F,))
+    bp, bld = _chk(bias_table, "bias_table", F32, allow_none=True), bias_ld
+    if bias_col is not None:
+        bp, bld = tp + 4 * bias_col, ld
+    lp, lld = _chk(lin_w, "lin_w", F32, allow_none=True), lin_ld
+    lo = _chk(lin_off, "lin_off", I64, (F,), allow_none=True)
+    if lin_col is not None:
+        lp, lld, lo = tp + 4 * lin_col, ld, fo
     _lib.call(
-        "rm_embed_fwd", _chk(idx, "idx", I64), _chk(table, "table", F32), ld,
-        _chk(field_off, "field_off", I64, (F,)),
-        _chk(bias_table, "bias_table", F32, allow_none=True), bias_ld,
-        _chk(lin_w, "lin_w", F32, allow_none=True), lin_ld,
-        _chk(lin_off, "lin_off", I64, (F,), allow_none=True),
+        "rm_embed_fwd", _chk(idx, "idx", I64), tp, ld, fo, bp, bld, lp, lld, lo,
         _chk(lin_w_dense, "lin_w_dense", F32, (Dn,), allow_none=True),
         _chk(lin_w0, "lin_w0", F32, (1,), allow_none=True),
         _chk(dense, "dense", F32, (B, Dn), allow_none=True), Dn,
@@ -262,7 +269,8 @@ def mlp_fwd(xe, xd, Ws, bs, w_out, w0_out, act, h_out, logit):
               _ptr_array(h_out), _chk(logit, "logit", F32, (B,)), _stream())
 
 
-def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None):
+def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None, db=None,
+            d_w_out=None, d_w0_out=None):
     B, FD = xe.shape
     Dn = 0 if xd is None else xd.shape[1]
     H = [W.shape[1] for W in Ws]
@@ -278,4 +286,7 @@ def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None
               Dn, len(Ws), _int_array(H), _ptr_array(Ws), _chk(w_out, "w_out", F32, (H[-1],)),
               ACT_IDS[act], B, _chk(g, "g", F32, (B,)), _ptr_array(h),
               _chk(fm_sum, "fm_sum", F32, allow_none=True), D, _chk(d_rows, "d_rows", F32, (B, FD)),
-              _ptr_array(dh), _ptr_array(dW), _chk(workspace, "workspace", F32), _stream())
+              _ptr_array(dh), _ptr_array(dW), None if db is None else _ptr_array(db),
+              _chk(d_w_out, "d_w_out", F32, (H[-1],), allow_none=True),
+              _chk(d_w0_out, "d_w0_out", F32, (1,), allow_none=True),
+              _chk(workspace, "workspace", F32), _stream())

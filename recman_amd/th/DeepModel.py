@@ -67,7 +67,7 @@ class DeepModel(BaseEstimator, TransformerMixin):
     @property
     def variables(self):
         """name -> tensor with the reference's variable names (DeepModel.py:43)."""
-        return self._build().params
+        return self._build().state_dict()
 
     def _encode(self, X, y=None):
         inp = DataInputs().load(self.feat_dict, X, y)

@@ -82,13 +82,18 @@ def test_fused_mlp_fwd_bwd(hip_lib, B, FD, Dn, hidden, act, fm):
     dh = [torch.empty(B, 32, device="cuda") for _ in hidden]
     dW = [torch.empty_like(c(W)) for W in Ws]
     ws = torch.empty(ops.mlp_bwd_workspace(FD, Dn), device="cuda")
+    db = [torch.empty(hh, device="cuda") for hh in hidden]
+    dwo, dw0 = torch.empty(hidden[-1], device="cuda"), torch.empty(1, device="cuda")
     ops.mlp_bwd(c(xe), c(xd) if Dn else None, [c(W) for W in Ws], c(w_out), act, c(g), h_out, d_rows,
-                dh, dW, ws, fm_sum=c(S) if fm else None)
+                dh, dW, ws, fm_sum=c(S) if fm else None, db=db, d_w_out=dwo, d_w0_out=dw0)
     torch.cuda.synchronize()
     close(d_rows, xe.grad, "d_rows")
     for l in range(len(hidden)):
         close(dW[l], Ws[l].grad, f"dW{l}")
         close(dh[l][:, : hidden[l]].sum(0), bs[l].grad, f"db{l} (colsum dh)")
+        close(db[l], bs[l].grad, f"db{l}")
+    close(dwo, w_out.grad, "d w_out")
+    close(dw0, g.sum().reshape(1), "d w0")
 
 
 def test_mlp_unsupported_shapes_reported(hip_lib):

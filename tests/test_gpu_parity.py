@@ -27,7 +27,7 @@ def _engine(model, spec, D, hp, p):
 
     espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names)
     e = eng.ENGINES[model](espec, D, hp)
-    e.load_params({k: v for k, v in p.items() if k in e.params})
+    e.load_params({k: v for k, v in p.items() if k in e.params or k == "linear_w"})
     return e
 
 
@@ -41,7 +41,7 @@ def _check_model(model, hip_lib, D=8, B=37, **kw):
     _close(e.logit, logit_o, rtol=0, atol=1e-5, what="logit")
     _close(e.pred, pred_o, rtol=0, atol=1e-6, what="pred")
     _close(loss, loss_o.reshape(1), what="loss")
-    grads = e.dense_grads(idx_d)
+    grads = e.dense_grads(idx_d, reference_names=True)
     for k in grads_o:
         if k in grads:
             _close(grads[k], grads_o[k], what=f"grad {k}")
@@ -120,7 +120,7 @@ def test_mlp_dropout_masks_injected(hip_lib):
     e = _engine("deepfm", spec, 8, hp, p)
     loss = e.fwd_bwd(idx.cuda(), dense.cuda(), y.cuda(), masks={"dnn": [m.cuda() for m in masks]})
     _close(e.logit, logit_o, rtol=0, atol=1e-5, what="logit")
-    grads = e.dense_grads(idx.cuda())
+    grads = e.dense_grads(idx.cuda(), reference_names=True)
     for k in grads_o:
         _close(grads[k], grads_o[k], what=f"grad {k}")
 
@@ -139,7 +139,7 @@ def test_regression_task(hip_lib):
     e.load_params(p)
     loss = e.fwd_bwd(idx.cuda(), dense.cuda(), yf.cuda())
     _close(loss, loss_o.detach().reshape(1), what="mse loss")
-    grads = e.dense_grads(idx.cuda())
+    grads = e.dense_grads(idx.cuda(), reference_names=True)
     for k, v in leaves.items():
         _close(grads[k], v.grad, what=f"grad {k}")
 
@@ -194,15 +194,15 @@ def test_row_sharded_engine_world1_equals_plain_engine(hip_lib, model, kw):
     e = _engine(model, spec, 16, hp, p)
     idx_d, dense_d, y_d = idx.cuda(), dense.cuda(), y.cuda()
     loss = e.fwd_bwd(idx_d, dense_d, y_d).clone()
-    gd = e.dense_grads(idx_d)
+    gd = e.dense_grads(idx_d, reference_names=True)
     espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names)
     s = rd.make_sharded_engine(model, espec, 16, hp, torch.device("cuda"), 0, 1)
-    s.load_params({k: v for k, v in p.items() if k in s.params})
+    s.load_params({k: v for k, v in p.items() if k in s.params})  # dense parameters only
     full = torch.cat([p[f"{n}_feat_embed"] for n in spec.sparse_names])
     bias = torch.cat([p[f"{n}_feat_bias"].reshape(-1) for n in spec.sparse_names]) if model == "deepfm" else None
     R = full.shape[0]
     s.st.load_global(full, bias=bias, lin=p["linear_w"].reshape(-1)[:R])
-    s.linear_w.copy_(p["linear_w"].reshape(-1)[R:])
+    s.linear_w_dense.copy_(p["linear_w"].reshape(-1)[R:])
     loss_s = s.fwd_bwd(idx_d, dense_d, y_d)
     _close(s.logit, e.logit, rtol=0, atol=1e-6, what="logit")
     _close(loss_s, loss, what="loss")
@@ -214,6 +214,7 @@ def test_row_sharded_engine_world1_equals_plain_engine(hip_lib, model, kw):
     _close(dt[:, D + 1], gd["linear_w"].reshape(-1)[:R], what="linear grad")
     if model == "deepfm":
         _close(dt[:, D], torch.cat([gd[f"{n}_feat_bias"].reshape(-1) for n in spec.sparse_names]), what="bias grad")
+    gi = e.dense_grads(idx_d)
     for k in s.grads:
-        if k in gd:
-            _close(s.grads[k], gd[k], what=f"grad {k}")
+        if k in gi:
+            _close(s.grads[k], gi[k], what=f"grad {k}")
