@@ -240,6 +240,23 @@ int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int x
 /* ------------------------------------------------------------------------
  * Row helpers (owner-side gather and re-ordering for the row-sharded table).
  */
+/* Buckets the n = B*F occurrences (b,f) by the owner rank of their global row
+ * g = field_off[f] + idx[b,f] (owner g % world, local row g / world) - a deterministic
+ * counting sort:  pos[o] = position of occurrence o in the bucketed order,
+ * send_ids[pos[o]] = g / world, counts[w] = occurrences owned by rank w.
+ * workspace: rm_shard_route_workspace(world) int32 words.  world <= 16. */
+int64_t rm_shard_route_workspace(int world);
+int rm_shard_route(const int64_t *idx, const int64_t *field_off, int64_t B, int F, int world,
+                   int64_t *pos, int64_t *send_ids, int64_t *counts, int32_t *workspace,
+                   rm_stream_t stream);
+
+/* out[pos[o], :] = [d_rows[o, 0..D) | g_bias[b] | g_lin[b] | 0 ..] (width floats per row): the
+ * per-occurrence gradient rows of the fused table rows, written straight in bucketed order
+ * (the send buffer of the backward all_to_all).  g_bias / g_lin [B] may be NULL (0). */
+int rm_pack_grad_rows(const float *d_rows, const float *g_bias, const float *g_lin,
+                      const int64_t *pos, int64_t B, int F, int D, int width, float *out,
+                      rm_stream_t stream);
+
 /* rows_out[i,:] = table[rows[i],:] for i < n (owner-side gather of the requested
  * local rows; width floats per row, width % 4 == 0). */
 int rm_gather_rows(const float *table, const int64_t *rows, int64_t n, int width,

@@ -42,6 +42,8 @@ SIGNATURES = {
                          c_int, P, P],
     "rm_cin_layer_bwd": [P, P, I64, c_int, P, c_int, P, P, I64, P, P, c_int, I64, c_int, c_int, c_int,
                          c_int, P, c_int, P, I64, P, P, P, I64, P],
+    "rm_shard_route": [P, P, I64, c_int, c_int, P, P, P, P, P],
+    "rm_pack_grad_rows": [P, P, P, P, I64, c_int, c_int, c_int, P, P],
     "rm_gather_rows": [P, P, I64, c_int, P, P],
     "rm_permute_rows": [P, P, I64, c_int, c_int, P, P],
 }
@@ -52,6 +54,7 @@ SIGNATURES_I64 = {
     "rm_cin_filter_workspace": [c_int, c_int, c_int],
     "rm_cin_bwd_workspace": [I64, c_int, c_int, c_int, c_int],
     "rm_mlp_bwd_workspace": [c_int, c_int],
+    "rm_shard_route_workspace": [c_int],
 }
 
 

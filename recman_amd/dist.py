@@ -7,13 +7,14 @@ FUSED: [D embedding floats | FM bias | linear weight | pad] = D+4 floats, so one
 exchange carries everything a lookup needs.  The batch stays data-parallel.
 
 One step (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI):
-  fwd  route (bucket the B*F occurrences by owner)          - index arithmetic only
+  fwd  route (bucket the B*F occurrences by owner)          - rm_shard_route (counting sort)
        all_to_all of counts, then of local row ids          - 8 B per occurrence
        owner-side gather (rm_gather_rows)                   - HIP
        all_to_all of the rows back                          - (D+4)*4 B per occurrence
-       un-route into (b,f) order (rm_permute_rows)          - HIP
-       FM / linear / DNN / CIN / cross exactly as on one GPU, on the gathered rows
-  bwd  gradient rows [dE | g | g | 0] routed the same way, all_to_all to the owners:
+       FM / linear / DNN / CIN / cross exactly as on one GPU: the gather kernel reads
+       occurrence (b,f) at row pos[b,f] of the received buffer (no un-route copy)
+  bwd  gradient rows [dE | g | g | 0] written in bucketed order (rm_pack_grad_rows),
+       all_to_all to the owners:
        each owner ends with IndexedSlices (local row ids, rows) for ITS shard;
        dense parameters: one flat all_reduce.
 There is no collective in the dense compute; xGMI is a full mesh, so the all_to_all
@@ -21,7 +22,7 @@ uses all 7 links of a GPU at once.
 
 The routing/exchange logic below is device- and backend-agnostic torch code (it is the
 same on gloo/CPU, where tests/test_dist.py runs it with world_size 2); the row gather and
-permutation are injected callables - HIP kernels in the product, plain indexing only in
+routing are injected callables - HIP kernels in the product, plain torch indexing only in
 the tests.
 """
 import torch
@@ -40,33 +41,36 @@ def shard_rows(R, rank, world):
     return (R - rank + world - 1) // world
 
 
-def route(global_rows, world):
-    """global_rows int64 [n] -> (order, counts, local_rows_sorted).
-    `order` sorts the occurrences by owner (stable); bucketed position i holds occurrence
-    order[i]; counts[w] = occurrences owned by rank w."""
-    owner = global_rows % world
+def route_torch(idx, field_off, world):
+    """Reference routing in plain torch (any device; what the CPU tests inject):
+    idx [B,F], field_off [F] -> (pos [n], counts [world], send_ids [n]) with
+    pos[o] = position of occurrence o in the owner-bucketed order (stable),
+    send_ids[pos[o]] = local row of occurrence o on its owner."""
+    g = (idx + field_off).reshape(-1)
+    owner = g % world
     order = torch.argsort(owner, stable=True)
     counts = torch.bincount(owner, minlength=world)
-    local = (global_rows // world)[order]
-    return order, counts, local
+    pos = torch.empty_like(order)
+    pos[order] = torch.arange(g.numel(), device=g.device)
+    return pos, counts, (g // world)[order]
 
 
 class RowExchange:
     """The all_to_all plumbing of one batch: built once per batch from its indices, used
     for the forward row fetch and the backward gradient push."""
 
-    def __init__(self, global_rows, world, group=None):
+    def __init__(self, idx, field_off, world, route_fn, group=None):
         self.world, self.group = world, group
-        self.n = global_rows.numel()
-        self.order, counts, self.send_ids = route(global_rows.reshape(-1), world)
+        self.n = idx.numel()
+        self.pos, counts, self.send_ids = route_fn(idx, field_off, world)
         self.coll = world > 1 or (FORCE and dist.is_initialized())
         if self.coll:
             recv_counts = torch.empty_like(counts)
             dist.all_to_all_single(recv_counts, counts, group=group)
             self.send_counts = counts.tolist()  # host sync: split sizes must be host-side
             self.recv_counts = recv_counts.tolist()
-            self.recv_ids = torch.empty(sum(self.recv_counts), dtype=global_rows.dtype,
-                                        device=global_rows.device)
+            self.recv_ids = torch.empty(sum(self.recv_counts), dtype=self.send_ids.dtype,
+                                        device=self.send_ids.device)
             dist.all_to_all_single(self.recv_ids, self.send_ids, self.recv_counts, self.send_counts,
                                    group=group)
         else:
@@ -75,7 +79,7 @@ class RowExchange:
 
     def fetch(self, owner_rows):
         """owner_rows [len(recv_ids), W]: the rows this rank serves, in recv_ids order ->
-        [n, W] rows for this rank's occurrences, in BUCKETED order (use `order` to un-route)."""
+        [n, W] rows for this rank's occurrences in BUCKETED order: occurrence o is row pos[o]."""
         if not self.coll:
             return owner_rows
         out = torch.empty(self.n, owner_rows.shape[1], dtype=owner_rows.dtype, device=owner_rows.device)
@@ -96,11 +100,11 @@ class RowExchange:
 class ShardedTable:
     """This rank's shard [R_local, D+4] of the fused table + the lookup / gradient routing."""
 
-    def __init__(self, R, D, rank, world, device, gather_fn, permute_fn, group=None):
+    def __init__(self, R, D, rank, world, device, gather_fn, route_fn, group=None):
         self.R, self.D, self.W = R, D, D + PAD
         self.rank, self.world, self.group = rank, world, group
         self.shard = torch.zeros(shard_rows(R, rank, world), self.W, dtype=torch.float32, device=device)
-        self.gather_fn, self.permute_fn = gather_fn, permute_fn
+        self.gather_fn, self.route_fn = gather_fn, route_fn
 
     def load_global(self, table, bias=None, lin=None):
         """Fills the shard from full-size arrays (tests / small tables): row r -> rank r % W."""
@@ -111,24 +115,18 @@ class ShardedTable:
         if lin is not None:
             self.shard[:, self.D + 1] = lin[sl].to(self.shard.device)
 
-    def lookup(self, global_rows):
-        """global_rows int64 [n] (occurrence order) -> (rows [n, D+4] in occurrence order,
-        the RowExchange to reuse in the backward)."""
-        ex = RowExchange(global_rows, self.world, self.group)
+    def lookup(self, idx, field_off):
+        """idx [B,F] -> (rows [n, D+4] in BUCKETED order, the RowExchange): the row of
+        occurrence o = b*F+f is rows[ex.pos[o]] - consumers gather through pos, no un-route copy."""
+        ex = RowExchange(idx, field_off, self.world, self.route_fn, self.group)
         served = torch.empty(len(ex.recv_ids), self.W, dtype=torch.float32, device=self.shard.device)
         self.gather_fn(self.shard, ex.recv_ids, served)
-        bucketed = ex.fetch(served)
-        rows = torch.empty(ex.n, self.W, dtype=torch.float32, device=self.shard.device)
-        # rows[order[i]] = bucketed[i]
-        self.permute_fn(bucketed, ex.order, rows, True)
-        return rows, ex
+        return ex.fetch(served), ex
 
-    def push_grads(self, ex, grad_rows):
-        """grad_rows [n, D+4] in occurrence order -> (local row ids, gradient rows) for this
-        shard: IndexedSlices, duplicates not merged."""
-        bucketed = torch.empty_like(grad_rows)
-        self.permute_fn(grad_rows, ex.order, bucketed, False)  # bucketed[i] = grad_rows[order[i]]
-        return ex.recv_ids, ex.push(bucketed)
+    def push_grads(self, ex, bucketed_grads):
+        """bucketed_grads [n, D+4] (row pos[o] = gradient of occurrence o) -> (local row ids,
+        gradient rows) for this shard: IndexedSlices, duplicates not merged."""
+        return ex.recv_ids, ex.push(bucketed_grads)
 
 
 def allreduce_dense(grads, world, group=None):
@@ -152,10 +150,26 @@ def hip_gather(table, rows, out):
     ops.gather_rows(table, rows, out)
 
 
-def hip_permute(src, slot, dst, inverse):
-    from . import ops
+class HipRouter:
+    """rm_shard_route with its buffers (counting sort by owner on the GPU)."""
 
-    ops.permute_rows(src, slot, dst, inverse=inverse)
+    def __init__(self, device):
+        self.device = device
+        self._n = None
+
+    def __call__(self, idx, field_off, world):
+        from . import ops
+
+        n = idx.numel()
+        if self._n != (n, world):
+            self._n = (n, world)
+            self.pos = torch.empty(n, dtype=torch.int64, device=self.device)
+            self.ids = torch.empty(n, dtype=torch.int64, device=self.device)
+            self.counts = torch.empty(world, dtype=torch.int64, device=self.device)
+            self.ws = torch.empty(ops._lib.lib().rm_shard_route_workspace(world), dtype=torch.int32,
+                                  device=self.device)
+        ops.shard_route(idx, field_off, world, self.pos, self.ids, self.counts, self.ws)
+        return self.pos, self.counts, self.ids
 
 
 def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
@@ -174,7 +188,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
         def _alloc_tables(self):
             dev = self.device
             R = self.spec.rows
-            self.st = ShardedTable(R, self.D, rank, world, dev, hip_gather, hip_permute, group)
+            self.st = ShardedTable(R, self.D, rank, world, dev, hip_gather, HipRouter(dev), group)
             self.table = self.st.shard  # [R_local, D+4] fused rows
             self.linear_w_dense = torch.zeros(self.Dn, dtype=torch.float32, device=dev)
             self.field_off = torch.tensor(self.spec.offsets(), dtype=torch.int64, device=dev)
@@ -186,24 +200,24 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
             first = self._B != B
             super()._alloc(B)
             if first:
-                F = self.F
-                self._iota = (torch.arange(B, device=self.device, dtype=torch.int64) * F).view(B, 1).expand(B, F).contiguous()
-                self._foff = torch.arange(F, device=self.device, dtype=torch.int64)
-                self.grad_rows = torch.zeros(B * F, self.D + PAD, dtype=torch.float32, device=self.device)
+                self._zoff = torch.zeros(self.F, dtype=torch.int64, device=self.device)
+                self.grad_rows = torch.empty(B * self.F, self.D + PAD, dtype=torch.float32,
+                                             device=self.device)
 
         def _embed(self, idx, dense, want_fm, masks, lin_w=None):
             from . import ops
 
             m = masks or {}
             fm_masks = m.get("fm", (None, None))
-            g_rows = (idx + self.field_off).reshape(-1)
-            self.rows, self.ex = self.st.lookup(g_rows)
+            B = idx.shape[0]
+            # rows arrive owner-bucketed; the gather kernel reads occurrence (b,f) at row pos[b,f]
+            self.rows, self.ex = self.st.lookup(idx, self.field_off)
             W = self.D + PAD
             flat = self.rows.view(-1)
             ops.embed_fwd(
-                self._iota, self.rows, self._foff, table_ld=W, D=self.D,
+                self.ex.pos.view(B, self.F), self.rows, self._zoff, table_ld=W, D=self.D,
                 bias_table=flat[self.D:] if want_fm else None, bias_ld=W,
-                lin_w=flat[self.D + 1:] if self.use_linear else None, lin_ld=W, lin_off=self._foff,
+                lin_w=flat[self.D + 1:] if self.use_linear else None, lin_ld=W, lin_off=self._zoff,
                 lin_w_dense=self.linear_w_dense if (self.use_linear and self.Dn) else None,
                 lin_w0=self.params["linear_w0"] if self.use_linear else None,
                 dense=dense if (self.use_linear and self.Dn) else None,
@@ -213,17 +227,13 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
                 lin_logit=self.lin_logit if self.use_linear else None)
 
         def fwd_bwd(self, idx, dense, y, masks=None):
+            from . import ops
+
             loss = super().fwd_bwd(idx, dense, y, masks)
-            # gradient rows [dE | g_fm | g_lin | 0 0] -> owners
-            B = idx.shape[0]
-            gr = self.grad_rows
-            gr[:, : self.D] = self.d_rows.view(-1, self.D)
-            g_occ = self.dlogit.view(B, 1).expand(B, self.F).reshape(-1)
-            if self._has_fm():
-                gr[:, self.D] = g_occ
-            if self.use_linear:
-                gr[:, self.D + 1] = g_occ
-            self.shard_grad_ids, self.shard_grad_rows = self.st.push_grads(self.ex, gr)
+            # gradient rows [dE | g_fm | g_lin | 0 0], written straight in bucketed order -> owners
+            ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
+                               self.dlogit if self.use_linear else None, self.ex.pos, self.grad_rows)
+            self.shard_grad_ids, self.shard_grad_rows = self.st.push_grads(self.ex, self.grad_rows)
             allreduce_dense(self.grads, world, group)
             return loss
 

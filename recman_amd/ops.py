@@ -290,3 +290,25 @@ def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None
               _chk(d_w_out, "d_w_out", F32, (H[-1],), allow_none=True),
               _chk(d_w0_out, "d_w0_out", F32, (1,), allow_none=True),
               _chk(workspace, "workspace", F32), _stream())
+
+
+def shard_route(idx, field_off, world, pos, send_ids, counts, workspace):
+    B, F = idx.shape
+    n = B * F
+    need = int(_lib.lib().rm_shard_route_workspace(world))
+    if workspace.dtype != torch.int32 or workspace.numel() < need:
+        raise ValueError(f"shard_route: workspace must be int32 with >= {need} elements")
+    _lib.call("rm_shard_route", _chk(idx, "idx", I64), _chk(field_off, "field_off", I64, (F,)), B, F,
+              world, _chk(pos, "pos", I64, (n,)), _chk(send_ids, "send_ids", I64, (n,)),
+              _chk(counts, "counts", I64, (world,)), workspace.data_ptr(), _stream())
+
+
+def pack_grad_rows(d_rows, g_bias, g_lin, pos, out):
+    B, F, D = d_rows.shape
+    n, width = out.shape
+    if n != B * F:
+        raise ValueError("pack_grad_rows: out must have B*F rows")
+    _lib.call("rm_pack_grad_rows", _chk(d_rows, "d_rows", F32),
+              _chk(g_bias, "g_bias", F32, (B,), allow_none=True),
+              _chk(g_lin, "g_lin", F32, (B,), allow_none=True), _chk(pos, "pos", I64, (n,)), B, F, D,
+              width, _chk(out, "out", F32), _stream())

@@ -14,11 +14,7 @@ def cpu_gather(table, rows, out):
     out.copy_(table[rows])
 
 
-def cpu_permute(src, slot, dst, inverse):
-    if inverse:
-        dst[slot] = src
-    else:
-        dst.copy_(src[slot])
+ZOFF = torch.zeros(1, dtype=torch.int64)
 
 
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
@@ -30,32 +26,32 @@ def test_fake_rank_routing_is_a_bit_exact_permutation(world):
     assert [s.shape[0] for s in shards] == [rd.shard_rows(R, r, world) for r in range(world)]
     rows = torch.randint(0, R, (777,), generator=g)
     rows[:50] = rows[0]  # heavy duplicates
-    order, counts, local = rd.route(rows, world)
-    assert int(counts.sum()) == 777 and torch.equal(torch.sort(order).values, torch.arange(777))
-    # owner-side gather per bucket, then un-route
+    pos, counts, local = rd.route_torch(rows.view(-1, 1), ZOFF, world)
+    assert int(counts.sum()) == 777 and torch.equal(torch.sort(pos).values, torch.arange(777))
+    # owner-side gather per bucket; occurrence o then reads row pos[o]
     pieces, off = [], 0
     for w in range(world):
         ids = local[off: off + int(counts[w])]
-        assert bool(((rows[order][off: off + int(counts[w])] % world) == w).all())
+        members = torch.nonzero((pos >= off) & (pos < off + int(counts[w]))).reshape(-1)
+        assert bool(((rows[members] % world) == w).all())
         pieces.append(shards[w][ids])
         off += int(counts[w])
     bucketed = torch.cat(pieces)
-    out = torch.empty(777, D)
-    out[order] = bucketed
-    assert torch.equal(out, table[rows])
+    assert torch.equal(bucketed[pos], table[rows])
 
 
 def test_world_one_table_roundtrip():
     g = torch.Generator().manual_seed(0)
     R, D = 50, 4
     full = torch.randn(R, D, generator=g)
-    st = rd.ShardedTable(R, D, 0, 1, "cpu", cpu_gather, cpu_permute)
+    st = rd.ShardedTable(R, D, 0, 1, "cpu", cpu_gather, rd.route_torch)
     st.load_global(full, bias=torch.arange(R).float(), lin=-torch.arange(R).float())
     rows = torch.randint(0, R, (33,), generator=g)
-    got, ex = st.lookup(rows)
+    buck, ex = st.lookup(rows.view(-1, 1), ZOFF)
+    got = buck[ex.pos]
     assert torch.equal(got[:, :D], full[rows])
     assert torch.equal(got[:, D], rows.float()) and torch.equal(got[:, D + 1], -rows.float())
-    ids, grows = st.push_grads(ex, got)
+    ids, grows = st.push_grads(ex, buck)
     dense = torch.zeros(R, D + rd.PAD).index_add_(0, ids, grows)
     want = torch.zeros(R, D + rd.PAD).index_add_(0, rows, got)
     assert torch.allclose(dense, want)
@@ -68,17 +64,20 @@ def _worker(rank, world, port, R, D, n):
     try:
         full = torch.randn(R, D, generator=torch.Generator().manual_seed(123))
         bias = torch.arange(R).float()
-        st = rd.ShardedTable(R, D, rank, world, "cpu", cpu_gather, cpu_permute)
+        st = rd.ShardedTable(R, D, rank, world, "cpu", cpu_gather, rd.route_torch)
         st.load_global(full, bias=bias)
         all_rows = [torch.randint(0, R, (n + 7 * r,), generator=torch.Generator().manual_seed(10 + r))
                     for r in range(world)]
         rows = all_rows[rank]
-        got, ex = st.lookup(rows)
+        buck, ex = st.lookup(rows.view(-1, 1), ZOFF)
+        got = buck[ex.pos]
         assert torch.equal(got[:, :D], full[rows]), "lookup mismatch"
         assert torch.equal(got[:, D], bias[rows])
         # gradient push: every rank sends grad = f(its rows); the owner must receive the sum
         grads = [torch.cat([full[rw] * (r + 1), torch.ones(len(rw), rd.PAD)], 1) for r, rw in enumerate(all_rows)]
-        ids, grows = st.push_grads(ex, grads[rank])
+        bucketed = torch.empty_like(grads[rank])
+        bucketed[ex.pos] = grads[rank]
+        ids, grows = st.push_grads(ex, bucketed)
         mine = torch.zeros(st.shard.shape[0], D + rd.PAD, dtype=torch.float64).index_add_(0, ids, grows.double())
         want = torch.zeros(R, D + rd.PAD, dtype=torch.float64)
         for rw, gr in zip(all_rows, grads):

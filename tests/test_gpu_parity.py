@@ -218,3 +218,28 @@ def test_row_sharded_engine_world1_equals_plain_engine(hip_lib, model, kw):
     for k in s.grads:
         if k in gi:
             _close(s.grads[k], gi[k], what=f"grad {k}")
+
+
+@pytest.mark.parametrize("world", [1, 2, 8, 16])
+def test_shard_route_kernel_matches_torch_routing(hip_lib, world):
+    """rm_shard_route (counting sort) against the plain-torch routing: same bucket contents,
+    a bijection onto the bucketed order, consistent local ids and counts."""
+    from recman_amd import dist as rd
+
+    g = torch.Generator().manual_seed(world)
+    for B, F in ((1, 1), (37, 5), (4099, 26)):
+        sizes = torch.randint(3, 1000, (F,), generator=g)
+        foff = torch.cat([torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)[:-1]])
+        idx = torch.stack([torch.randint(0, int(v), (B,), generator=g) for v in sizes], 1)
+        pos_t, counts_t, ids_t = rd.route_torch(idx, foff, world)
+        r = rd.HipRouter(torch.device("cuda"))
+        pos, counts, ids = r(idx.cuda(), foff.cuda(), world)
+        torch.cuda.synchronize()
+        assert torch.equal(counts.cpu(), counts_t)
+        n = B * F
+        assert torch.equal(torch.sort(pos.cpu()).values, torch.arange(n))
+        gl = (idx + foff).reshape(-1)
+        starts = torch.cat([torch.zeros(1, dtype=torch.int64), counts_t.cumsum(0)])
+        owner_of_pos = torch.bucketize(pos.cpu(), starts[1:], right=True)
+        assert torch.equal(owner_of_pos, gl % world)
+        assert torch.equal(ids.cpu()[pos.cpu()], gl // world)
