@@ -71,6 +71,31 @@ __device__ __forceinline__ void store_chunk(float *xs, const float4 (&v)[8], int
   }
 }
 
+// Stages W0 [K,H0] into LDS, zero-padded to [Kp][32] logical elements.  All of a thread's
+// global loads are issued before its first LDS write (a load->store loop serialises ~28 L2
+// round trips per thread: 20 us of prologue at the benchmark shape).
+// TRANSPOSED: dst[u*ld + k]; otherwise dst[k*ld + u].
+template <bool TRANSPOSED, int NTHREADS>
+__device__ __forceinline__ void stage_w0(float *dst, int ld, const float *__restrict__ W0, int K,
+                                         int Kp, int H0, int tid) {
+  constexpr int PER = 8;
+  for (int base = 0; base < Kp * 32; base += NTHREADS * PER) {
+    float v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int t = base + q * NTHREADS + tid;
+      const int k = t >> 5, u = t & 31;
+      v[q] = (t < Kp * 32 && k < K && u < H0) ? W0[(int64_t)k * H0 + u] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int t = base + q * NTHREADS + tid;
+      const int k = t >> 5, u = t & 31;
+      if (t < Kp * 32) dst[TRANSPOSED ? u * ld + k : k * ld + u] = v[q];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // forward: all layers + output projection in one kernel
 // ---------------------------------------------------------------------------
@@ -90,10 +115,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(
   float *xs_all = bs + (NL + 1) * 32;        // [8 waves][32][kLDX]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
 
-  for (int t = tid; t < 32 * Kp; t += 512) {
-    const int u = t / Kp, k = t - u * Kp;
-    W0t[u * LDW + k] = (k < K && u < w.H[0]) ? w.W[0][(int64_t)k * w.H[0] + u] : 0.f;
-  }
+  stage_w0<true, 512>(W0t, LDW, w.W[0], K, Kp, w.H[0], tid);
 #pragma unroll
   for (int l = 1; l < NL; ++l)
     for (int t = tid; t < 1024; t += 512) {
@@ -119,19 +141,31 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float4 pf[8];
-    load_chunk(pf, xe, xd, FD, Dn, B, ex0, 0, lane);
-    for (int ch = 0; ch < nch; ++ch) {
-      store_chunk(xs, pf, lane);
-      if (ch + 1 < nch) load_chunk(pf, xe, xd, FD, Dn, B, ex0, (ch + 1) * 64, lane);
+    // two chunks in flight per wave (the 7-deep dependent load chain is what bounds this kernel)
+    float4 pfa[8], pfb[8];
+    load_chunk(pfa, xe, xd, FD, Dn, B, ex0, 0, lane);
+    if (nch > 1) load_chunk(pfb, xe, xd, FD, Dn, B, ex0, 64, lane);
+    for (int ch = 0; ch < nch; ch += 2) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float4 a4 = *reinterpret_cast<const float4 *>(W0t + c * LDW + ch * 64 + 8 * u + 4 * h);
-        const float4 b4 = *reinterpret_cast<const float4 *>(xs + c * kLDX + 8 * u + 4 * h);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      for (int half = 0; half < 2; ++half) {
+        const int cc = ch + half;
+        if (cc >= nch) break;
+        if (half == 0) {
+          store_chunk(xs, pfa, lane);
+          if (cc + 2 < nch) load_chunk(pfa, xe, xd, FD, Dn, B, ex0, (cc + 2) * 64, lane);
+        } else {
+          store_chunk(xs, pfb, lane);
+          if (cc + 2 < nch) load_chunk(pfb, xe, xd, FD, Dn, B, ex0, (cc + 2) * 64, lane);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float4 a4 = *reinterpret_cast<const float4 *>(W0t + c * LDW + cc * 64 + 8 * u + 4 * h);
+          const float4 b4 = *reinterpret_cast<const float4 *>(xs + c * kLDX + 8 * u + 4 * h);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
       }
     }
     const int64_t b = ex0 + c;
@@ -166,10 +200,51 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// backward: dh chain in registers, dX (+ FM term) -> d_rows, dW0 accumulated on the MFMA
+// backward: dh chain in registers, dX (+ FM term) -> d_rows, dW0 accumulated on the MFMA.
+// The 4 waves of a block share one 32-example tile and split its k-tiles (wave w owns
+// k-tiles w, w+4, ...): each wave loads only its own 32 x 32 slices of x (private LDS,
+// no block barrier in the loop), keeps 4 dW0 accumulators (64 registers instead of 224,
+// so 2 waves per SIMD and a deeper prefetch fit) and owns disjoint rows of the block's
+// dW0 partial (no end-of-kernel reduction).  The cheap dh chain is recomputed per wave.
 // ---------------------------------------------------------------------------
+constexpr int kLDT = 36;  // k-tile slice row stride in LDS (32 + 4 pad)
+constexpr int kWT = 4;    // k-tiles per wave: Kp <= 448 -> 14 tiles over 4 waves
+
+__device__ __forceinline__ void load_ktile(float4 (&v)[4], const float *__restrict__ xe,
+                                           const float *__restrict__ xd, int FD, int Dn, int64_t B,
+                                           int64_t ex0, int kb, int lane) {
+  const int c4 = lane & 7;
+  const int k = kb + 4 * c4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (lane >> 3) + 8 * q;
+    int64_t b = ex0 + row;
+    b = b < B ? b : B - 1;
+    if (k + 3 < FD) {
+      v[q] = *reinterpret_cast<const float4 *>(xe + b * FD + k);
+    } else {
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = k + e;
+        t[e] = (kk >= FD && kk < FD + Dn) ? xd[b * Dn + (kk - FD)] : 0.f;
+      }
+      v[q] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+  }
+}
+
+__device__ __forceinline__ void store_ktile(float *xs, const float4 (&v)[4], int lane) {
+  const int c4 = lane & 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (lane >> 3) + 8 * q;
+    *reinterpret_cast<float4 *>(xs + row * kLDT + 4 * c4) = v[q];
+  }
+}
+
 template <int NL>
-__global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(
+__global__ __launch_bounds__(512) void mlp_bwd_kernel(
     const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn, MlpW w,
     const float *__restrict__ w_out, int act, int64_t B, const float *__restrict__ g,
     const float *__restrict__ h0, const float *__restrict__ h1, const float *__restrict__ h2,
@@ -178,21 +253,22 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = FD + Dn;
   const int Kp = ((K + 63) / 64) * 64;
+  const int nkt = Kp / 32;
   constexpr int LDR = 36;
   float *W0r = smem;                         // [Kp][36]: W0r[k][u] = W0[k][u]
   float *WB = W0r + Kp * LDR;                // [NL-1][16][2][32]: W_l[c][u(s,h)]
   float *wo = WB + (NL - 1) * 1024;          // [32] w_out
-  float *xs_all = wo + 32;                   // [4 waves][32][kLDX]
-  float *dT_all = xs_all + 4 * 32 * kLDX;    // [4 waves][32][33]: dh0 as [example][unit]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+  float *xs_all = wo + 32;                   // [8 waves][32][kLDT]
+  float *dT_all = xs_all + 8 * 32 * kLDT;    // [8 waves][32][33]: dh0 as [example][unit]
+  // 8 waves = two groups of 4; a group shares one 32-example tile, wave `wave` of the group
+  // owns k-tiles wave, wave+4, ...
+  const int tid = threadIdx.x, lane = tid & 63, wv8 = tid >> 6, wave = wv8 & 3, grp = wv8 >> 2;
+  const int h = lane >> 5, c = lane & 31;
 
-  for (int t = tid; t < Kp * 32; t += 256) {
-    const int k = t >> 5, u = t & 31;
-    W0r[k * LDR + u] = (k < K && u < w.H[0]) ? w.W[0][(int64_t)k * w.H[0] + u] : 0.f;
-  }
+  stage_w0<false, 512>(W0r, LDR, w.W[0], K, Kp, w.H[0], tid);
 #pragma unroll
   for (int l = 1; l < NL; ++l)
-    for (int t = tid; t < 1024; t += 256) {
+    for (int t = tid; t < 1024; t += 512) {
       const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
       const int ku = unit_of(s, hh);  // unit of layer l (the reduction index)
       WB[(l - 1) * 1024 + t] =
@@ -201,26 +277,24 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(
   if (tid < 32) wo[tid] = tid < w.H[NL - 1] ? w_out[tid] : 0.f;
   __syncthreads();
 
-  float *xs = xs_all + wave * 32 * kLDX;
-  float *dT = dT_all + wave * 32 * 33;
-  const int nch = Kp / 64;
-  const int nkt = Kp / 32;
-  f32x16 accw[14];  // dW0 partial: up to 14 k-tiles (Kp <= 448)
+  float *xs = xs_all + wv8 * 32 * kLDT;
+  float *dT = dT_all + wv8 * 32 * 33;
+  f32x16 accw[kWT];
 #pragma unroll
-  for (int t = 0; t < 14; ++t)
+  for (int t = 0; t < kWT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accw[t][r] = 0.f;
 
   const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  for (int64_t tile = (int64_t)blockIdx.x * 2 + grp; tile < ntiles; tile += (int64_t)gridDim.x * 2) {
     const int64_t ex0 = tile * 32;
     const int64_t b = ex0 + c;
     const bool valid = b < B;
     const int64_t bb = valid ? b : B - 1;
-    float4 pf[8];
-    load_chunk(pf, xe, xd, FD, Dn, B, ex0, 0, lane);
+    float4 pf[4];
+    if (wave < nkt) load_ktile(pf, xe, xd, FD, Dn, B, ex0, wave * 32, lane);
     const float gb = valid ? g[bb] : 0.f;
-    // ---- dh chain ----
+    // ---- dh chain (recomputed by every wave; wave 0 stores dh_l) ----
     float dh[16];
     {
       const float *hl = NL == 1 ? h0 : (NL == 2 ? h1 : h2);
@@ -236,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(
 #pragma unroll
     for (int l = NL - 1; l >= 1; --l) {
       float *dout = l == 1 ? dh1 : dh2;
-      if (valid) {
+      if (valid && wave == 0) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
           *reinterpret_cast<float4 *>(dout + b * 32 + 8 * gq + 4 * h) =
@@ -259,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(
         dh[4 * gq + 3] = acc[4 * gq + 3] * actg(hv.w, act);
       }
     }
-    if (valid) {
+    if (valid && wave == 0) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq)
         *reinterpret_cast<float4 *>(dh0 + b * 32 + 8 * gq + 4 * h) =
@@ -269,91 +343,84 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) dT[c * 33 + unit_of(r, h)] = valid ? dh[r] : 0.f;
 
-    // ---- sweep x: dX tiles (-> d_rows) and dW0 tiles ----
-    for (int ch = 0; ch < nch; ++ch) {
-      store_chunk(xs, pf, lane);
-      if (ch + 1 < nch) load_chunk(pf, xe, xd, FD, Dn, B, ex0, (ch + 1) * 64, lane);
+    // ---- this wave's k-tiles: dX tile (-> d_rows) and dW0 tile ----
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const int kb = ch * 64 + kt * 32;
-        if (kb < FD) {  // dX only for the embedding part of x
-          f32x16 acc;
+    for (int j = 0; j < kWT; ++j) {
+      const int kt = wave + 4 * j;
+      if (kt >= nkt) break;
+      const int kb = kt * 32;
+      float *xb = xs;  // single buffer: LDS ops of one wave execute in order
+      store_ktile(xb, pf, lane);
+      if (kt + 4 < nkt) load_ktile(pf, xe, xd, FD, Dn, B, ex0, (kt + 4) * 32, lane);
+      if (kb < FD) {  // dX only for the embedding part of x
+        f32x16 acc;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(W0r + (kb + c) * LDR + 8 * gq + 4 * h);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, dh[4 * gq + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, dh[4 * gq + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, dh[4 * gq + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, dh[4 * gq + 3], acc, 0, 0, 0);
-          }
-          // acc[r] = dX[example c][k = kb + u(r,h)]
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const int k = kb + 8 * gq + 4 * h;
-            if (k < FD && valid) {
-              float4 o = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
-              if (fm_sum != nullptr) {
-                const float4 e = *reinterpret_cast<const float4 *>(xs + c * kLDX + kt * 32 + 8 * gq + 4 * h);
-                const float4 s4 = *reinterpret_cast<const float4 *>(fm_sum + b * D + (k % D));
-                o.x += gb * (s4.x - e.x); o.y += gb * (s4.y - e.y);
-                o.z += gb * (s4.z - e.z); o.w += gb * (s4.w - e.w);
-              }
-              *reinterpret_cast<float4 *>(d_rows + b * FD + k) = o;
-            }
-          }
+        for (int gq = 0; gq < 4; ++gq) {
+          const float4 a4 = *reinterpret_cast<const float4 *>(W0r + (kb + c) * LDR + 8 * gq + 4 * h);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, dh[4 * gq + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, dh[4 * gq + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, dh[4 * gq + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, dh[4 * gq + 3], acc, 0, 0, 0);
         }
-        // dW0[kb + c'][unit] += sum_ex x[ex][kb + c'] * dh0[ex][unit]
-        // accw is indexed by a compile-time t (registers); the wave-uniform branch picks the tile
-        const int ktg = ch * 2 + kt;
+        // acc[r] = dX[example c][k = kb + u(r,h)]
 #pragma unroll
-        for (int t = 0; t < 14; ++t) {
-          if (t == ktg) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-              accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * s + h) * kLDX + kt * 32 + c],
-                                                            dT[(2 * s + h) * 33 + c], accw[t], 0, 0, 0);
+        for (int gq = 0; gq < 4; ++gq) {
+          const int k = kb + 8 * gq + 4 * h;
+          if (k < FD && valid) {
+            float4 o = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+            if (fm_sum != nullptr) {
+              const float4 e = *reinterpret_cast<const float4 *>(xb + c * kLDT + 8 * gq + 4 * h);
+              const float4 s4 = *reinterpret_cast<const float4 *>(fm_sum + b * D + (k % D));
+              o.x += gb * (s4.x - e.x); o.y += gb * (s4.y - e.y);
+              o.z += gb * (s4.z - e.z); o.w += gb * (s4.w - e.w);
+            }
+            *reinterpret_cast<float4 *>(d_rows + b * FD + k) = o;
           }
         }
       }
+      // dW0[kb + c'][unit] += sum_ex x[ex][kb + c'] * dh0[ex][unit]
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[(2 * s + h) * kLDT + c],
+                                                      dT[(2 * s + h) * 33 + c], accw[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the unrolled k-tiles from being interleaved
     }
   }
 
-  // ---- block reduction of the dW0 partials through LDS, then one slab per block ----
-  __syncthreads();
-  float *red = smem;  // [Kp][32] (reuses W0r: Kp*32 <= Kp*36)
-  for (int wv = 0; wv < 4; ++wv) {
-    if (wave == wv) {
+  // ---- the block's dW0 partial: every wave owns the rows of its k-tiles ----
 #pragma unroll
-      for (int t = 0; t < 14; ++t) {
-        if (t < nkt) {
+  for (int j = 0; j < kWT; ++j) {
+    const int kt = wave + 4 * j;
+    if (kt < nkt) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int idx = (t * 32 + unit_of(r, h)) * 32 + c;
-            red[idx] = (wv == 0 ? 0.f : red[idx]) + accw[t][r];
-          }
-        }
-      }
+      for (int r = 0; r < 16; ++r)
+        dW0_part[(((int64_t)blockIdx.x * 2 + grp) * Kp + kt * 32 + unit_of(r, h)) * 32 + c] = accw[j][r];
     }
-    __syncthreads();
   }
-  for (int t = tid; t < Kp * 32; t += 256) dW0_part[(int64_t)blockIdx.x * Kp * 32 + t] = red[t];
 }
 
-// dW0[k][u] = sum_blocks part[blk][k][u]   (k < K, u < H0): one wave per output,
-// fixed summation order -> deterministic
-__global__ __launch_bounds__(256) void mlp_dw0_reduce_kernel(const float *__restrict__ part, int nblk,
+// dW0[k][u] = sum_slabs part[slab][k][u]   (k < K, u < H0).  A block owns 64 consecutive
+// slab elements; its 4 waves take every 4th slab (coalesced 256-byte reads), partial sums
+// meet in LDS in a fixed order -> deterministic.
+__global__ __launch_bounds__(256) void mlp_dw0_reduce_kernel(const float *__restrict__ part, int nslab,
                                                              int K, int Kp, int H0,
                                                              float *__restrict__ dW0) {
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= K * H0) return;
-  const int k = t / H0, u = t - k * H0;
+  __shared__ float sm[4][64];
+  const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + o;  // element of the [Kp][32] slab
+  const int64_t slab = (int64_t)Kp * 32;
   float acc = 0.f;
-  for (int i = lane; i < nblk; i += 64) acc += part[((int64_t)i * Kp + k) * 32 + u];
-  acc = rm_wave_sum(acc);
-  if (lane == 0) dW0[t] = acc;
+#pragma unroll 8
+  for (int i = grp; i < nslab; i += 4) acc += part[(int64_t)i * slab + e];
+  sm[grp][o] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    const float v = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
+    const int k = e >> 5, u = e & 31;
+    if (k < K && u < H0) dW0[k * H0 + u] = v;
+  }
 }
 
 // Every remaining (tiny) gradient of the MLP in ONE pass over h_l / dh_l / g:
@@ -427,27 +494,30 @@ struct SgOut {
 };
 __global__ __launch_bounds__(256) void mlp_small_grads_stage2(const float *__restrict__ part, int nblk,
                                                               int NL, SgOut o) {
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nW = (NL - 1) * 1024, nv = 32 * NL + 33;
-  if (t >= nW + nv) return;
-  const int src = t < nW ? t : 2 * 1024 + (t - nW);
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int src = blockIdx.x * 64 + lane;  // element of the per-block partial
   float acc = 0.f;
-  for (int i = lane; i < nblk; i += 64) acc += part[(int64_t)i * kSgStride + src];
-  acc = rm_wave_sum(acc);
-  if (lane != 0) return;
-  if (t < nW) {
-    const int l = 1 + t / 1024, pq = t % 1024, p = pq >> 5, q = pq & 31;
-    if (p < o.H[l - 1] && q < o.H[l]) o.dW[l][p * o.H[l] + q] = acc;
+  if (src < kSgStride) {
+#pragma unroll 8
+    for (int i = grp; i < nblk; i += 4) acc += part[(int64_t)i * kSgStride + src];
+  }
+  sm[grp][lane] = acc;
+  __syncthreads();
+  if (grp != 0 || src >= kSgStride) return;
+  acc = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+  if (src < 2 * 1024) {
+    const int l = 1 + src / 1024, pq = src % 1024, p = pq >> 5, q = pq & 31;
+    if (l < NL && p < o.H[l - 1] && q < o.H[l]) o.dW[l][p * o.H[l] + q] = acc;
   } else {
-    const int v = t - nW;
+    const int v = src - 2 * 1024;
     if (v < 32 * NL) {
       const int l = v >> 5, q = v & 31;
       if (q < o.H[l] && o.db[l]) o.db[l][q] = acc;
     } else if (v < 32 * NL + 32) {
       const int q = v - 32 * NL;
       if (q < o.H[NL - 1] && o.dw_out) o.dw_out[q] = acc;
-    } else if (o.dw0) {
+    } else if (v == 32 * NL + 32 && o.dw0) {
       o.dw0[0] = acc;
     }
   }
@@ -459,7 +529,7 @@ size_t mlp_fwd_smem(int K, int NL) {
 }
 size_t mlp_bwd_smem(int K, int NL) {
   const int Kp = ((K + 63) / 64) * 64;
-  return (size_t)(Kp * 36 + (NL - 1) * 1024 + 32 + 4 * 32 * kLDX + 4 * 32 * 33) * sizeof(float);
+  return (size_t)(Kp * 36 + (NL - 1) * 1024 + 32 + 8 * 32 * kLDT + 8 * 32 * 33) * sizeof(float);
 }
 
 int mlp_check(const char *fn, int FD, int Dn, int NL, const int *H) {
@@ -515,7 +585,7 @@ extern "C" int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int 
 
 extern "C" int64_t rm_mlp_bwd_workspace(int FD, int Dn) {
   const int Kp = ((FD + Dn + 63) / 64) * 64;
-  return (int64_t)256 * Kp * 32 + 256 * kSgStride;
+  return (int64_t)512 * Kp * 32 + 512 * kSgStride;
 }
 
 extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
@@ -539,22 +609,22 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
   const int K = FD + Dn, Kp = ((K + 63) / 64) * 64;
   const size_t smem = mlp_bwd_smem(K, NL);
   const int64_t ntiles = (B + 31) / 32;
-  const int nblk = rm_grid_cap((ntiles + 3) / 4, 256);
+  const int nblk = rm_grid_cap((ntiles + 1) / 2, 256);  // one 8-wave block per CU, 2 tiles at a time
   hipStream_t st = (hipStream_t)stream;
   float *part = workspace;
-  float *part2 = workspace + (int64_t)256 * Kp * 32;
+  float *part2 = workspace + (int64_t)512 * Kp * 32;
 #define RM_MLP_BWD(NL_)                                                                          \
   {                                                                                              \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_kernel<NL_>),               \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
-    hipLaunchKernelGGL((mlp_bwd_kernel<NL_>), dim3(nblk), dim3(256), smem, st, xe, xd, FD, Dn, w, \
+    hipLaunchKernelGGL((mlp_bwd_kernel<NL_>), dim3(nblk), dim3(512), smem, st, xe, xd, FD, Dn, w, \
                        w_out, act, B, g, h[0], NL > 1 ? h[1] : nullptr, NL > 2 ? h[2] : nullptr, \
                        fm_sum, D, d_rows, dh[0], NL > 1 ? dh[1] : nullptr,                       \
                        NL > 2 ? dh[2] : nullptr, part);                                          \
   }
   if (NL == 1) RM_MLP_BWD(1) else if (NL == 2) RM_MLP_BWD(2) else RM_MLP_BWD(3)
 #undef RM_MLP_BWD
-  hipLaunchKernelGGL(mlp_dw0_reduce_kernel, dim3((K * H[0] + 3) / 4), dim3(256), 0, st, part, nblk, K,
+  hipLaunchKernelGGL(mlp_dw0_reduce_kernel, dim3(Kp * 32 / 64), dim3(256), 0, st, part, 2 * nblk, K,
                      Kp, H[0], dW[0]);
   {
     SgOut o;
@@ -567,7 +637,7 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     o.dw0 = d_w0_out;
     const float *h1p = NL > 1 ? h[1] : nullptr, *h2p = NL > 2 ? h[2] : nullptr;
     const float *d1p = NL > 1 ? dh[1] : nullptr, *d2p = NL > 2 ? dh[2] : nullptr;
-    const int sblk = 256;
+    const int sblk = 512;
     if (NL == 1)
       hipLaunchKernelGGL((mlp_small_grads_stage1<1>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
                          dh[0], d1p, d2p, g, B, part2);
@@ -577,8 +647,8 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     else
       hipLaunchKernelGGL((mlp_small_grads_stage1<3>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
                          dh[0], d1p, d2p, g, B, part2);
-    const int nout = (NL - 1) * 1024 + 32 * NL + 33;
-    hipLaunchKernelGGL(mlp_small_grads_stage2, dim3((nout + 3) / 4), dim3(256), 0, st, part2, sblk, NL, o);
+    hipLaunchKernelGGL(mlp_small_grads_stage2, dim3((kSgStride + 63) / 64), dim3(256), 0, st, part2, sblk,
+                       NL, o);
   }
   RM_CHECK_LAUNCH("rm_mlp_bwd");
   return RM_OK;
