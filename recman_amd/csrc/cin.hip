@@ -52,8 +52,11 @@ __global__ void cin_prep_fwd_kernel(const float *__restrict__ W, int m, int H, i
   }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, 1) void cin_fwd_kernel(
+// MT = 32-row M-tiles per wave; the block always covers 256 rows with 8/MT waves.
+// MT = 1 (8 waves, 2 per SIMD) lets one wave's s_waitcnt / barrier time be covered by its
+// SIMD partner: rocprofv3 showed 26 % of wave-cycles parked in waits at 1 wave per SIMD.
+template <int NT, int MT>
+__global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
     const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride,
     const float *__restrict__ Wp, const float *__restrict__ bias, int act, int64_t B, int m, int H,
     int N, int D, float *__restrict__ out, float *__restrict__ pooled, int pool_stride,
@@ -66,50 +69,54 @@ __global__ __launch_bounds__(256, 1) void cin_fwd_kernel(
   float *X0s = smem;                      // [(m+1)][256], row m is zero
   float *Xks = X0s + (m + 1) * kRows;     // [He][256], row H (if padded) is zero
   float *Ws = Xks + He * kRows;           // [2][32][Np]
+  constexpr int NTHR = 512 / MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
   const int epb = kRows / D;
   const int64_t b0 = (int64_t)blockIdx.x * epb;
   const int D4 = D / 4;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int t = tid; t < epb * m * D4; t += 256) {
+  for (int t = tid; t < epb * m * D4; t += NTHR) {
     const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
     const int64_t b = b0 + bl;
     const float4 v = b < B ? *reinterpret_cast<const float4 *>(X0 + (b * m + i) * D + 4 * d4) : z4;
     *reinterpret_cast<float4 *>(X0s + i * kRows + bl * D + 4 * d4) = v;
   }
-  X0s[m * kRows + tid] = 0.f;
-  for (int t = tid; t < epb * H * D4; t += 256) {
+  if (tid < kRows) X0s[m * kRows + tid] = 0.f;
+  for (int t = tid; t < epb * H * D4; t += NTHR) {
     const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
     const int64_t b = b0 + bl;
     const float4 v =
         b < B ? *reinterpret_cast<const float4 *>(Xk + b * xk_bstride + (int64_t)j * D + 4 * d4) : z4;
     *reinterpret_cast<float4 *>(Xks + j * kRows + bl * D + 4 * d4) = v;
   }
-  if (He > H) Xks[H * kRows + tid] = 0.f;
+  if (He > H && tid < kRows) Xks[H * kRows + tid] = 0.f;
+  constexpr int PF = (NT * 256 + NTHR - 1) / NTHR;  // float4 of a filter chunk per thread
 #pragma unroll
-  for (int q = 0; q < NT; ++q)
-    *reinterpret_cast<float4 *>(Ws + (tid + q * 256) * 4) =
-        *reinterpret_cast<const float4 *>(Wp + (tid + q * 256) * 4);
+  for (int q = 0; q < PF; ++q)
+    if (tid + q * NTHR < NT * 256)
+      *reinterpret_cast<float4 *>(Ws + (tid + q * NTHR) * 4) =
+          *reinterpret_cast<const float4 *>(Wp + (tid + q * NTHR) * 4);
   __syncthreads();
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const int prow = wave * 64 + c;  // + mt*32
+  const int prow = wave * 32 * MT + c;  // + mt*32
   const int nchunks = Kp / 32;
   int i_cur = 0, j_cur = 0;  // (i, even j) of the running k' pair: wave-uniform
   for (int ch = 0; ch < nchunks; ++ch) {
-    float4 pf[NT];
+    float4 pf[PF];
     if (ch + 1 < nchunks) {
 #pragma unroll
-      for (int q = 0; q < NT; ++q)
-        pf[q] = *reinterpret_cast<const float4 *>(Wp + (int64_t)(ch + 1) * WCH + (tid + q * 256) * 4);
+      for (int q = 0; q < PF; ++q)
+        if (tid + q * NTHR < NT * 256)
+          pf[q] = *reinterpret_cast<const float4 *>(Wp + (int64_t)(ch + 1) * WCH + (tid + q * NTHR) * 4);
     }
     const float *Wb = Ws + (ch & 1) * WCH;
 #pragma unroll
@@ -117,8 +124,9 @@ __global__ __launch_bounds__(256, 1) void cin_fwd_kernel(
       const int irow = i_cur < m ? i_cur : m;
       const float *x0p = X0s + irow * kRows + prow;
       const float *xkp = Xks + (j_cur + h) * kRows + prow;
-      const float a0 = x0p[0] * xkp[0];
-      const float a1 = x0p[32] * xkp[32];
+      float av[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[mt] = x0p[32 * mt] * xkp[32 * mt];
       float bv[NT];
       const float *wp = Wb + (2 * s + h) * Np + c * NT;
       if constexpr (NT == 4) {
@@ -131,17 +139,18 @@ __global__ __launch_bounds__(256, 1) void cin_fwd_kernel(
         bv[0] = wp[0];
       }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[nt], acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[nt], acc[1][nt], 0, 0, 0);
-      }
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
       j_cur += 2;
       if (j_cur >= He) { j_cur = 0; ++i_cur; }
     }
     if (ch + 1 < nchunks) {
       float *Wn = Ws + ((ch + 1) & 1) * WCH;
 #pragma unroll
-      for (int q = 0; q < NT; ++q) *reinterpret_cast<float4 *>(Wn + (tid + q * 256) * 4) = pf[q];
+      for (int q = 0; q < PF; ++q)
+        if (tid + q * NTHR < NT * 256) *reinterpret_cast<float4 *>(Wn + (tid + q * NTHR) * 4) = pf[q];
     }
     __syncthreads();
   }
@@ -150,18 +159,18 @@ __global__ __launch_bounds__(256, 1) void cin_fwd_kernel(
   float *pool_s = Ws;  // [epb][Np] (<= 32 KB, fits the two filter buffers when epb <= 64)
   const bool want_pool = pooled != nullptr;
   if (want_pool) {
-    for (int t = tid; t < epb * Np; t += 256) pool_s[t] = 0.f;
+    for (int t = tid; t < epb * Np; t += NTHR) pool_s[t] = 0.f;
     __syncthreads();
   }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = nt * 32 + c;
       const float bn = n < N ? bias[n] : 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int p = wave * 64 + mt * 32 + 8 * g + 4 * h;  // first of 4 consecutive rows
+        const int p = wave * 32 * MT + mt * 32 + 8 * g + 4 * h;  // first of 4 consecutive rows
         const int bl = p / D, d = p - bl * D;
         const int64_t b = b0 + bl;
         float4 v;
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd_kernel(
   if (want_pool) {
     __syncthreads();
     const int ncols = N - pool_from;
-    for (int t = tid; t < epb * ncols; t += 256) {
+    for (int t = tid; t < epb * ncols; t += NTHR) {
       const int bl = t / ncols, cidx = t - bl * ncols;
       const int64_t b = b0 + bl;
       if (b < B) pooled[b * pool_stride + pool_col0 + cidx] = pool_s[bl * Np + pool_from + cidx];
@@ -249,7 +258,8 @@ __global__ void cin_prep_bwd_kernel(const float *__restrict__ W, int m, int H, i
   }
 }
 
-constexpr int kRowsX = 128;  // rows per dX block (4 waves x 32)
+// rows per dX block: 256 (8 waves, 2 per SIMD: waits of one wave are covered by its SIMD
+// partner) when the LDS images fit, else 128 (4 waves)
 
 // dZ^T tile [32 k'][32 rows] = W[k'][:] . dM[row][:]^T on the MFMA (A = filter chunk from
 // LDS, B = the lane's own dM row kept in registers), contracted on the fly IN REGISTERS:
@@ -257,8 +267,8 @@ constexpr int kRowsX = 128;  // rows per dX block (4 waves x 32)
 //                                          are added with one cross-lane move)
 //   dXk[j][row] += dZ * X0[i][row]        (JB*16 registers per lane, j static per register)
 // No LDS atomics: an earlier version contracted with ds_add_f32 and ran 8x slower.
-template <int NT, int JB>
-__global__ __launch_bounds__(256, 1) void cin_dx_kernel(
+template <int NT, int JB, int ROWS>
+__global__ __launch_bounds__(ROWS * 2) void cin_dx_kernel(
     const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride, int xk_is_x0,
     const float *__restrict__ Wq, const float *__restrict__ dM, int64_t B, int m, int H, int D,
     float *__restrict__ dX0, int accumulate_dx0, float *__restrict__ dXk, int64_t dxk_bstride) {
@@ -266,7 +276,9 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
   constexpr int Np = 32 * NT;
   constexpr int LDW = Np + 4;
   constexpr int Hp = 32 * JB;
-  float *X0s = smem;                         // [m][128]
+  constexpr int kRowsX = ROWS;
+  constexpr int NTHR = ROWS * 2;
+  float *X0s = smem;                         // [m][ROWS]
   float *Xks = X0s + m * kRowsX;             // [Hp][128] (rows >= H zero)
   float *dX0s = Xks + Hp * kRowsX;           // [m][128]
   float *Wt = dX0s + m * kRowsX;             // [2][32][LDW]
@@ -276,13 +288,13 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
   const int D4 = D / 4;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int t = tid; t < epb * m * D4; t += 256) {
+  for (int t = tid; t < epb * m * D4; t += NTHR) {
     const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
     const int64_t b = b0 + bl;
     const float4 v = b < B ? *reinterpret_cast<const float4 *>(X0 + (b * m + i) * D + 4 * d4) : z4;
     *reinterpret_cast<float4 *>(X0s + i * kRowsX + bl * D + 4 * d4) = v;
   }
-  for (int t = tid; t < epb * Hp * D4; t += 256) {
+  for (int t = tid; t < epb * Hp * D4; t += NTHR) {
     const int d4 = t % D4, j = (t / D4) % Hp, bl = t / (D4 * Hp);
     const int64_t b = b0 + bl;
     const float4 v = (b < B && j < H)
@@ -299,12 +311,14 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
     dm[4 * u + 0] = v.x; dm[4 * u + 1] = v.y; dm[4 * u + 2] = v.z; dm[4 * u + 3] = v.w;
   }
   // filter chunk 0
-  constexpr int F4 = 32 * Np / 4 / 256;  // float4 per thread per chunk (= NT)
+  constexpr int CF4 = 32 * Np / 4;                 // float4 per filter chunk
+  constexpr int F4 = (CF4 + NTHR - 1) / NTHR;      // per thread
 #pragma unroll
   for (int q = 0; q < F4; ++q) {
-    const int f = tid + q * 256, row = f / (Np / 4), c4 = f - row * (Np / 4);
-    *reinterpret_cast<float4 *>(Wt + row * LDW + 4 * c4) =
-        *reinterpret_cast<const float4 *>(Wq + (int64_t)row * Np + 4 * c4);
+    const int f = tid + q * NTHR, row = f / (Np / 4), c4 = f - row * (Np / 4);
+    if (f < CF4)
+      *reinterpret_cast<float4 *>(Wt + row * LDW + 4 * c4) =
+          *reinterpret_cast<const float4 *>(Wq + (int64_t)row * Np + 4 * c4);
   }
   __syncthreads();
 
@@ -330,8 +344,9 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
       if (kt + 1 < ntiles) {
 #pragma unroll
         for (int q = 0; q < F4; ++q) {
-          const int f = tid + q * 256, row = f / (Np / 4), c4 = f - row * (Np / 4);
-          pf[q] = *reinterpret_cast<const float4 *>(Wq + ((int64_t)(kt + 1) * 32 + row) * Np + 4 * c4);
+          const int f = tid + q * NTHR, row = f / (Np / 4), c4 = f - row * (Np / 4);
+          if (f < CF4)
+            pf[q] = *reinterpret_cast<const float4 *>(Wq + ((int64_t)(kt + 1) * 32 + row) * Np + 4 * c4);
         }
       }
       const float *Wb = Wt + (kt & 1) * 32 * LDW;
@@ -356,8 +371,8 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
         float *Wn = Wt + ((kt + 1) & 1) * 32 * LDW;
 #pragma unroll
         for (int q = 0; q < F4; ++q) {
-          const int f = tid + q * 256, row = f / (Np / 4), c4 = f - row * (Np / 4);
-          *reinterpret_cast<float4 *>(Wn + row * LDW + 4 * c4) = pf[q];
+          const int f = tid + q * NTHR, row = f / (Np / 4), c4 = f - row * (Np / 4);
+          if (f < CF4) *reinterpret_cast<float4 *>(Wn + row * LDW + 4 * c4) = pf[q];
         }
       }
       __syncthreads();
@@ -373,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
       Xks[(jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * kRowsX + prow] = dxk[jb][r];
   __syncthreads();
 
-  for (int t = tid; t < epb * m * D4; t += 256) {
+  for (int t = tid; t < epb * m * D4; t += NTHR) {
     const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
     const int64_t b = b0 + bl;
     if (b >= B) continue;
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
     *dst = v;
   }
   if (!xk_is_x0 && dXk != nullptr) {
-    for (int t = tid; t < epb * H * D4; t += 256) {
+    for (int t = tid; t < epb * H * D4; t += NTHR) {
       const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
       const int64_t b = b0 + bl;
       if (b >= B) continue;
@@ -400,23 +415,25 @@ __global__ __launch_bounds__(256, 1) void cin_dx_kernel(
   }
 }
 
-size_t cin_dx_smem(int m, int H, int NT) {
+size_t cin_dx_smem(int m, int H, int NT, int rows) {
   const int Np = 32 * NT;
-  return (size_t)((2 * m + cin_Hp(H)) * kRowsX + 2 * 32 * (Np + 4)) * sizeof(float);
+  return (size_t)((2 * m + cin_Hp(H)) * rows + 2 * 32 * (Np + 4)) * sizeof(float);
 }
 
 // dW partial: part[s][k'][n] = sum over the split's rows p of Z[p][k'] * dM[p][n].
 // MFMA with the rows as the reduction dimension: A = Z^T (formed in registers from the
 // [row][field] LDS images), B = dM rows.  A wave owns 4 k'-tiles x NT n-tiles.
 constexpr int kRC = 64;   // rows per staged chunk
-constexpr int kKT = 4;    // k'-tiles per wave
+constexpr int kKT = 2;    // k'-tiles per wave
+constexpr int kDWW = 8;   // waves per dW block (2 per SIMD)
 template <int NT>
-__global__ __launch_bounds__(256, 1) void cin_dw_kernel(
+__global__ __launch_bounds__(512) void cin_dw_kernel(
     const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride,
     const float *__restrict__ dM, int64_t B, int m, int H, int D, int chunks_per_split,
     float *__restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int Np = 32 * NT;
+  constexpr int NTHR = 64 * kDWW;
   const int He = cin_He(H);
   const int Kp = cin_Kp(m, H);
   const int ld0 = (m + 1) | 1, ldk = He | 1;
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void cin_dw_kernel(
   int iq[kKT], jq[kKT];
 #pragma unroll
   for (int q = 0; q < kKT; ++q) {
-    const int kp = (group * 4 * kKT + wave * kKT + q) * 32 + c;
+    const int kp = (group * kDWW * kKT + wave * kKT + q) * 32 + c;
     const int i = kp / He, j = kp - i * He;
     const bool ok = kp < Kp && i < m && j < H;
     iq[q] = ok ? i : m;
@@ -446,49 +463,74 @@ __global__ __launch_bounds__(256, 1) void cin_dw_kernel(
       for (int r = 0; r < 16; ++r) acc[q][nt][r] = 0.f;
 
   const int D4 = D / 4;
-  const int n0f4 = kRC * m / 4;   // float4 of X0 per chunk (rows*m/4)
+  const int n0f4 = kRC * m / 4;   // float4 of X0 per chunk
   const int nkf4 = kRC * H / 4;
-  constexpr int DMF4 = kRC * Np / 4 / 256;  // float4 of dM per thread per chunk
+  constexpr int DMF4 = kRC * Np / 4 / NTHR;  // float4 of dM per thread per chunk
+  constexpr int XF4 = 2;                      // X0 / Xk float4 per thread per chunk (m, H <= 64)
+  float4 p0[XF4], pk[XF4], pd[DMF4];
+
+  auto prefetch = [&](int64_t r0) {
+#pragma unroll
+    for (int q = 0; q < XF4; ++q) {
+      const int t = tid + q * NTHR;
+      p0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pk[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < n0f4) {
+        const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+        const int64_t pgl = r0 + bl * D + 4 * d4;
+        if (pgl < rows_total) p0[q] = *reinterpret_cast<const float4 *>(X0 + ((pgl / D) * m + i) * D + 4 * d4);
+      }
+      if (t < nkf4) {
+        const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
+        const int64_t pgl = r0 + bl * D + 4 * d4;
+        if (pgl < rows_total)
+          pk[q] = *reinterpret_cast<const float4 *>(Xk + (pgl / D) * xk_bstride + (int64_t)j * D + 4 * d4);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < DMF4; ++q) {
+      const int f = tid + q * NTHR, pl = f / (Np / 4), c4 = f - pl * (Np / 4);
+      const int64_t pgl = r0 + pl;
+      pd[q] = pgl < rows_total ? *reinterpret_cast<const float4 *>(dM + pgl * Np + 4 * c4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < XF4; ++q) {
+      const int t = tid + q * NTHR;
+      if (t < n0f4) {
+        const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+        const int pl = bl * D + 4 * d4;
+        X0T[(pl + 0) * ld0 + i] = p0[q].x; X0T[(pl + 1) * ld0 + i] = p0[q].y;
+        X0T[(pl + 2) * ld0 + i] = p0[q].z; X0T[(pl + 3) * ld0 + i] = p0[q].w;
+      }
+      if (t < nkf4) {
+        const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
+        const int pl = bl * D + 4 * d4;
+        XkT[(pl + 0) * ldk + j] = pk[q].x; XkT[(pl + 1) * ldk + j] = pk[q].y;
+        XkT[(pl + 2) * ldk + j] = pk[q].z; XkT[(pl + 3) * ldk + j] = pk[q].w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < DMF4; ++q) {
+      const int f = tid + q * NTHR, pl = f / (Np / 4), c4 = f - pl * (Np / 4);
+      const int n = 4 * c4, nt = n >> 5, cc = n & 31;
+      float *dst = dMs + pl * Np + cc * NT + nt;
+      dst[0] = pd[q].x; dst[NT] = pd[q].y; dst[2 * NT] = pd[q].z; dst[3 * NT] = pd[q].w;
+    }
+  };
+
+  if (tid < kRC) X0T[tid * ld0 + m] = 0.f;
+  if (chunk0 * kRC < rows_total) prefetch(chunk0 * kRC);
   for (int ci = 0; ci < chunks_per_split; ++ci) {
     const int64_t r0 = (chunk0 + ci) * kRC;
     if (r0 >= rows_total) break;
     __syncthreads();  // previous chunk fully consumed
-    // ---- stage: X0T / XkT transposed images, dM rows (permuted columns) ----
-    for (int t = tid; t < n0f4; t += 256) {
-      // t -> (example-in-chunk bl, field i, d4); rows pl = bl*D + 4*d4 .. +3
-      const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
-      const int pl = bl * D + 4 * d4;
-      const int64_t pgl = r0 + pl;
-      const int64_t b = pgl / D;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pgl < rows_total) v = *reinterpret_cast<const float4 *>(X0 + (b * m + i) * D + 4 * d4);
-      X0T[(pl + 0) * ld0 + i] = v.x; X0T[(pl + 1) * ld0 + i] = v.y;
-      X0T[(pl + 2) * ld0 + i] = v.z; X0T[(pl + 3) * ld0 + i] = v.w;
-    }
-    if (tid < kRC) X0T[tid * ld0 + m] = 0.f;
-    for (int t = tid; t < nkf4; t += 256) {
-      const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
-      const int pl = bl * D + 4 * d4;
-      const int64_t pgl = r0 + pl;
-      const int64_t b = pgl / D;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pgl < rows_total)
-        v = *reinterpret_cast<const float4 *>(Xk + b * xk_bstride + (int64_t)j * D + 4 * d4);
-      XkT[(pl + 0) * ldk + j] = v.x; XkT[(pl + 1) * ldk + j] = v.y;
-      XkT[(pl + 2) * ldk + j] = v.z; XkT[(pl + 3) * ldk + j] = v.w;
-    }
-#pragma unroll
-    for (int q = 0; q < DMF4; ++q) {
-      const int f = tid + q * 256, pl = f / (Np / 4), c4 = f - pl * (Np / 4);
-      const int64_t pgl = r0 + pl;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pgl < rows_total) v = *reinterpret_cast<const float4 *>(dM + pgl * Np + 4 * c4);
-      const int n = 4 * c4, nt = n >> 5, cc = n & 31;
-      float *dst = dMs + pl * Np + cc * NT + nt;
-      dst[0] = v.x; dst[NT] = v.y; dst[2 * NT] = v.z; dst[3 * NT] = v.w;
-    }
+    commit();
     __syncthreads();
-    // ---- 32 MFMA steps over the 64 staged rows ----
+    // the next chunk's global loads fly during this chunk's 32 MFMA steps
+    if (ci + 1 < chunks_per_split && r0 + kRC < rows_total) prefetch(r0 + kRC);
 #pragma unroll 4
     for (int t = 0; t < kRC / 2; ++t) {
       const int pl = 2 * t + h;
@@ -515,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void cin_dw_kernel(
   // ---- partial slab: part[split][k'][n] ----
 #pragma unroll
   for (int q = 0; q < kKT; ++q) {
-    const int tile = group * 4 * kKT + wave * kKT + q;
+    const int tile = group * kDWW * kKT + wave * kKT + q;
     if (tile * 32 >= Kp) continue;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -567,6 +609,7 @@ extern "C" int64_t rm_cin_filter_workspace(int m, int H, int N) {
 static int cin_check(const char *fn, int64_t B, int m, int H, int N, int D) {
   RM_REQUIRE(B >= 0 && m > 0 && H > 0 && N > 0 && D > 0, "%s: bad sizes", fn);
   RM_REQUIRE(N <= 128, "%s: N=%d unsupported (<= 128 filters per layer)", fn, N);
+  RM_REQUIRE(m <= 64, "%s: m=%d unsupported (<= 64 fields)", fn, m);
   RM_REQUIRE(H <= 128, "%s: H=%d unsupported (<= 128 hidden maps)", fn, H);
   RM_REQUIRE(D % 4 == 0 && kRows % D == 0, "%s: D=%d unsupported (must divide 256, multiple of 4)", fn, D);
   return RM_OK;
@@ -595,9 +638,9 @@ extern "C" int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bst
   dim3 grid((unsigned)((B + epb - 1) / epb));
 #define RM_CIN_FWD(NT_)                                                                          \
   {                                                                                              \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_fwd_kernel<NT_>),                     \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                  \
-    hipLaunchKernelGGL((cin_fwd_kernel<NT_>), grid, dim3(256), smem, st, X0, Xk, xk_bstride,     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_fwd_kernel<NT_, 1>),            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
+    hipLaunchKernelGGL((cin_fwd_kernel<NT_, 1>), grid, dim3(512), smem, st, X0, Xk, xk_bstride,  \
                        filter_ws, bias, act, B, m, H, N, D, out, pooled, pool_stride, pool_col0, \
                        pool_from);                                                               \
   }
@@ -610,7 +653,7 @@ extern "C" int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bst
 extern "C" int64_t rm_cin_bwd_workspace(int64_t B, int m, int H, int N, int D) {
   const int NT = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
   const int Np = 32 * NT, Kp = cin_Kp(m, H);
-  const int ngroups = (Kp / 32 + 4 * kKT - 1) / (4 * kKT);
+  const int ngroups = (Kp / 32 + kDWW * kKT - 1) / (kDWW * kKT);
   const int64_t chunks_total = (B * D + kRC - 1) / kRC;
   const int S = cin_pick_splits(ngroups, chunks_total > 0 ? chunks_total : 1);
   return (int64_t)m * cin_Hp(H) * Np + B * D * Np + (int64_t)S * Kp * Np;
@@ -654,22 +697,24 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
                        d_hidden, dh_bstride, g, cin_w_direct, pool_from, act, B, N, Np, D, dM, dbias);
   }
   {
-    const size_t smem = cin_dx_smem(m, H, NT);
+    const int rows = (kRC * 2 % D == 0 && 256 % D == 0 && cin_dx_smem(m, H, NT, 256) <= 160 * 1024) ? 256 : 128;
+    const size_t smem = cin_dx_smem(m, H, NT, rows);
     RM_REQUIRE(smem <= 160 * 1024, "rm_cin_layer_bwd: m=%d H=%d needs %zu B of LDS (> 160 KiB)", m, H, smem);
-    const int epb = kRowsX / D;
+    const int epb = rows / D;
     dim3 grid((unsigned)((B + epb - 1) / epb));
-#define RM_CIN_DX(NT_, JB_)                                                                   \
+#define RM_CIN_DX(NT_, JB_, R_)                                                               \
   {                                                                                           \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dx_kernel<NT_, JB_>),        \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dx_kernel<NT_, JB_, R_>),    \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);         \
-    hipLaunchKernelGGL((cin_dx_kernel<NT_, JB_>), grid, dim3(256), smem, st, X0, Xk,          \
+    hipLaunchKernelGGL((cin_dx_kernel<NT_, JB_, R_>), grid, dim3(R_ * 2), smem, st, X0, Xk,   \
                        xk_bstride, xk_is_x0, Wq, dM, B, m, H, D, dX0, accumulate_dx0, dXk,    \
                        dxk_bstride);                                                          \
   }
-#define RM_CIN_DX_JB(NT_)                                                  \
-  {                                                                        \
-    if (JB == 1) RM_CIN_DX(NT_, 1) else if (JB == 2) RM_CIN_DX(NT_, 2)     \
-    else RM_CIN_DX(NT_, 4)                                                 \
+#define RM_CIN_DX_JB(NT_)                                                                      \
+  {                                                                                            \
+    if (JB == 1) { if (rows == 256) RM_CIN_DX(NT_, 1, 256) else RM_CIN_DX(NT_, 1, 128) }        \
+    else if (JB == 2) { if (rows == 256) RM_CIN_DX(NT_, 2, 256) else RM_CIN_DX(NT_, 2, 128) }   \
+    else RM_CIN_DX(NT_, 4, 128)                                                                \
   }
     const int JB = cin_Hp(H) / 32;  // 1, 2 or 4
     if (NT == 1) RM_CIN_DX_JB(1) else if (NT == 2) RM_CIN_DX_JB(2) else RM_CIN_DX_JB(4)
@@ -678,7 +723,7 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
   }
   {
     const size_t smem = cin_dw_smem(m, H, NT);
-    const int ngroups = (Kp / 32 + 4 * kKT - 1) / (4 * kKT);
+    const int ngroups = (Kp / 32 + kDWW * kKT - 1) / (kDWW * kKT);
     const int64_t chunks_total = (B * D + kRC - 1) / kRC;
     const int S = cin_pick_splits(ngroups, chunks_total);
     const int cps = (int)((chunks_total + S - 1) / S);
@@ -687,7 +732,7 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
   {                                                                                           \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dw_kernel<NT_>),             \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);         \
-    hipLaunchKernelGGL((cin_dw_kernel<NT_>), grid, dim3(256), smem, st, X0, Xk, xk_bstride,   \
+    hipLaunchKernelGGL((cin_dw_kernel<NT_>), grid, dim3(512), smem, st, X0, Xk, xk_bstride,   \
                        dM, B, m, H, D, cps, part);                                            \
   }
     if (NT == 1) RM_CIN_DW(1) else if (NT == 2) RM_CIN_DW(2) else RM_CIN_DW(4)
