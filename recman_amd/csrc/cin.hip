@@ -14,6 +14,8 @@
 // k' ordering: k' = i*He + j with He = H rounded up to even, so that the two k's
 // of one MFMA (lane halves h=0/1) always share i.  The padded j = H row of Xk is
 // zero in LDS and the matching filter rows are zero in the prepared filter.
+#include <type_traits>
+
 #include "rm_common.h"
 
 namespace {
@@ -426,10 +428,52 @@ size_t cin_dx_smem(int m, int H, int NT, int rows) {
 constexpr int kRC = 64;   // rows per staged chunk
 constexpr int kKT = 2;    // k'-tiles per wave
 constexpr int kDWW = 8;   // waves per dW block (2 per SIMD)
+constexpr int kMaxGroups = 16;
+
+// Work plan of the dW pass: group g (16 k'-tiles) is split over S[g] row ranges of cps[g]
+// chunks each; S[g] is proportional to the group's per-SIMD tile load so that every block
+// takes the same time (a partially filled last group gets fewer, longer blocks).
+struct DwPlan {
+  int ngroups, Smax;
+  int S[kMaxGroups], cps[kMaxGroups], blk0[kMaxGroups + 1];
+};
+
+DwPlan cin_dw_plan(int Kp, int64_t chunks_total, int target_blocks) {
+  DwPlan p;
+  const int ntiles = Kp / 32;
+  p.ngroups = (ntiles + kDWW * kKT - 1) / (kDWW * kKT);
+  int u[kMaxGroups], usum = 0;
+  for (int g = 0; g < p.ngroups; ++g) {
+    int t = ntiles - g * kDWW * kKT;
+    if (t > kDWW * kKT) t = kDWW * kKT;
+    int per_simd[4] = {0, 0, 0, 0};
+    for (int i = 0; i < t; ++i) per_simd[(i % kDWW) % 4]++;
+    // cost of one row chunk for this group, in MFMA tile-units per SIMD; never below 2: a
+    // chunk's staging (global loads, transposed LDS writes, two barriers) takes about as
+    // long as two tile-units, so lighter blocks are staging-bound (measured: weighting a
+    // 1-unit group as 1 made its blocks the critical path, 4.5 -> 6.1 ms)
+    u[g] = 2;
+    for (int q = 0; q < 4; ++q) u[g] = per_simd[q] > u[g] ? per_simd[q] : u[g];
+    usum += u[g];
+  }
+  p.Smax = 0;
+  p.blk0[0] = 0;
+  for (int g = 0; g < p.ngroups; ++g) {
+    int64_t S = (int64_t)target_blocks * u[g] / usum;
+    if (S < 1) S = 1;
+    if (S > chunks_total) S = chunks_total;
+    if (S < 1) S = 1;
+    p.S[g] = (int)S;
+    p.cps[g] = (int)((chunks_total + S - 1) / S);
+    p.blk0[g + 1] = p.blk0[g] + p.S[g];
+    if (p.S[g] > p.Smax) p.Smax = p.S[g];
+  }
+  return p;
+}
 template <int NT>
 __global__ __launch_bounds__(512) void cin_dw_kernel(
     const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride,
-    const float *__restrict__ dM, int64_t B, int m, int H, int D, int chunks_per_split,
+    const float *__restrict__ dM, int64_t B, int m, int H, int D, DwPlan plan,
     float *__restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int Np = 32 * NT;
@@ -441,14 +485,38 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(
   float *XkT = X0T + kRC * ld0;      // [64][ldk]
   float *dMs = XkT + kRC * ldk;      // [64][Np], n = nt*32+cc stored at cc*NT+nt
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
-  const int group = blockIdx.x, split = blockIdx.y;
+  // split-major block order: the groups of one row range run side by side and share the
+  // staged rows through L2 / Infinity Cache (group-major order re-read them from HBM)
+  int group = 0, split = 0;
+  {
+    int bleft = blockIdx.x;
+    for (split = 0; split < plan.Smax; ++split) {
+      int cnt = 0;
+      for (int g = 0; g < plan.ngroups; ++g) cnt += plan.S[g] > split;
+      if (bleft < cnt) break;
+      bleft -= cnt;
+    }
+    for (group = 0; group < plan.ngroups; ++group) {
+      if (plan.S[group] > split) {
+        if (bleft == 0) break;
+        --bleft;
+      }
+    }
+  }
+  const int chunks_per_split = plan.cps[group];
   const int64_t rows_total = B * D;
   const int64_t chunk0 = (int64_t)split * chunks_per_split;
 
+  // tile -> wave round-robin (tile = group*16 + q*8 + wave): a partially filled last group
+  // then loads every SIMD equally, and a wave skips the MFMAs of a tile slot beyond K'
+  // (its SIMD partner gets the matrix pipe) instead of multiplying zeros.
   int iq[kKT], jq[kKT];
+  bool tile_ok[kKT];
 #pragma unroll
   for (int q = 0; q < kKT; ++q) {
-    const int kp = (group * kDWW * kKT + wave * kKT + q) * 32 + c;
+    const int tile = group * kDWW * kKT + q * kDWW + wave;
+    tile_ok[q] = tile * 32 < Kp;
+    const int kp = tile * 32 + c;
     const int i = kp / He, j = kp - i * He;
     const bool ok = kp < Kp && i < m && j < H;
     iq[q] = ok ? i : m;
@@ -531,33 +599,42 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(
     __syncthreads();
     // the next chunk's global loads fly during this chunk's 32 MFMA steps
     if (ci + 1 < chunks_per_split && r0 + kRC < rows_total) prefetch(r0 + kRC);
+    // branch-free hot loop when both tile slots are real; the checked variant only runs in
+    // the partially filled last group
+    auto steps = [&](auto checked) {
 #pragma unroll 4
-    for (int t = 0; t < kRC / 2; ++t) {
-      const int pl = 2 * t + h;
-      float bv[NT];
-      const float *bp = dMs + pl * Np + c * NT;
-      if constexpr (NT == 4) {
-        const float4 t4 = *reinterpret_cast<const float4 *>(bp);
-        bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
-      } else if constexpr (NT == 2) {
-        const float2 t2 = *reinterpret_cast<const float2 *>(bp);
-        bv[0] = t2.x; bv[1] = t2.y;
-      } else {
-        bv[0] = bp[0];
-      }
+      for (int t = 0; t < kRC / 2; ++t) {
+        const int pl = 2 * t + h;
+        float bv[NT];
+        const float *bp = dMs + pl * Np + c * NT;
+        if constexpr (NT == 4) {
+          const float4 t4 = *reinterpret_cast<const float4 *>(bp);
+          bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
+        } else if constexpr (NT == 2) {
+          const float2 t2 = *reinterpret_cast<const float2 *>(bp);
+          bv[0] = t2.x; bv[1] = t2.y;
+        } else {
+          bv[0] = bp[0];
+        }
 #pragma unroll
-      for (int q = 0; q < kKT; ++q) {
-        const float a = X0T[pl * ld0 + iq[q]] * XkT[pl * ldk + jq[q]];
+        for (int q = 0; q < kKT; ++q) {
+          if constexpr (decltype(checked)::value) {
+            if (!tile_ok[q]) continue;  // wave-uniform
+          }
+          const float a = X0T[pl * ld0 + iq[q]] * XkT[pl * ldk + jq[q]];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[nt], acc[q][nt], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt)
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[nt], acc[q][nt], 0, 0, 0);
+        }
       }
-    }
+    };
+    if (tile_ok[0] && tile_ok[1]) steps(std::false_type{});
+    else steps(std::true_type{});
   }
   // ---- partial slab: part[split][k'][n] ----
 #pragma unroll
   for (int q = 0; q < kKT; ++q) {
-    const int tile = group * kDWW * kKT + wave * kKT + q;
+    const int tile = group * kDWW * kKT + q * kDWW + wave;
     if (tile * 32 >= Kp) continue;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -574,7 +651,7 @@ size_t cin_dw_smem(int m, int H, int NT) {
 }
 
 // dW[(i*H+j)][n] = sum_s part[s][i*He+j][n]
-__global__ void cin_dw_reduce_kernel(const float *__restrict__ part, int S, int m, int H, int N,
+__global__ void cin_dw_reduce_kernel(const float *__restrict__ part, DwPlan plan, int m, int H, int N,
                                      int Np, float *__restrict__ dW) {
   const int He = cin_He(H), Kp = cin_Kp(m, H);
   const int total = m * H * N;
@@ -582,17 +659,11 @@ __global__ void cin_dw_reduce_kernel(const float *__restrict__ part, int S, int 
     const int k = t / N, n = t - k * N;
     const int i = k / H, j = k - i * H;
     const int kp = i * He + j;
+    const int S = plan.S[(kp / 32) / (kDWW * kKT)];
     float acc = 0.f;
     for (int s = 0; s < S; ++s) acc += part[((int64_t)s * Kp + kp) * Np + n];
     dW[t] = acc;
   }
-}
-
-int cin_pick_splits(int ngroups, int64_t chunks_total) {
-  int S = 256 / ngroups;
-  if (S < 1) S = 1;
-  if ((int64_t)S > chunks_total) S = (int)chunks_total;
-  return S < 1 ? 1 : S;
 }
 
 size_t cin_fwd_smem(int m, int H, int NT) {
@@ -653,10 +724,9 @@ extern "C" int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bst
 extern "C" int64_t rm_cin_bwd_workspace(int64_t B, int m, int H, int N, int D) {
   const int NT = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
   const int Np = 32 * NT, Kp = cin_Kp(m, H);
-  const int ngroups = (Kp / 32 + kDWW * kKT - 1) / (kDWW * kKT);
   const int64_t chunks_total = (B * D + kRC - 1) / kRC;
-  const int S = cin_pick_splits(ngroups, chunks_total > 0 ? chunks_total : 1);
-  return (int64_t)m * cin_Hp(H) * Np + B * D * Np + (int64_t)S * Kp * Np;
+  const DwPlan plan = cin_dw_plan(Kp, chunks_total > 0 ? chunks_total : 1, 256);
+  return (int64_t)m * cin_Hp(H) * Np + B * D * Np + (int64_t)plan.Smax * Kp * Np;
 }
 
 extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int xk_is_x0,
@@ -723,21 +793,19 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
   }
   {
     const size_t smem = cin_dw_smem(m, H, NT);
-    const int ngroups = (Kp / 32 + kDWW * kKT - 1) / (kDWW * kKT);
     const int64_t chunks_total = (B * D + kRC - 1) / kRC;
-    const int S = cin_pick_splits(ngroups, chunks_total);
-    const int cps = (int)((chunks_total + S - 1) / S);
-    dim3 grid(ngroups, S);
+    const DwPlan plan = cin_dw_plan(Kp, chunks_total, 256);
+    dim3 grid(plan.blk0[plan.ngroups]);
 #define RM_CIN_DW(NT_)                                                                        \
   {                                                                                           \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dw_kernel<NT_>),             \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);         \
     hipLaunchKernelGGL((cin_dw_kernel<NT_>), grid, dim3(512), smem, st, X0, Xk, xk_bstride,   \
-                       dM, B, m, H, D, cps, part);                                            \
+                       dM, B, m, H, D, plan, part);                                           \
   }
     if (NT == 1) RM_CIN_DW(1) else if (NT == 2) RM_CIN_DW(2) else RM_CIN_DW(4)
 #undef RM_CIN_DW
-    hipLaunchKernelGGL(cin_dw_reduce_kernel, dim3(256), dim3(256), 0, st, part, S, m, H, N, Np, dW);
+    hipLaunchKernelGGL(cin_dw_reduce_kernel, dim3(256), dim3(256), 0, st, part, plan, m, H, N, Np, dW);
   }
   RM_CHECK_LAUNCH("rm_cin_layer_bwd");
   return RM_OK;
