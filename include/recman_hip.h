@@ -238,6 +238,23 @@ int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int x
                      int64_t workspace_floats, rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Row-wise (lazy) optimizer step on the fused table rows, straight from the IndexedSlices
+ * form the backward produces.  Replaces optimizer.minimize(...) of xDeepFM.py:121-126 /
+ * create_optimizer (utils.py:201-213) for the embedding-side variables: Keras Adam
+ * (kind 0: beta1/beta2, epsilon outside the sqrt), Adagrad (kind 1, accumulator starts at
+ * 0.1) or SGD (kind 2).  Only rows occurring in idx are touched; duplicates are summed.
+ *   rows, m_state, v_state, gbuf [R, LD] (gbuf must be all-zero on entry, is on exit),
+ *   stamp [R] int32 (any values != step), step >= 1 and different from the previous call,
+ *   g_bias / g_lin [B]: per-example gradient of the bias (column D) / linear (column D+1)
+ *   entries or NULL; reset != 0 ignores the stored moments (the reference builds a new
+ *   optimizer for every batch). */
+int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field_off, const float *d_rows,
+                             const float *g_bias, const float *g_lin, int64_t B, int F, int D,
+                             int LD, float *rows, float *m_state, float *v_state, float *gbuf,
+                             int32_t *stamp, int step, int kind, float lr, float beta1, float beta2,
+                             float eps, int reset, rm_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Row helpers (owner-side gather and re-ordering for the row-sharded table).
  */
 /* Buckets the n = B*F occurrences (b,f) by the owner rank of their global row

@@ -312,3 +312,26 @@ def pack_grad_rows(d_rows, g_bias, g_lin, pos, out):
               _chk(g_bias, "g_bias", F32, (B,), allow_none=True),
               _chk(g_lin, "g_lin", F32, (B,), allow_none=True), _chk(pos, "pos", I64, (n,)), B, F, D,
               width, _chk(out, "out", F32), _stream())
+
+
+OPT_KINDS = {"adam": 0, "adagrad": 1, "gd": 2, "sgd": 2}
+
+
+def sparse_optimizer_step(idx, field_off, d_rows, rows, m_state, v_state, gbuf, stamp, step, kind, lr,
+                          g_bias=None, g_lin=None, reset=False, beta1=0.9, beta2=0.999, eps=1e-7):
+    """Lazy row-wise optimizer step on fused rows [R, LD] (see rm_sparse_optimizer_step)."""
+    B, F, D = d_rows.shape
+    R, LD = rows.shape
+    for nm, t in (("m_state", m_state), ("v_state", v_state), ("gbuf", gbuf)):
+        if t is not None:
+            _chk(t, nm, F32, (R, LD))
+    if stamp.dtype != torch.int32 or stamp.numel() != R:
+        raise ValueError("sparse_optimizer_step: stamp must be int32 [R]")
+    _lib.call("rm_sparse_optimizer_step", _chk(idx, "idx", I64, (B, F)),
+              _chk(field_off, "field_off", I64, (F,)), _chk(d_rows, "d_rows", F32),
+              _chk(g_bias, "g_bias", F32, (B,), allow_none=True),
+              _chk(g_lin, "g_lin", F32, (B,), allow_none=True), B, F, D, LD, _chk(rows, "rows", F32),
+              None if m_state is None else m_state.data_ptr(),
+              None if v_state is None else v_state.data_ptr(), gbuf.data_ptr(), stamp.data_ptr(),
+              int(step), OPT_KINDS[kind], float(lr), float(beta1), float(beta2), float(eps),
+              1 if reset else 0, _stream())

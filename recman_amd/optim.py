@@ -51,3 +51,34 @@ class Optimizer:
                 p.add_(buf, alpha=-self.lr)
             else:
                 p.add_(g, alpha=-self.lr)
+
+
+class SparseTableOptimizer:
+    """Lazy row-wise update of the fused table rows straight from the IndexedSlices the
+    backward produces (rm_sparse_optimizer_step): only rows occurring in the batch are
+    touched, no dense gradient is ever formed.  Needs embedding_l2_reg == linear_l2_reg == 0
+    (a dense l2 term touches every row, layers.py:188-193) - DeepModel falls back to the
+    dense path otherwise."""
+
+    def __init__(self, engine, name="adam", lr=1e-3):
+        import torch as _t
+
+        from . import ops
+
+        self.ops, self.e, self.name, self.lr = ops, engine, name, float(lr)
+        R, LD = engine.rows.shape
+        dev = engine.device
+        self.m = _t.zeros(R, LD, device=dev) if name == "adam" else None
+        self.v = (_t.zeros(R, LD, device=dev) if name == "adam"
+                  else _t.full((R, LD), 0.1, device=dev) if name == "adagrad" else None)
+        self.gbuf = _t.zeros(R, LD, device=dev)
+        self.stamp = _t.zeros(R, dtype=_t.int32, device=dev)
+        self.t = 0
+
+    def step(self, idx, reset=False):
+        e = self.e
+        self.t += 1
+        self.ops.sparse_optimizer_step(
+            idx, e.field_off, e.d_rows, e.rows, self.m, self.v, self.gbuf, self.stamp, self.t,
+            self.name, self.lr, g_bias=e.dlogit if (e.use_bias_tables and e._has_fm()) else None,
+            g_lin=e.dlogit if e.use_linear else None, reset=reset)

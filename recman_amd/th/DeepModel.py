@@ -21,7 +21,7 @@ from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_random_state
 
 from .. import engine as eng
-from ..optim import Optimizer
+from ..optim import Optimizer, SparseTableOptimizer
 from .inputs import DataInputs, FeatureDictionary
 
 log = logging.getLogger(__name__)
@@ -62,6 +62,13 @@ class DeepModel(BaseEstimator, TransformerMixin):
         eng.init_reference(e, self.random_seed)
         self._engine = e
         self._opt = Optimizer(hp.get("optimizer", "adam"), hp.get("learning_rate", 1e-3))
+        # row-wise sparse step for the table when nothing forces a dense gradient
+        no_l2 = not hp.get("embedding_l2_reg", 0.0) and not hp.get("linear_l2_reg", 0.0)
+        want = hp.get("sparse_optimizer", e.rows.numel() > (1 << 24))
+        self._sparse_opt = None
+        if want and no_l2 and hp.get("optimizer", "adam") in ("adam", "adagrad", "gd", "sgd"):
+            self._sparse_opt = SparseTableOptimizer(e, hp.get("optimizer", "adam"),
+                                                    hp.get("learning_rate", 1e-3))
         return e
 
     @property
@@ -152,7 +159,12 @@ class DeepModel(BaseEstimator, TransformerMixin):
         loss = e.fwd_bwd(idx, dense, yt, masks=self._dropout_masks(idx.shape[0]))
         if self.strict_reference:
             self._opt.reset()  # a NEW optimizer every batch (xDeepFM.py:121-126)
-        self._opt.step(e.params, e.dense_grads(idx))
+        fm_masked = getattr(e, "d_bias", None) is not None  # FM bias dropout: per-occurrence grads
+        if self._sparse_opt is not None and not fm_masked:
+            self._sparse_opt.step(idx, reset=self.strict_reference)
+            self._opt.step(e.params, e.grads)  # dense parameters only
+        else:
+            self._opt.step(e.params, e.dense_grads(idx))
         return loss
 
     def _eval_at_epoch(self, enc_train, y_train, enc_valid=None, y_valid=None, start_time=None, epoch=0):
