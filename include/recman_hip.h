@@ -238,6 +238,22 @@ int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int x
                      int64_t workspace_floats, rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Multi-valued tag-list features (MultiValCsvFeat, inputs.py:380-425): the sqrtn-pooled
+ * lookup tf.nn.embedding_lookup_sparse(..., combiner="sqrtn") of layers.py:144-169 and the
+ * multi-hot linear input of utils.py:86-108.  CSR input: example b owns tag ids
+ * ids[offsets[b] .. offsets[b+1]) (0 = unknown tag).  rm_pool_rows writes one pooled FUSED
+ * row per example: out[b, 0..D) = sum emb / sqrt(n), out[b, D] = sum bias / sqrt(n),
+ * out[b, D+1] = sum over known tags (id >= 1) of the linear weight; the gather kernel then
+ * reads that row like any other.  rm_pool_rows_bwd scatters a row gradient (d_rows rows of
+ * dr_stride floats, g_bias / g_lin [B] or NULL) back to the tag rows of dense gradient
+ * buffers d_table [R,D], d_bias [R], d_lin [R] (float atomics; NULL = skip). */
+int rm_pool_rows(const float *rows, int64_t row0, int LD, int D, const int64_t *offsets,
+                 const int64_t *ids, int64_t B, float *out, rm_stream_t stream);
+int rm_pool_rows_bwd(const float *d_rows, int64_t dr_stride, const float *g_bias, const float *g_lin,
+                     int D, const int64_t *offsets, const int64_t *ids, int64_t B, int64_t row0,
+                     float *d_table, float *d_bias, float *d_lin, rm_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Row-wise (lazy) optimizer step on the fused table rows, straight from the IndexedSlices
  * form the backward produces.  Replaces optimizer.minimize(...) of xDeepFM.py:121-126 /
  * create_optimizer (utils.py:201-213) for the embedding-side variables: Keras Adam

@@ -48,10 +48,13 @@ class Spec:
     (inputs.py:166).  dense_names: DenseFeat columns in dictionary order.
     """
 
-    def __init__(self, sparse_names, feat_sizes, dense_names=()):
+    def __init__(self, sparse_names, feat_sizes, dense_names=(), multi_names=()):
         self.sparse_names = list(sparse_names)
         self.feat_sizes = [int(v) for v in feat_sizes]
         self.dense_names = list(dense_names)
+        # embedding features that are MultiValCsvFeat (inputs.py:380-425): their idx column is
+        # ignored, their tag ids come as CSR (offsets [B+1], ids [nnz]) in the `mv` dict
+        self.multi_names = list(multi_names)
 
     @property
     def F(self):
@@ -63,13 +66,16 @@ class Spec:
 
     @property
     def lin_offsets(self):
-        # one-hot block offsets of LinearCombiner (layers.py:284-293) with the
-        # feature order of utils.py:31-36: sparse feats first, dense last
-        off, out = 0, []
-        for v in self.feat_sizes:
-            out.append(off)
-            off += v
-        return out, off  # (per sparse feature, start of the dense block)
+        # one-hot block offsets of LinearCombiner (layers.py:284-293) with the feature order
+        # of utils.py:31-36: sparse feats first, then multi-valued csv feats, dense last.
+        # Returned per embedding feature IN sparse_names ORDER, plus the dense block start.
+        size = dict(zip(self.sparse_names, self.feat_sizes))
+        order = [n for n in self.sparse_names if n not in self.multi_names] + list(self.multi_names)
+        off, at = 0, {}
+        for n in order:
+            at[n] = off
+            off += size[n]
+        return [at[n] for n in self.sparse_names], off
 
 
 # ---------------------------------------------------------------------------
@@ -151,17 +157,30 @@ def _lookup(table, ids):
     return table[ids]
 
 
-def feat_embedding_layer(p, spec, idx, use_bias=True):
-    """FeatEmbeddingLayer.__call__ (layers.py:238-261) over FeatEmbedding.__call__
-    SparseFeat branch (layers.py:117-128): E [B,F,D], bias [B,F,1] or None."""
-    E = torch.stack(
-        [_lookup(p[f"{n}_feat_embed"], idx[:, f]) for f, n in enumerate(spec.sparse_names)], dim=1
-    )
+def pooled_lookup(table, offsets, ids):
+    """tf.nn.embedding_lookup_sparse(table, sp_ids, None, combiner="sqrtn") (layers.py:150-156):
+    per example sum of the looked-up rows / sqrt(number of ids); no ids -> zeros."""
+    B = offsets.shape[0] - 1
+    n = offsets[1:] - offsets[:-1]
+    seg = torch.repeat_interleave(torch.arange(B), n)
+    out = torch.zeros(B, table.shape[1], dtype=table.dtype).index_add(0, seg, table[ids])
+    return out / n.clamp(min=1).to(table.dtype).sqrt().unsqueeze(1)
+
+
+def feat_embedding_layer(p, spec, idx, use_bias=True, mv=None):
+    """FeatEmbeddingLayer.__call__ (layers.py:238-261) over FeatEmbedding.__call__:
+    SparseFeat branch (layers.py:117-128) and the sqrtn-pooled MultiValCsvFeat branch
+    (layers.py:144-169): E [B,F,D], bias [B,F,1] or None."""
+    def one(suffix, f, n):
+        t = p[f"{n}_feat_{suffix}"]
+        if n in spec.multi_names:
+            return pooled_lookup(t, *mv[n])
+        return _lookup(t, idx[:, f])
+
+    E = torch.stack([one("embed", f, n) for f, n in enumerate(spec.sparse_names)], dim=1)
     bias = None
     if use_bias:
-        bias = torch.stack(
-            [_lookup(p[f"{n}_feat_bias"], idx[:, f]) for f, n in enumerate(spec.sparse_names)], dim=1
-        )
+        bias = torch.stack([one("bias", f, n) for f, n in enumerate(spec.sparse_names)], dim=1)
     return E, bias
 
 
@@ -169,15 +188,24 @@ def embedding_l2(p, spec, l2_reg):
     return sum(l2_reg * 0.5 * p[f"{n}_feat_embed"].square().sum() for n in spec.sparse_names)
 
 
-def linear_layer(p, spec, idx, dense, manual_weights=None):
+def linear_layer(p, spec, idx, dense, manual_weights=None, mv=None):
     """LinearCombiner + LinearLayer (layers.py:281-347) / the Sparse* twins
-    (layers.py:368-439) in gather form: one_hot(idx) @ W == W[offset + idx]."""
+    (layers.py:368-439) in gather form: one_hot(idx) @ W == W[offset + idx]; a
+    MultiValCsvFeat contributes its multi-hot counts with slot 0 zeroed (utils.py:86-108)."""
     W = p["linear_w"]
     if manual_weights is not None:  # training=False (layers.py:338-345, 426-437)
         W = W + manual_weights.reshape(-1, 1).to(W.dtype)
     offs, dense_off = spec.lin_offsets
     out = p["linear_w0"].reshape(1, 1).expand(idx.shape[0], 1)
     for f, off in enumerate(offs):
+        n = spec.sparse_names[f]
+        if n in spec.multi_names:
+            offsets, ids = mv[n]
+            B = offsets.shape[0] - 1
+            seg = torch.repeat_interleave(torch.arange(B), offsets[1:] - offsets[:-1])
+            contrib = W[off + ids] * (ids >= 1).to(W.dtype).unsqueeze(1)
+            out = out + torch.zeros(B, 1, dtype=W.dtype).index_add(0, seg, contrib)
+            continue
         out = out + _lookup(W, off + idx[:, f])
     if spec.Dn:
         out = out + dense @ W[dense_off : dense_off + spec.Dn]
@@ -295,11 +323,11 @@ def create_loss(y, pred, task="classification"):
 # ---------------------------------------------------------------------------
 # model compositions
 # ---------------------------------------------------------------------------
-def deepfm_logit(p, spec, idx, dense, hp, training=True, masks=None, manual_weights=None):
+def deepfm_logit(p, spec, idx, dense, hp, training=True, masks=None, manual_weights=None, mv=None):
     """DeepFM._init_graph (DeepFM.py:107-158): final = linear + fm + dnn."""
     masks = masks or {}
-    E, bias = feat_embedding_layer(p, spec, idx, use_bias=True)
-    logit = linear_layer(p, spec, idx, dense, manual_weights)
+    E, bias = feat_embedding_layer(p, spec, idx, use_bias=True, mv=mv)
+    logit = linear_layer(p, spec, idx, dense, manual_weights, mv)
     if hp.get("use_fm", True):
         keep = hp.get("fm_dropout", (1, 1)) if training else (1, 1)
         logit = logit + fm_layer(E, bias, keep, masks.get("fm", (None, None)))
@@ -319,12 +347,12 @@ def deepfm_l2(p, spec, hp):
     return out  # DeepFM.py:164-180 (FMLayer.l2 is 0)
 
 
-def dcn_logit(p, spec, idx, dense, hp, training=True, masks=None, manual_weights=None):
+def dcn_logit(p, spec, idx, dense, hp, training=True, masks=None, manual_weights=None, mv=None):
     """DCN._init_graph (DCN.py:99-144): dnn_input feeds DNN and CrossNet;
     final = dnn + cross + dnn (dnn counted twice, DCN.py:140-142) only with
     strict_reference, else dnn + cross; + linear if use_linear."""
     masks = masks or {}
-    E, _ = feat_embedding_layer(p, spec, idx, use_bias=False)
+    E, _ = feat_embedding_layer(p, spec, idx, use_bias=False, mv=mv)
     x = dnn_input(E, dense)
     n = len(hp["deep_hidden_units"])
     keep = hp.get("deep_dropout", [1] * (n + 1)) if training else [1] * (n + 1)
@@ -333,7 +361,7 @@ def dcn_logit(p, spec, idx, dense, hp, training=True, masks=None, manual_weights
     if hp.get("strict_reference", False):
         logit = logit + dnn_logit
     if hp.get("use_linear", True):
-        logit = logit + linear_layer(p, spec, idx, dense, manual_weights)
+        logit = logit + linear_layer(p, spec, idx, dense, manual_weights, mv)
     return logit
 
 
@@ -345,12 +373,12 @@ def dcn_l2(p, spec, hp):
     return out + cross_l2(p, hp.get("cross_layer_l2_reg", 0.0))  # DCN.py:151-166
 
 
-def xdeepfm_logit(p, spec, idx, dense, hp, training=True, masks=None, manual_weights=None):
+def xdeepfm_logit(p, spec, idx, dense, hp, training=True, masks=None, manual_weights=None, mv=None):
     """xDeepFM._out (xDeepFM.py:47-104): embeddings without bias tables,
     final = linear + cin + dnn."""
     masks = masks or {}
-    E, _ = feat_embedding_layer(p, spec, idx, use_bias=False)
-    logit = linear_layer(p, spec, idx, dense, manual_weights)
+    E, _ = feat_embedding_layer(p, spec, idx, use_bias=False, mv=mv)
+    logit = linear_layer(p, spec, idx, dense, manual_weights, mv)
     nc = len(hp["cin_cross_layer_units"])
     keep = hp.get("cin_dropout", [1] * (nc + 1)) if training else [1] * (nc + 1)
     logit = logit + cin(p, E, nc, hp.get("cin_activation", "leaky_relu"), keep, masks.get("cin"))
@@ -376,7 +404,7 @@ MODELS = {
 
 
 def model_loss(model, p, spec, idx, dense, y, hp, task="classification", masks=None,
-               sparse_grad=False):
+               sparse_grad=False, mv=None):
     """_loss (xDeepFM.py:106-114): create_loss(y, _out(inputs)) + sum of layer l2().
     sparse_grad: table gradients as sparse tensors (bench.py's CPU baseline; needs all
     l2 factors 0, as TF's IndexedSlices stay sparse only then)."""
@@ -384,7 +412,7 @@ def model_loss(model, p, spec, idx, dense, y, hp, task="classification", masks=N
     logit_fn, l2_fn = MODELS[model]
     SPARSE_GRAD = bool(sparse_grad)
     try:
-        logit = logit_fn(p, spec, idx, dense, hp, True, masks)
+        logit = logit_fn(p, spec, idx, dense, hp, True, masks, mv=mv)
     finally:
         SPARSE_GRAD = False
     pred = prediction(logit, task)
@@ -394,12 +422,12 @@ def model_loss(model, p, spec, idx, dense, y, hp, task="classification", masks=N
     return loss, logit, pred
 
 
-def fwd_bwd(model, p, spec, idx, dense, y, hp, task="classification", masks=None):
+def fwd_bwd(model, p, spec, idx, dense, y, hp, task="classification", masks=None, mv=None):
     """One forward+backward: returns (loss, logit [B], pred [B], grads dict).
     Embedding-table gradients come back dense (what TF's IndexedSlices + the
     dense l2 term add up to)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-    loss, logit, pred = model_loss(model, leaves, spec, idx, dense, y, hp, task, masks)
+    loss, logit, pred = model_loss(model, leaves, spec, idx, dense, y, hp, task, masks, mv=mv)
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     return loss.detach(), logit.detach().reshape(-1), pred.detach(), grads

@@ -43,10 +43,12 @@ class FeatureSpec:
     FeatureDictionary order (inputs.py:13-15) with their feat_size (null slot
     included, inputs.py:166) and the dense feature names."""
 
-    def __init__(self, sparse_names, feat_sizes, dense_names=()):
+    def __init__(self, sparse_names, feat_sizes, dense_names=(), multi_names=()):
         self.sparse_names = list(sparse_names)
         self.feat_sizes = [int(v) for v in feat_sizes]
         self.dense_names = list(dense_names)
+        # embedding features that are multi-valued (MultiValCsvFeat): sqrtn-pooled lookup
+        self.multi_names = list(multi_names)
         if len(self.sparse_names) != len(self.feat_sizes):
             raise ValueError("sparse_names and feat_sizes differ in length")
 
@@ -68,6 +70,13 @@ class FeatureSpec:
             out.append(off)
             off += v
         return out
+
+    def lin_ref_blocks(self):
+        """(row offset in the table, size) of each feature's one-hot block in the order the
+        reference's linear_w stacks them (utils.py:27-36): sparse feats, then multi-valued."""
+        at = dict(zip(self.sparse_names, zip(self.offsets(), self.feat_sizes)))
+        order = [n for n in self.sparse_names if n not in self.multi_names] + list(self.multi_names)
+        return [at[n] for n in order]
 
 
 class MLP:
@@ -287,6 +296,8 @@ class Engine:
         self.table = self.rows
         self.linear_w_dense = torch.zeros(Dn, dtype=F32, device=dev)
         offs = spec.offsets()
+        self.field_off_host = offs
+        self._mv = None
         self.field_off = torch.tensor(offs, dtype=I64, device=dev)
         self.lin_off = self.field_off  # sparse one-hot blocks share the table's row numbering
         for name, off, V in zip(spec.sparse_names, offs, spec.feat_sizes):
@@ -314,7 +325,7 @@ class Engine:
             v = torch.as_tensor(v).to(self.device, F32)
             if k == "linear_w":  # [sum V_f + Dn, 1]: one-hot blocks first, dense columns last
                 v = v.reshape(-1)
-                self.params["linear_w_sparse"].copy_(v[:R])
+                self.params["linear_w_sparse"].copy_(self._lin_from_ref(v[:R]))
                 self.params["linear_w_dense"].copy_(v[R:])
                 continue
             if k not in self.params:
@@ -330,15 +341,31 @@ class Engine:
                 continue
             out[k] = v.detach().clone().contiguous()
         if "linear_w_sparse" in self.params:
-            out["linear_w"] = torch.cat([self.params["linear_w_sparse"].detach().reshape(-1),
+            out["linear_w"] = torch.cat([self._lin_to_ref(self.params["linear_w_sparse"].detach().reshape(-1)),
                                          self.params["linear_w_dense"].detach().reshape(-1)]).view(-1, 1)
+        return out
+
+    def _lin_to_ref(self, v_rows):
+        """[R] in table-row order -> the reference's linear_w block order (sparse, multi-valued)."""
+        if not self.spec.multi_names:
+            return v_rows
+        return torch.cat([v_rows[o: o + n] for o, n in self.spec.lin_ref_blocks()])
+
+    def _lin_from_ref(self, v_ref):
+        if not self.spec.multi_names:
+            return v_ref
+        out = torch.empty_like(v_ref)
+        at = 0
+        for o, n in self.spec.lin_ref_blocks():
+            out[o: o + n] = v_ref[at: at + n]
+            at += n
         return out
 
     def to_reference_names(self, d):
         """Merges the internal linear_w_sparse / linear_w_dense entries into `linear_w`."""
         d = dict(d)
         if "linear_w_sparse" in d:
-            d["linear_w"] = torch.cat([d.pop("linear_w_sparse").reshape(-1),
+            d["linear_w"] = torch.cat([self._lin_to_ref(d.pop("linear_w_sparse").reshape(-1)),
                                        d.pop("linear_w_dense").reshape(-1)]).view(-1, 1)
         return d
 
@@ -357,6 +384,23 @@ class Engine:
         self.dlogit = torch.empty(B, dtype=F32, device=dev)
         self.loss = torch.zeros(1, dtype=F32, device=dev)
         self.ws = torch.empty(256 * 1024, dtype=F32, device=dev)
+        self.mv_fields = [f for f, n in enumerate(self.spec.sparse_names) if n in self.spec.multi_names]
+        if self.mv_fields:
+            # per-batch pooled rows of the multi-valued features live in a scratch block that is
+            # addressed AS ROWS OF THE TABLE: its start is aligned so that (scratch - table) is a
+            # whole number of rows, and the gather kernel reads row `base + b` like any other
+            LD = self.LD
+            raw = torch.zeros((len(self.mv_fields) * B + 2) * LD, dtype=F32, device=dev)
+            shift = ((self.rows.data_ptr() - raw.data_ptr()) // 4) % LD
+            self._mv_raw = raw
+            self.mv_scratch = raw[shift: shift + len(self.mv_fields) * B * LD].view(len(self.mv_fields), B, LD)
+            base = (self.mv_scratch.data_ptr() - self.rows.data_ptr()) // (4 * LD)
+            assert (self.mv_scratch.data_ptr() - self.rows.data_ptr()) % (4 * LD) == 0
+            self.field_off_mv = self.field_off.clone()
+            for j, f in enumerate(self.mv_fields):
+                self.field_off_mv[f] = base + j * B
+            self.idx_mv = torch.zeros(B, self.F, dtype=I64, device=dev)
+            self._arange = torch.arange(B, dtype=I64, device=dev)
         self._alloc_model(B)
 
     def _alloc_model(self, B):
@@ -364,53 +408,66 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def _embed(self, idx, dense, want_fm, masks, lin_w=None):
-        """lin_w: optional (sparse [R], dense [Dn]) override of the linear weights (predict
-        with manual feature weights); then the linear term is gathered from that separate
-        array instead of the row."""
         m = masks or {}
         fm_masks = m.get("fm", (None, None))
         D = self.D
-        common = dict(
+        foff = self.field_off
+        if self.mv_fields:
+            mv = self._mv
+            if mv is None:
+                raise ValueError(f"multi-valued features {self.spec.multi_names} need their tag ids (mv=...)")
+            self.idx_mv.copy_(idx)
+            for j, f in enumerate(self.mv_fields):
+                offsets, ids = mv[self.spec.sparse_names[f]]
+                ops.pool_rows(self.rows, int(self.field_off_host[f]), D, offsets, ids, self.mv_scratch[j])
+                self.idx_mv[:, f] = self._arange
+            idx, foff = self.idx_mv, self.field_off_mv
+        ops.embed_fwd(
+            idx, self.rows, foff, D=D, table_ld=self.LD,
+            bias_col=D if (want_fm and self.use_bias_tables) else None,
+            lin_col=D + 1 if self.use_linear else None,
+            lin_w_dense=self.linear_w_dense if (self.use_linear and self.Dn) else None,
             dense=dense if (self.use_linear and self.Dn) else None,
             lin_w0=self.params["linear_w0"] if self.use_linear else None,
             mask_b=fm_masks[0] if want_fm else None, mask_e=fm_masks[1] if want_fm else None,
             E=self.E, fm_sum=self.fm_sum if want_fm else None,
             fm_logit=self.fm_logit if want_fm else None,
             lin_logit=self.lin_logit if self.use_linear else None)
-        if lin_w is None:
-            ops.embed_fwd(idx, self.rows, self.field_off, D=D, table_ld=self.LD,
-                          bias_col=D if (want_fm and self.use_bias_tables) else None,
-                          lin_col=D + 1 if self.use_linear else None,
-                          lin_w_dense=self.linear_w_dense if (self.use_linear and self.Dn) else None,
-                          **common)
-        else:
-            ops.embed_fwd(idx, self.rows, self.field_off, D=D, table_ld=self.LD,
-                          bias_col=D if (want_fm and self.use_bias_tables) else None,
-                          lin_w=lin_w[0] if self.use_linear else None, lin_off=self.lin_off,
-                          lin_w_dense=lin_w[1] if (self.use_linear and self.Dn) else None, **common)
 
-    def forward(self, idx, dense=None, training=False, masks=None, manual_weights=None):
+    def forward(self, idx, dense=None, training=False, masks=None, manual_weights=None, mv=None):
         """-> (logit [B], pred [B]).  training=False disables dropout and (as the
-        reference does, layers.py:338-345) adds the per-feature manual weights."""
+        reference does, layers.py:338-345) adds the per-feature manual weights (a vector in
+        the reference's linear_w order).  mv: name -> (offsets, ids) device tensors of the
+        multi-valued features."""
         self._alloc(idx.shape[0])
-        lin_w = None
+        self._mv = mv
+        backup = None
         if manual_weights is not None:
+            # W + weights for this call only: exact restore from a copy (an add/subtract pair
+            # would drift by an ulp per predict call)
             mw = manual_weights.to(self.device, F32).reshape(-1)
             R = self.spec.rows
-            lin_w = ((self.params["linear_w_sparse"] + mw[:R]).contiguous(),
-                     self.linear_w_dense + mw[R:])
-        branches = self._branches_fwd(idx, dense, training, masks, lin_w)
-        ops.logit_loss(branches, task=self.task, logit=self.logit, pred=self.pred)
+            backup = (self.params["linear_w_sparse"].clone(), self.linear_w_dense.clone())
+            self.params["linear_w_sparse"].add_(self._lin_from_ref(mw[:R]))
+            self.linear_w_dense.add_(mw[R:])
+        try:
+            branches = self._branches_fwd(idx, dense, training, masks, None)
+            ops.logit_loss(branches, task=self.task, logit=self.logit, pred=self.pred)
+        finally:
+            if backup is not None:
+                self.params["linear_w_sparse"].copy_(backup[0])
+                self.linear_w_dense.copy_(backup[1])
         return self.logit, self.pred
 
     # --------------------------------------------------------- forward+backward
-    def fwd_bwd(self, idx, dense, y, masks=None):
+    def fwd_bwd(self, idx, dense, y, masks=None, mv=None):
         """One training step's forward + backward.  Returns the loss tensor [1]
         (data loss + l2 terms).  Gradients: self.grads (dense parameters),
         self.d_rows [B,F,D] + idx (embedding rows, IndexedSlices form), self.dlogit
         (per-occurrence gradient of the bias-table / sparse linear entries)."""
         B = idx.shape[0]
         self._alloc(B)
+        self._mv = mv
         branches = self._branches_fwd(idx, dense, True, masks, None)
         yk = dict(y=y) if y.dtype == I64 else dict(y_f=y)
         ops.logit_loss(branches, task=self.task, logit=self.logit, pred=self.pred,
@@ -486,28 +543,50 @@ class Engine:
         hp, D = self.hp, self.D
         out = {k: v.clone() for k, v in self.grads.items()}
         R = self.spec.rows
-        d_table = torch.zeros(R, D, dtype=F32, device=self.device)
-        ops.scatter_add_rows(d_table, idx, self.field_off, rows=self.d_rows)
+        foff = self.field_off
+        if self.mv_fields:
+            # occurrences of multi-valued fields go to a dummy row R here; their gradient is
+            # scattered to the tag rows below (rm_pool_rows_bwd)
+            idx = idx.clone()
+            foff = self.field_off.clone()
+            for f in self.mv_fields:
+                idx[:, f] = 0
+                foff[f] = R
+        d_table = torch.zeros(R + 1, D, dtype=F32, device=self.device)
+        ops.scatter_add_rows(d_table, idx, foff, rows=self.d_rows)
+        offs = self.spec.offsets()
+        d_bias = None
+        g_bias_occ = None
+        if self.use_bias_tables:
+            d_bias = torch.zeros(R + 1, dtype=F32, device=self.device)
+            if self._has_fm():
+                if getattr(self, "d_bias", None) is not None:
+                    ops.scatter_add_rows(d_bias, idx, foff, rows=self.d_bias, width=1, ld=1)
+                    g_bias_occ = self.d_bias
+                else:
+                    ops.scatter_add_rows(d_bias, idx, foff, g_row=self.dlogit)
+        d_lin = torch.zeros(R + 1, dtype=F32, device=self.device)
+        if self.use_linear:
+            ops.scatter_add_rows(d_lin, idx, foff, g_row=self.dlogit)
+        for f in self.mv_fields:
+            offsets, ids = self._mv[self.spec.sparse_names[f]]
+            gb = None
+            if d_bias is not None and self._has_fm():
+                gb = g_bias_occ[:, f].contiguous() if g_bias_occ is not None else self.dlogit
+            ops.pool_rows_bwd(self.d_rows[:, f, :], gb, self.dlogit if self.use_linear else None, D,
+                              offsets, ids, offs[f], d_table, d_bias if gb is not None else None,
+                              d_lin if self.use_linear else None)
+        d_table, d_lin = d_table[:R], d_lin[:R]
+        if d_bias is not None:
+            d_bias = d_bias[:R]
         reg = hp.get("embedding_l2_reg", 0.0)
         if reg:
             d_table.add_(self.rows[:, :D], alpha=reg)
-        offs = self.spec.offsets()
-        d_bias = None
-        if self.use_bias_tables:
-            d_bias = torch.zeros(R, dtype=F32, device=self.device)
-            if self._has_fm():
-                if getattr(self, "d_bias", None) is not None:
-                    ops.scatter_add_rows(d_bias, idx, self.field_off, rows=self.d_bias, width=1,
-                                         ld=1)
-                else:
-                    ops.scatter_add_rows(d_bias, idx, self.field_off, g_row=self.dlogit)
         for name, off, V in zip(self.spec.sparse_names, offs, self.spec.feat_sizes):
             out[f"{name}_feat_embed"] = d_table[off: off + V]
             if d_bias is not None:
                 out[f"{name}_feat_bias"] = d_bias[off: off + V].view(V, 1)
-        d_lin = torch.zeros(R, dtype=F32, device=self.device)
         if self.use_linear:
-            ops.scatter_add_rows(d_lin, idx, self.lin_off, g_row=self.dlogit)
             reg = hp.get("linear_l2_reg", 0.0)
             if reg:
                 d_lin.add_(self.params["linear_w_sparse"], alpha=reg)

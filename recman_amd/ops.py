@@ -335,3 +335,24 @@ def sparse_optimizer_step(idx, field_off, d_rows, rows, m_state, v_state, gbuf, 
               None if v_state is None else v_state.data_ptr(), gbuf.data_ptr(), stamp.data_ptr(),
               int(step), OPT_KINDS[kind], float(lr), float(beta1), float(beta2), float(eps),
               1 if reset else 0, _stream())
+
+
+def pool_rows(rows, row0, D, offsets, ids, out):
+    """sqrtn-pooled fused rows of a multi-valued feature (rm_pool_rows): out [B, LD]."""
+    B = offsets.shape[0] - 1
+    LD = rows.shape[1]
+    _lib.call("rm_pool_rows", _chk(rows, "rows", F32), int(row0), LD, D, _chk(offsets, "offsets", I64),
+              _chk(ids, "ids", I64), B, _chk(out, "out", F32, (B, LD)), _stream())
+
+
+def pool_rows_bwd(d_rows_f, g_bias, g_lin, D, offsets, ids, row0, d_table, d_bias, d_lin):
+    """d_rows_f: [B, D] view (row stride may be larger) of the pooled rows' gradient."""
+    B = offsets.shape[0] - 1
+    if d_rows_f.stride(1) != 1:
+        raise ValueError("pool_rows_bwd: d_rows_f must be unit-stride along D")
+    _lib.call("rm_pool_rows_bwd", d_rows_f.data_ptr(), d_rows_f.stride(0),
+              _chk(g_bias, "g_bias", F32, (B,), allow_none=True),
+              _chk(g_lin, "g_lin", F32, (B,), allow_none=True), D, _chk(offsets, "offsets", I64),
+              _chk(ids, "ids", I64), B, int(row0), _chk(d_table, "d_table", F32),
+              _chk(d_bias, "d_bias", F32, allow_none=True), _chk(d_lin, "d_lin", F32, allow_none=True),
+              _stream())

@@ -55,7 +55,8 @@ class DeepModel(BaseEstimator, TransformerMixin):
         fd.check_supported()
         spec = eng.FeatureSpec([f.name for f in fd.embedding_feats],
                                [f.feat_size for f in fd.embedding_feats],
-                               [f.name for f in fd.dense_feats])
+                               [f.name for f in fd.dense_feats],
+                               [f.name for f in fd.multi_val_csv_feats])
         hp = dict(self.hparams)
         hp["strict_reference"] = self.strict_reference
         e = eng.ENGINES[self.model](spec, hp["embedding_size"], hp, task=self.task, device=self.device)
@@ -64,7 +65,7 @@ class DeepModel(BaseEstimator, TransformerMixin):
         self._opt = Optimizer(hp.get("optimizer", "adam"), hp.get("learning_rate", 1e-3))
         # row-wise sparse step for the table when nothing forces a dense gradient
         no_l2 = not hp.get("embedding_l2_reg", 0.0) and not hp.get("linear_l2_reg", 0.0)
-        want = hp.get("sparse_optimizer", e.rows.numel() > (1 << 24))
+        want = hp.get("sparse_optimizer", e.rows.numel() > (1 << 24)) and not spec.multi_names
         self._sparse_opt = None
         if want and no_l2 and hp.get("optimizer", "adam") in ("adam", "adagrad", "gd", "sgd"):
             self._sparse_opt = SparseTableOptimizer(e, hp.get("optimizer", "adam"),
@@ -85,13 +86,25 @@ class DeepModel(BaseEstimator, TransformerMixin):
         if y is not None:
             ya = np.asarray(y)
             yt = torch.from_numpy(ya.astype(np.int64 if self.task == "classification" else np.float32)).to(dev)
+        self._mv_host = inp.mv  # name -> CSR (host) of the multi-valued features of the LAST encoded frame
         return idx, dense, yt
+
+    def _mv_batch(self, mv_host, s, t):
+        """Device (offsets, ids) of examples [s, t) for every multi-valued feature (or None)."""
+        if not mv_host:
+            return None
+        dev = self._build().device
+        out = {}
+        for name, csr in mv_host.items():
+            c = csr.slice(s, t)
+            out[name] = (torch.from_numpy(c.offsets).to(dev), torch.from_numpy(c.ids).to(dev))
+        return out
 
     def _manual_weights(self):
         """Concatenated per-feature manual weights in linear-feature order
         (layers.py:338-345), or None when no feature has any."""
         fd = self.feat_dict
-        feats = fd.sparse_feats + fd.dense_feats  # utils.py:31-36
+        feats = fd.linear_feats  # utils.py:31-36: sparse, multi-valued csv, dense
         if not any(getattr(f, "_weights", None) for f in feats):
             return None
         w = np.concatenate([np.asarray(f.weights, dtype=np.float64).reshape(-1) for f in feats])
@@ -104,7 +117,7 @@ class DeepModel(BaseEstimator, TransformerMixin):
         end = min(start + batch_size, len(y))
         return X[start:end], y[start:end]
 
-    def _predict_encoded(self, idx, dense, training):
+    def _predict_encoded(self, idx, dense, training, mv_host=None):
         e = self._build()
         n = idx.shape[0]
         out = np.empty((n,), dtype=np.float32)
@@ -116,13 +129,13 @@ class DeepModel(BaseEstimator, TransformerMixin):
                 continue
             masks = self._dropout_masks(t - s) if training else None
             _, pred = e.forward(idx[s:t].contiguous(), dense[s:t].contiguous(), training=training,
-                                masks=masks, manual_weights=mw)
+                                masks=masks, manual_weights=mw, mv=self._mv_batch(mv_host, s, t))
             out[s:t] = pred.cpu().numpy()
         return out
 
     def predict(self, X, training=False, batch_number_to_show_progress=50):
         idx, dense, _ = self._encode(X)
-        return self._predict_encoded(idx, dense, training)
+        return self._predict_encoded(idx, dense, training, self._mv_host)
 
     def evaluate(self, X, y, training=False, batch_number_to_show_progress=50):
         pred = self.predict(X, training, batch_number_to_show_progress)
@@ -150,13 +163,13 @@ class DeepModel(BaseEstimator, TransformerMixin):
 
     def fit_on_batch(self, X, y):
         idx, dense, yt = self._encode(X, y)
-        return self._fit_encoded(idx, dense, yt)
+        return self._fit_encoded(idx, dense, yt, self._mv_batch(self._mv_host, 0, idx.shape[0]))
 
-    def _fit_encoded(self, idx, dense, yt):
+    def _fit_encoded(self, idx, dense, yt, mv=None):
         e = self._build()
         if idx.shape[0] == 0:
             return None
-        loss = e.fwd_bwd(idx, dense, yt, masks=self._dropout_masks(idx.shape[0]))
+        loss = e.fwd_bwd(idx, dense, yt, masks=self._dropout_masks(idx.shape[0]), mv=mv)
         if self.strict_reference:
             self._opt.reset()  # a NEW optimizer every batch (xDeepFM.py:121-126)
         fm_masked = getattr(e, "d_bias", None) is not None  # FM bias dropout: per-occurrence grads
@@ -169,10 +182,12 @@ class DeepModel(BaseEstimator, TransformerMixin):
 
     def _eval_at_epoch(self, enc_train, y_train, enc_valid=None, y_valid=None, start_time=None, epoch=0):
         training = bool(self.strict_reference)  # DeepModel.py:103-111 evaluates with training=True
-        tr = [m(y_train, self._predict_encoded(enc_train[0], enc_train[1], training)) for m in self.metrics]
+        ptr = self._predict_encoded(enc_train[0], enc_train[1], training, enc_train[2])
+        tr = [m(y_train, ptr) for m in self.metrics]
         va = None
         if enc_valid is not None:
-            va = [m(y_valid, self._predict_encoded(enc_valid[0], enc_valid[1], training)) for m in self.metrics]
+            pva = self._predict_encoded(enc_valid[0], enc_valid[1], training, enc_valid[2])
+            va = [m(y_valid, pva) for m in self.metrics]
         log.info("[%d] train-result=%s%s [%.1f s]", epoch, [round(float(r), 4) for r in tr],
                  "" if va is None else ", valid-result=%s" % [round(float(r), 4) for r in va],
                  time() - (start_time or time()))
@@ -183,12 +198,13 @@ class DeepModel(BaseEstimator, TransformerMixin):
             batch_number_to_show_progress=50):
         assert X_train is not None or y_train is not None  # DeepModel.py:153
         y_train = np.asarray(y_train)
-        idx, dense, yt = self._encode(X_train, y_train)
         enc_valid = None
         if X_valid is not None and y_valid is not None:
             vi, vd, _ = self._encode(X_valid)
-            enc_valid = (vi, vd)
-        eval_results = self._eval_at_epoch((idx, dense), y_train, enc_valid, y_valid, time())
+            enc_valid = (vi, vd, self._mv_host)
+        idx, dense, yt = self._encode(X_train, y_train)
+        mv_host = self._mv_host
+        eval_results = self._eval_at_epoch((idx, dense, mv_host), y_train, enc_valid, y_valid, time())
         n = len(y_train)
         for epoch in range(1, self.epoch + 1):
             start = time()
@@ -200,15 +216,17 @@ class DeepModel(BaseEstimator, TransformerMixin):
             pt = torch.from_numpy(perm).to(idx.device)
             idx, dense, yt = idx[pt], dense[pt], yt[pt]
             y_train = y_train[perm]
+            mv_host = {k: c.take(perm) for k, c in mv_host.items()} if mv_host else mv_host
             total_batch = n // self.batch_size + 1  # DeepModel.py:188
             for i in range(total_batch):
                 s, t = i * self.batch_size, min((i + 1) * self.batch_size, n)
                 if t <= s:
                     continue  # the reference's trailing empty batch
-                self._fit_encoded(idx[s:t].contiguous(), dense[s:t].contiguous(), yt[s:t].contiguous())
+                self._fit_encoded(idx[s:t].contiguous(), dense[s:t].contiguous(), yt[s:t].contiguous(),
+                                  self._mv_batch(mv_host, s, t))
                 if i % batch_number_to_show_progress == 0:
                     log.info(f"Fit: {(i + 1)}/{total_batch} has been completed")
-            eval_results = self._eval_at_epoch((idx, dense), y_train, enc_valid, y_valid, start, epoch)
+            eval_results = self._eval_at_epoch((idx, dense, mv_host), y_train, enc_valid, y_valid, start, epoch)
             if epoch_callback:
                 epoch_callback(model=self, eval_results=eval_results, df_all=X_train[:1])
         return None  # the reference's fit returns None

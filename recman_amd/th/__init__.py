@@ -5,9 +5,10 @@ fit()/predict()/evaluate() signatures as recman/tf/core."""
 from .DCN import DCN
 from .DeepFM import DeepFM
 from .DeepModel import DeepModel
-from .inputs import DataInputs, DenseFeat, FeatureDictionary, ResilientLabelEncoder, SparseFeat
+from .inputs import (DataInputs, DenseFeat, FeatureDictionary, MultiValCsvFeat, ResilientLabelEncoder,
+                     SparseFeat)
 from .xDeepFM import xDeepFM
 from . import hparams
 
 __all__ = ["DCN", "DeepFM", "DeepModel", "xDeepFM", "DataInputs", "DenseFeat", "FeatureDictionary",
-           "ResilientLabelEncoder", "SparseFeat", "hparams"]
+           "MultiValCsvFeat", "ResilientLabelEncoder", "SparseFeat", "hparams"]

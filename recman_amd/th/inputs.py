@@ -152,6 +152,88 @@ class DenseFeat:
         return f"DenseFeat({self.name}, {self.feat_size})"
 
 
+class CSR:
+    """Ragged tag-id lists of a multi-valued feature: example b owns ids[offsets[b]:offsets[b+1]]."""
+
+    def __init__(self, offsets, ids):
+        self.offsets = np.asarray(offsets, dtype=np.int64)
+        self.ids = np.asarray(ids, dtype=np.int64)
+
+    @classmethod
+    def from_lists(cls, lists):
+        n = np.fromiter((len(x) for x in lists), dtype=np.int64, count=len(lists))
+        offsets = np.concatenate(([0], np.cumsum(n)))
+        ids = np.concatenate(lists) if len(lists) and offsets[-1] else np.zeros(0, np.int64)
+        return cls(offsets, ids)
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def slice(self, s, t):
+        o = self.offsets[s: t + 1]
+        return CSR(o - o[0], self.ids[o[0]: o[-1]])
+
+    def take(self, perm):
+        n = self.offsets[1:] - self.offsets[:-1]
+        starts = self.offsets[:-1][perm]
+        lens = n[perm]
+        offsets = np.concatenate(([0], np.cumsum(lens)))
+        pos = np.repeat(starts - offsets[:-1], lens) + np.arange(offsets[-1])
+        return CSR(offsets, self.ids[pos])
+
+
+class MultiValCsvFeat:
+    """inputs.py:380-425: a '|'-separated tag list per example ("a|b|d"); tag -> 1-based id
+    (tag_hash_table, :389), unknown tags -> 0; feat_size = len(tags) + 1.  Looked up with the
+    sqrtn combiner (layers.py:144-169); the linear term sees its multi-hot counts with slot 0
+    zeroed (utils.py:86-108)."""
+
+    def __init__(self, name, tags=(), weights=None, dtype=None, description=None):
+        self.name = name
+        self.dtype = dtype
+        self.description = description
+        self.tags = tags
+        self.tag_hash_table = dict((tag, i + 1) for i, tag in enumerate(self.tags))
+        self.feat_size = len(self.tags) + 1
+        self._weights = weights
+        self._weights_cache = None
+
+    def get_shape(self, for_tf=True):
+        return None if for_tf else -1, 1
+
+    def initialize(self, X):
+        pass
+
+    def __call__(self, x, training=True):
+        return np.array(x).reshape(-1, 1)  # the reference hands the raw strings to the graph
+
+    def encode(self, x):
+        """-> CSR of tag ids; python str.split semantics (as tf.strings.split with a separator):
+        the empty string is ONE empty token, which is unknown -> id 0."""
+        table = self.tag_hash_table
+        return CSR.from_lists([np.fromiter((table.get(t, 0) for t in str(v).split("|")), dtype=np.int64)
+                               for v in np.asarray(x).reshape(-1)])
+
+    def set_weights(self, val):
+        self._weights = val
+        self._weights_cache = None
+
+    @property
+    def weights(self):
+        if self._weights:
+            if self._weights_cache is None:
+                w = np.zeros((self.feat_size,))
+                for tag, weight in self._weights.items():
+                    if tag in self.tag_hash_table:
+                        w[self.tag_hash_table[tag]] = weight
+                self._weights_cache = w
+            return self._weights_cache
+        return np.zeros((self.feat_size,))
+
+    def __repr__(self):
+        return f"MultiValCsvFeat({self.name}, {len(self.tags)})"
+
+
 class FeatureDictionary(OrderedDict):
     """inputs.py:8-43.  Insertion order defines the field axis of E (and therefore the
     row order of the CIN filters): embedding_feats are the non-dense features in order."""
@@ -168,16 +250,25 @@ class FeatureDictionary(OrderedDict):
     def dense_feats(self):
         return [f for f in self.values() if isinstance(f, DenseFeat)]
 
+    @property
+    def multi_val_csv_feats(self):
+        return [f for f in self.values() if isinstance(f, MultiValCsvFeat)]
+
+    @property
+    def linear_feats(self):
+        """get_linear_features (utils.py:27-36): sparse, then multi-valued csv, then dense."""
+        return self.sparse_feats + self.multi_val_csv_feats + self.dense_feats
+
     def initialize(self, X):
         for feat in self.values():
             feat.initialize(X[feat.name])
 
     def check_supported(self):
-        bad = [f for f in self.values() if not isinstance(f, (SparseFeat, DenseFeat))]
+        bad = [f for f in self.values() if not isinstance(f, (SparseFeat, DenseFeat, MultiValCsvFeat))]
         if bad:
             raise NotImplementedError(
-                f"features {[f.name for f in bad]}: only SparseFeat and DenseFeat are on the HIP "
-                "path (multi-valued / value-weighted features are SURVEY.md section 8f items)")
+                f"features {[f.name for f in bad]}: SparseFeat, DenseFeat and MultiValCsvFeat are on "
+                "the HIP path (value-weighted / hashed multi-valued features are SURVEY.md 8f items)")
 
 
 class DataInputs(dict):
@@ -192,8 +283,10 @@ class DataInputs(dict):
         sparse = feat_dict.embedding_feats
         dense = feat_dict.dense_feats
         n = len(X)
-        self.idx = (np.concatenate([self[f.name] for f in sparse], axis=1) if sparse
-                    else np.zeros((n, 0), np.int64))
+        # multi-valued features: tag ids as CSR; their idx column is a placeholder
+        self.mv = {f.name: f.encode(X[f.name]) for f in sparse if isinstance(f, MultiValCsvFeat)}
+        cols = [np.zeros((n, 1), np.int64) if f.name in self.mv else self[f.name] for f in sparse]
+        self.idx = np.concatenate(cols, axis=1) if sparse else np.zeros((n, 0), np.int64)
         self.dense = (np.concatenate([self[f.name] for f in dense], axis=1).astype(np.float32)
                       if dense else np.zeros((n, 0), np.float32))
         return self

@@ -18,7 +18,7 @@ from sklearn.preprocessing import MinMaxScaler  # noqa: E402
 
 from oracle import inputs_ref as R  # noqa: E402
 
-df, _, _ = get_data("/root/reference/data")
+df, _, _domains = get_data("/root/reference/data")
 df = df.iloc[:1024].reset_index(drop=True)
 out = {}
 sparse = ["user_id", "item_id", "gender", "occupation", "zip"]
@@ -34,6 +34,8 @@ for c in dense:
     out["raw_" + c] = df[c].values
     sc = R.dense_feat_fit(df[c], MinMaxScaler())  # recman/examples/utils.py:57-66
     out["ref_dense_" + c] = R.dense_feat_encode(sc, df[c]).reshape(-1)
+out["raw_genres"] = df["genres"].values.astype(str)  # "Action|Comedy" strings from the reference loader
+out["genre_tags"] = np.array(_domains["genres"]).astype(str)
 out["label"] = (df["rating"].values >= 4).astype(np.int64)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ml100k_slice.npz"), **out)
 print({k: (v.shape, v.dtype) for k, v in out.items()})

@@ -157,3 +157,51 @@ def test_training_with_dropout_runs_and_learns(hip_lib):
     m.fit(df, df["label"].values)
     after = log_loss(df["label"].values, m.predict(df).astype(np.float64))
     assert after < before
+
+
+def test_ml100k_full_feature_set_with_genres(hip_lib):
+    """The reference's own ml-100k feature builder (recman/examples/utils.py:29-75): 5 sparse,
+    2 dense and the multi-valued `genres` - fit/predict against the oracle training loop."""
+    import recman_amd.th as th
+
+    df = ml_frame()
+    df["genres"] = GOLD["raw_genres"].astype(object)
+    fd = ml_features(df)
+    fd["genres"] = th.MultiValCsvFeat(name="genres", tags=tuple(GOLD["genre_tags"].tolist()))
+    m = th.DeepFM(fd, embedding_size=8, deep_dropout=(1, 1, 1), learning_rate=0.01, epoch=1,
+                  batch_size=256, random_seed=2019)
+    e = m._build()
+    assert e.spec.multi_names == ["genres"] and e.F == 6
+    p0 = {k: v.cpu() for k, v in e.state_dict().items()}
+    spec = T.Spec(e.spec.sparse_names, e.spec.feat_sizes, e.spec.dense_names, e.spec.multi_names)
+    inp = th.DataInputs().load(fd, df, df["label"].values)
+    idx, dense, y = torch.from_numpy(inp.idx), torch.from_numpy(inp.dense), torch.from_numpy(inp.y)
+    csr = inp.mv["genres"]
+    mv = {"genres": (torch.from_numpy(csr.offsets), torch.from_numpy(csr.ids))}
+    hp = dict(m.hparams)
+    want0 = T.prediction(T.deepfm_logit(p0, spec, idx, dense, hp, training=False, mv=mv)).numpy()
+    pred0 = m.predict(df)
+    assert np.abs(pred0 - want0).max() < 1e-6
+    m.fit(df, df["label"].values, random_seed_for_mini_batch=False)
+    # oracle loop: same shuffle, same batches, Keras Adam
+    from sklearn.utils import check_random_state
+
+    p, state, t = {k: v.clone() for k, v in p0.items()}, {}, 0
+    perm = np.arange(1024)
+    check_random_state(2019).shuffle(perm)
+    idx2, dense2, y2, csr2 = idx[perm], dense[perm], y[perm], csr.take(perm)
+    for s in range(0, 1024, 256):
+        c = csr2.slice(s, s + 256)
+        mvb = {"genres": (torch.from_numpy(c.offsets), torch.from_numpy(c.ids))}
+        _, _, _, g = T.fwd_bwd("deepfm", p, spec, idx2[s:s + 256], dense2[s:s + 256], y2[s:s + 256], hp, mv=mvb)
+        t += 1
+        keras_adam_cpu(p, g, state, t, 0.01)
+    want1 = T.prediction(T.deepfm_logit(p, spec, idx, dense, hp, training=False, mv=mv)).numpy()
+    pred1 = m.predict(df)
+    assert np.abs(pred1 - want1).max() < 2e-4, np.abs(pred1 - want1).max()
+    # manual tag weights at predict time (the reference example sets them on the multi-valued feature)
+    fd["genres"].set_weights({"Comedy": -5})
+    boosted = m.predict(df)
+    has = np.array(["Comedy" in s.split("|") for s in df["genres"].values])
+    z0, z1 = np.log(pred1 / (1 - pred1)), np.log(boosted / (1 - boosted))
+    assert np.allclose((z1 - z0)[has], -5, atol=2e-3) and np.allclose((z1 - z0)[~has], 0, atol=2e-3)

@@ -105,3 +105,32 @@ def test_manual_weights_vector():
     assert f.weights.tolist() == [0, -5, 0, 0]
     f.set_weights({"Rest": 2.0, "unseen": 9.0})
     assert f.weights.tolist() == [9.0, 0, 2.0, 0]  # unseen keys land on the null slot, as in the reference
+
+
+def test_multi_val_csv_feat_encoding_and_weights():
+    from recman_amd.th.inputs import CSR, MultiValCsvFeat
+
+    f = MultiValCsvFeat("h", tags=("a", "b", "c", "d"))
+    assert f.feat_size == 5 and f.tag_hash_table == {"a": 1, "b": 2, "c": 3, "d": 4}  # inputs.py:389-391
+    c = f.encode(np.array(["a|b|d", "b|c", "", "zz|a"]))
+    assert c.offsets.tolist() == [0, 3, 5, 6, 8]
+    assert c.ids.tolist() == [1, 2, 4, 2, 3, 0, 0, 1]  # unknown tag and the empty string -> 0
+    assert f(np.array(["a|b", "c"])).shape == (2, 1)   # the reference passes the raw strings on
+    f.set_weights({"b": -5, "nope": 3})
+    assert f.weights.tolist() == [0, 0, -5, 0, 0]
+    t = c.take(np.array([3, 0, 2, 1]))
+    assert t.offsets.tolist() == [0, 2, 5, 6, 8] and t.ids.tolist() == [0, 1, 1, 2, 4, 0, 2, 3]
+    s = c.slice(1, 3)
+    assert s.offsets.tolist() == [0, 2, 3] and s.ids.tolist() == [2, 3, 0]
+
+
+def test_linear_feature_order_with_multi_val():
+    from recman_amd.th.inputs import MultiValCsvFeat
+
+    fd = FeatureDictionary()
+    fd["s0"] = SparseFeat("s0", 2)
+    fd["mv"] = MultiValCsvFeat("mv", tags=("x", "y"))
+    fd["d0"] = DenseFeat("d0")
+    fd["s1"] = SparseFeat("s1", 3)
+    assert [f.name for f in fd.embedding_feats] == ["s0", "mv", "s1"]      # field axis of E
+    assert [f.name for f in fd.linear_feats] == ["s0", "s1", "mv", "d0"]    # utils.py:31-36

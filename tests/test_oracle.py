@@ -136,3 +136,23 @@ def test_keras_bce_clip_semantics():
     e = 1e-7
     want = np.mean([-np.log(e + e), -np.log(1 - (1 - e) + e), -np.log(0.5 + e), -np.log(1 - e + e)])
     assert abs(got - want) < 1e-12
+
+
+def test_multi_val_sqrtn_pooling_and_multi_hot_linear():
+    # layers.py:150-156 (combiner="sqrtn") and utils.py:86-108 (multi-hot, slot 0 zeroed)
+    spec = T.Spec(["a", "g", "b"], [5, 4, 6], ["d0"], multi_names=["g"])
+    assert spec.lin_offsets == ([0, 11, 5], 15)
+    p = T.make_params(spec, "deepfm", 4, hidden=(4,), scale=0.3, dtype=torch.float64)
+    idx = torch.tensor([[1, 0, 2], [3, 0, 5], [0, 0, 0]])
+    dense = torch.randn(3, 1, dtype=torch.float64)
+    mv = {"g": (torch.tensor([0, 2, 2, 5]), torch.tensor([1, 3, 0, 2, 2]))}
+    E, bias = T.feat_embedding_layer(p, spec, idx, True, mv)
+    t, bt = p["g_feat_embed"], p["g_feat_bias"]
+    assert torch.allclose(E[0, 1], (t[1] + t[3]) / 2 ** 0.5)
+    assert float(E[1, 1].abs().sum()) == 0.0                      # no tags -> zeros
+    assert torch.allclose(E[2, 1], (t[0] + 2 * t[2]) / 3 ** 0.5)  # unknown tag looks up row 0
+    assert torch.allclose(bias[2, 1], (bt[0] + 2 * bt[2]) / 3 ** 0.5)
+    lin = T.linear_layer(p, spec, idx, dense, mv=mv)
+    W = p["linear_w"]
+    want2 = p["linear_w0"] + W[0 + 0] + W[5 + 0] + 2 * W[11 + 2] + dense[2] @ W[15:16]  # id 0 contributes nothing
+    assert torch.allclose(lin[2], want2.reshape(-1))
