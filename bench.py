@@ -223,14 +223,21 @@ def main():
 
     # ---- roofline of the dominant hand-written kernel, HIP events on its stream ----
     roof = None if sharded else engine.roofline_probe(idx, dense, y, iters=max(10, min(a.steps, 50)))
+    if roof is not None and a.workload == "deepfm" and B == 65536 and V == 1_000_001 and a.zipf == 0:
+        # HBM bytes per launch of the gather kernel from rocprofv3 PMC passes of this same command
+        # (FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes on gfx950, + WRITE_SIZE):
+        # profiles/r01_p5_deepfm_fused.md
+        roof["traffic"] = 375.0e6
+        roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, profiles/r01_p5_deepfm_fused.md"
 
     out = {
-        "metric": "examples/sec fwd+bwd, Criteo-shape batch %d" % B,
+        "metric": "examples/sec fwd+bwd, Criteo-shape batch 65536; % HBM and MFMA roofline",
         "value": round(value, 1), "unit": "examples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": a.workload, "model": w["model"], "per_gpu_batch": B,
-                   "global_batch": B * world, "sparse_fields": w["F"], "rows_per_field": V,
+        "config": {"workload": f"{a.workload} (BASELINE configs[{1 + ['deepfm', 'xdeepfm', 'dcn'].index(a.workload)}])",
+                   "batch_per_gpu": B, "batch_all_gpus": B * world, "sparse_fields": w["F"],
+                   "rows_per_field": V,
                    "dense_fields": w["Dn"], "emb_dim": w["D"], "hp": {k: v for k, v in w["hp"].items()},
                    "indices": "uniform" if a.zipf == 0 else f"zipf({a.zipf})",
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
