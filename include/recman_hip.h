@@ -108,7 +108,7 @@ int rm_scatter_add_rows(const int64_t *idx, const int64_t *field_off, const floa
 /* Weighted column sums: d_w_dense[j] = sum_b g[b]*dense[b,j] (j < Dn <= 1023),
  * d_w0 = sum_b g[b].  The dense part of the linear-layer backward, and the gradient of
  * every [*,1] output projection (d cin_w = pooled^T g, d dnn_w = a^T g).  Deterministic
- * two-stage reduction; workspace >= 256*(Dn+1) floats; either output may be NULL. */
+ * two-stage reduction; workspace >= 262144 floats; either output may be NULL. */
 int rm_linear_dense_bwd(const float *g, const float *dense, int64_t B, int Dn,
                         float *d_w_dense, float *d_w0, float *workspace, rm_stream_t stream);
 
@@ -157,6 +157,12 @@ int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const i
                const float *const *h, const float *fm_sum, int D, float *d_rows,
                float *const *dh, float *const *dW, float *const *db, float *d_w_out,
                float *d_w0_out, float *workspace, rm_stream_t stream);
+
+/* Epilogues of the library-GEMM DNN path (wide hidden layers, layers.py:593-601):
+ * rm_bias_act: x[b,j] = act(x[b,j] + bias[j]) in place (bias may be NULL);
+ * rm_act_bwd:  da[b,j] *= act'(a[b,j]) in place, act' read off the post-activation a. */
+int rm_bias_act(float *x, const float *bias, int64_t B, int N, int act, rm_stream_t stream);
+int rm_act_bwd(float *da, const float *a, int64_t B, int N, int act, rm_stream_t stream);
 
 /* out[b] = sum_j X[b,j]*w[j] + w0[0]: the [*,1] output projections (dnn_w/dnn_w0,
  * layers.py:606-609; cin_w/cin_w0, layers.py:757-760).  w0 may be NULL. */

@@ -39,17 +39,30 @@ __device__ __forceinline__ float4 load_x0(const float *__restrict__ xe, const fl
 __device__ __forceinline__ void stage_params(float *sm, const float *__restrict__ w,
                                              const float *__restrict__ b,
                                              const float *__restrict__ w_out, int L, int d, int P) {
-  // sm layout: w [L][P] | b [L][P] | w_out [P]
-  for (int i = threadIdx.x; i < (2 * L + 1) * P; i += blockDim.x) {
-    const int r = i / P, e = i - r * P;
-    float v = 0.f;
-    if (e < d) v = r < L ? w[r * d + e] : (r < 2 * L ? b[(r - L) * d + e] : w_out[e]);
-    sm[i] = v;
+  // sm layout: w [L][P] | b [L][P] | w_out [P].  All of a thread's global loads are issued
+  // before its first LDS write: a load->store loop serialises one L2 round trip per element
+  // (23 per thread here), which dominated the kernel at 1024 short blocks.
+  constexpr int PER = 8;
+  const int total = (2 * L + 1) * P;
+  for (int base = 0; base < total; base += kBlock * PER) {
+    float v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = base + q * kBlock + threadIdx.x;
+      const int r = i / P, e = i - r * P;
+      v[q] = 0.f;
+      if (i < total && e < d) v[q] = r < L ? w[r * d + e] : (r < 2 * L ? b[(r - L) * d + e] : w_out[e]);
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = base + q * kBlock + threadIdx.x;
+      if (i < total) sm[i] = v[q];
+    }
   }
 }
 
 template <int T>
-__global__ __launch_bounds__(kBlock) void cross_fwd_kernel(
+__global__ __launch_bounds__(kBlock, 3) void cross_fwd_kernel(
     const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn,
     const float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ w_out,
     int L, int64_t B, float *__restrict__ logit, float *__restrict__ s_out) {
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void cross_fwd_kernel(
 }
 
 template <int T>
-__global__ __launch_bounds__(kBlock) void cross_bwd_kernel(
+__global__ __launch_bounds__(kBlock, 3) void cross_bwd_kernel(
     const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn,
     const float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ w_out,
     int L, int64_t B, const float *__restrict__ g, const float *__restrict__ s_in,
@@ -127,37 +140,31 @@ __global__ __launch_bounds__(kBlock) void cross_bwd_kernel(
       dl[t] = make_float4(gb * wo.x, gb * wo.y, gb * wo.z, gb * wo.w);  // delta_L = g * w_out
       acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // c_l = 1 + sum_{j<l} s_j  (x_l = c_l x0 + sum_{j<l} b_j)
-    float s[kMaxL], c[kMaxL + 1];
-    c[0] = 1.f;
-#pragma unroll
-    for (int l = 0; l < kMaxL; ++l) {
-      s[l] = l < L ? s_in[bb * L + l] : 0.f;
-      c[l + 1] = c[l] + s[l];
-    }
+    // c_l = 1 + sum_{j<l} s_j  (x_l = c_l x0 + sum_{j<l} b_j).  The layer loop is dynamic and
+    // the prefix sums are rebuilt from the (L1-resident) s row each time: unrolling kMaxL
+    // layers cost 256 VGPRs = 1 wave per SIMD.
+    const float *srow = s_in + bb * L;
     float cL = 1.f;
+    for (int j = 0; j < L; ++j) cL += srow[j];
+    for (int l = L - 1; l >= 0; --l) {
+      const float sl = srow[l];
+      float cl = 1.f;
+      for (int j = 0; j < l; ++j) cl += srow[j];
+      float part = 0.f;
 #pragma unroll
-    for (int l = 0; l < kMaxL; ++l)
-      if (l == L - 1) cL = c[l + 1];
+      for (int t = 0; t < T; ++t) part += dot4(dl[t], x0[t]);
+      const float tl = rm_group_sum<16>(part);  // t_l = delta_{l+1} . x0
+      if (valid && sub == 0) {
+        coef[bb * ncoef + l] = tl * cl;
+        coef[bb * ncoef + L + 1 + l] = tl;
+      }
 #pragma unroll
-    for (int l = kMaxL - 1; l >= 0; --l) {
-      if (l < L) {
-        float part = 0.f;
-#pragma unroll
-        for (int t = 0; t < T; ++t) part += dot4(dl[t], x0[t]);
-        const float tl = rm_group_sum<16>(part);  // t_l = delta_{l+1} . x0
-        if (valid && sub == 0) {
-          coef[bb * ncoef + l] = tl * c[l];
-          coef[bb * ncoef + L + 1 + l] = tl;
-        }
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const float4 wl = sw[l * (P / 4) + sub + 16 * t];
-          acc[t].x += s[l] * dl[t].x; acc[t].y += s[l] * dl[t].y;
-          acc[t].z += s[l] * dl[t].z; acc[t].w += s[l] * dl[t].w;
-          dl[t].x += tl * wl.x; dl[t].y += tl * wl.y;
-          dl[t].z += tl * wl.z; dl[t].w += tl * wl.w;
-        }
+      for (int t = 0; t < T; ++t) {
+        const float4 wl = sw[l * (P / 4) + sub + 16 * t];
+        acc[t].x += sl * dl[t].x; acc[t].y += sl * dl[t].y;
+        acc[t].z += sl * dl[t].z; acc[t].w += sl * dl[t].w;
+        dl[t].x += tl * wl.x; dl[t].y += tl * wl.y;
+        dl[t].z += tl * wl.z; dl[t].w += tl * wl.w;
       }
     }
     if (valid && sub == 0) {
@@ -252,7 +259,7 @@ extern "C" int rm_cross_fwd(const float *xe, const float *xd, int FD, int Dn, co
   RM_REQUIRE(logit, "rm_cross_fwd: logit must not be NULL");
   const int T = pick_T(FD + Dn);
   const size_t smem = (size_t)(2 * L + 1) * 64 * T * sizeof(float);
-  dim3 grid(rm_grid_cap((B + 15) / 16, 256 * 4));
+  dim3 grid(rm_grid_cap((B + 15) / 16, 256 * 3));  // persistent: the blocks grid-stride over examples
   hipStream_t st = (hipStream_t)stream;
   RM_CROSS_DISPATCH(T, cross_fwd_kernel, xe, xd, FD, Dn, w, b, w_out, L, B, logit, s_out)
   RM_CHECK_LAUNCH("rm_cross_fwd");
@@ -271,7 +278,7 @@ extern "C" int rm_cross_bwd(const float *xe, const float *xd, int FD, int Dn, co
   RM_REQUIRE(!dx_in_e || rm_aligned16(dx_in_e), "rm_cross_bwd: dx_in_e unaligned");
   const int T = pick_T(FD + Dn);
   const size_t smem = (size_t)(2 * L + 1) * 64 * T * sizeof(float);
-  dim3 grid(rm_grid_cap((B + 15) / 16, 256 * 4));
+  dim3 grid(rm_grid_cap((B + 15) / 16, 256 * 3));
   hipStream_t st = (hipStream_t)stream;
   RM_CROSS_DISPATCH(T, cross_bwd_kernel, xe, xd, FD, Dn, w, b, w_out, L, B, g, s, dx_in_e, dx_in_d,
                     d_xe, d_xd, coef)

@@ -285,6 +285,32 @@ __global__ __launch_bounds__(kBlock) void colsum_w_stage1(const float *__restric
   }
 }
 
+// wide inputs (P % 4 == 0, P >= 64): float4 column groups, 128 rows per block
+__global__ __launch_bounds__(kBlock) void colsum_w_wide_stage1(const float *__restrict__ g,
+                                                               const float *__restrict__ X, int64_t B,
+                                                               int P, int64_t rows_per_block,
+                                                               float *__restrict__ partial) {
+  const int P4 = P / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
+  float *out = partial + (int64_t)blockIdx.x * (P + 1);
+  for (int c4 = threadIdx.x; c4 < P4; c4 += kBlock) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int64_t r = r0; r < r1; ++r) {
+      const float gv = g[r];
+      const float4 x = *reinterpret_cast<const float4 *>(X + r * P + 4 * c4);
+      acc.x += gv * x.x; acc.y += gv * x.y; acc.z += gv * x.z; acc.w += gv * x.w;
+    }
+    out[4 * c4 + 0] = acc.x; out[4 * c4 + 1] = acc.y; out[4 * c4 + 2] = acc.z; out[4 * c4 + 3] = acc.w;
+  }
+  if (threadIdx.x == kBlock - 1) {
+    float a = 0.f;
+    for (int64_t r = r0; r < r1; ++r) a += g[r];
+    out[P] = a;
+  }
+}
+
 __global__ void colsum_w_stage2(const float *__restrict__ partial, int nblk, int P,
                                 float *__restrict__ out, float *__restrict__ out0) {
   const int j = blockIdx.x;  // column, P = the sum of g
@@ -483,10 +509,20 @@ extern "C" int rm_linear_dense_bwd(const float *g, const float *dense, int64_t B
   RM_REQUIRE(g && workspace && (Dn == 0 || dense), "rm_linear_dense_bwd: NULL argument");
   int Pp = 1;
   while (Pp < Dn + 1 && Pp < kBlock) Pp <<= 1;
-  const int nblk = rm_grid_cap((B + 255) / 256, 256);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_w_stage1, dim3(nblk), dim3(kBlock), kBlock * sizeof(float), st, g,
-                     dense, B, Dn, Pp, workspace);
+  int nblk;
+  if (Dn >= 64 && Dn % 4 == 0 && rm_aligned16(dense)) {
+    // each thread streams a float4 column group over the block's rows: many short blocks
+    const int64_t cap = 256 * 1024 / (Dn + 1);  // partial rows that fit the 256K-float workspace
+    nblk = rm_grid_cap((B + 63) / 64, (int)(cap < 2048 ? cap : 2048));
+    const int64_t rpb = (B + nblk - 1) / nblk;
+    hipLaunchKernelGGL(colsum_w_wide_stage1, dim3(nblk), dim3(kBlock), 0, st, g, dense, B, Dn, rpb,
+                       workspace);
+  } else {
+    nblk = rm_grid_cap((B + 255) / 256, 256);
+    hipLaunchKernelGGL(colsum_w_stage1, dim3(nblk), dim3(kBlock), kBlock * sizeof(float), st, g,
+                       dense, B, Dn, Pp, workspace);
+  }
   hipLaunchKernelGGL(colsum_w_stage2, dim3(Dn + 1), dim3(64), 0, st, workspace, nblk, Dn,
                      d_w_dense, d_w0);
   RM_CHECK_LAUNCH("rm_linear_dense_bwd");

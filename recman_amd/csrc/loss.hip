@@ -91,7 +91,68 @@ __global__ __launch_bounds__(kBlock) void rowdot_kernel(const float *__restrict_
   }
 }
 
+__device__ __forceinline__ float act_f(float v, int act) {
+  if (act == RM_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ float act_g(float o, int act) {
+  if (act == RM_ACT_RELU) return o > 0.f ? 1.f : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return o > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+
+// in place: x[b, j] = act(x[b, j] + bias[j])      (the DNN layer epilogue, layers.py:593-601)
+__global__ __launch_bounds__(kBlock) void bias_act_kernel(float4 *__restrict__ x,
+                                                          const float *__restrict__ bias, int64_t n4,
+                                                          int N4, int act) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += stride) {
+    const int j4 = (int)(t % N4);
+    float4 v = x[t];
+    const float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * j4) : make_float4(0, 0, 0, 0);
+    v.x = act_f(v.x + b.x, act); v.y = act_f(v.y + b.y, act);
+    v.z = act_f(v.z + b.z, act); v.w = act_f(v.w + b.w, act);
+    x[t] = v;
+  }
+}
+
+// in place: da[b, j] *= act'(a[b, j])  (act' read off the post-activation value)
+__global__ __launch_bounds__(kBlock) void act_bwd_kernel(float4 *__restrict__ da,
+                                                         const float4 *__restrict__ a, int64_t n4,
+                                                         int act) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += stride) {
+    float4 d = da[t];
+    const float4 o = a[t];
+    d.x *= act_g(o.x, act); d.y *= act_g(o.y, act); d.z *= act_g(o.z, act); d.w *= act_g(o.w, act);
+    da[t] = d;
+  }
+}
+
 }  // namespace
+
+extern "C" int rm_bias_act(float *x, const float *bias, int64_t B, int N, int act, rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && N > 0 && N % 4 == 0, "rm_bias_act: N must be a positive multiple of 4");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(x && rm_aligned16(x) && (!bias || rm_aligned16(bias)), "rm_bias_act: NULL or unaligned");
+  const int64_t n4 = B * (N / 4);
+  hipLaunchKernelGGL(bias_act_kernel, dim3(rm_grid_cap((n4 + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock),
+                     0, (hipStream_t)stream, (float4 *)x, bias, n4, N / 4, act);
+  RM_CHECK_LAUNCH("rm_bias_act");
+  return RM_OK;
+}
+
+extern "C" int rm_act_bwd(float *da, const float *a, int64_t B, int N, int act, rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && N > 0 && (B * N) % 4 == 0, "rm_act_bwd: B*N must be a multiple of 4");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(da && a && rm_aligned16(da) && rm_aligned16(a), "rm_act_bwd: NULL or unaligned");
+  const int64_t n4 = B * N / 4;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(rm_grid_cap((n4 + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock),
+                     0, (hipStream_t)stream, (float4 *)da, (const float4 *)a, n4, act);
+  RM_CHECK_LAUNCH("rm_act_bwd");
+  return RM_OK;
+}
 
 extern "C" int rm_rowdot(const float *X, const float *w, const float *w0, int64_t B, int P,
                          float *out, rm_stream_t stream) {

@@ -101,6 +101,7 @@ class MLP:
             grads[nm] = torch.zeros(shape, dtype=F32, device=device)
         self._B = None
         self._ws = None
+        self._ones = None
         # hand-written fused f32-MFMA path for skinny MLPs (csrc/mlp.hip); wider ones
         # (DCN's [400,400]) are library GEMMs
         self.fused_ok = bool(FD % 4 == 0 and ops.mlp_supported(FD, Dn, self.hidden))
@@ -153,13 +154,22 @@ class MLP:
         for i in range(n):
             W, b = p[f"{pre}dnn_layer_{i}_weights"], p[f"{pre}dnn_layer_{i}_bias"]
             a = self.a[i]
+            fuse = a.shape[1] % 4 == 0  # bias + activation in one pass (rm_bias_act)
             if i == 0:
-                torch.addmm(b, xe, W[: self.FD], out=a)
+                if fuse:
+                    torch.mm(xe, W[: self.FD], out=a)
+                else:
+                    torch.addmm(b, xe, W[: self.FD], out=a)
                 if xd is not None and self.Dn:
                     a.addmm_(xd, W[self.FD:])
+            elif fuse:
+                torch.mm(self.a[i - 1], W, out=a)
             else:
                 torch.addmm(b, self.a[i - 1], W, out=a)
-            self._act_(a)
+            if fuse:
+                ops.bias_act_(a, b, self.act)
+            else:
+                self._act_(a)
             if self.keep[i + 1] < 1 and self.masks[i + 1] is not None:
                 a.mul_(self.masks[i + 1] / self.keep[i + 1])
         ops.rowdot(self.a[-1], p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"], self.out.view(B))
@@ -194,14 +204,19 @@ class MLP:
             if self.act != "identity":
                 # act'(pre-activation) from the stored post-activation: same sign, and
                 # dropped positions (a == 0) already have da == 0
-                slope = _ACTS[self.act]
-                if slope:
-                    da.mul_(torch.where(a > 0, 1.0, slope))
+                if (da.numel() % 4) == 0:
+                    ops.act_bwd_(da, a, self.act)
                 else:
-                    da.mul_(a > 0)
+                    slope = _ACTS[self.act]
+                    da.mul_(torch.where(a > 0, 1.0, slope)) if slope else da.mul_(a > 0)
             W = p[f"{pre}dnn_layer_{i}_weights"]
             gW = gr[f"{pre}dnn_layer_{i}_weights"]
-            gr[f"{pre}dnn_layer_{i}_bias"].copy_(da.sum(0))
+            if da.shape[1] <= 1023:
+                if self._ones is None or self._ones.shape[0] != da.shape[0]:
+                    self._ones = torch.ones(da.shape[0], dtype=F32, device=da.device)
+                ops.linear_dense_bwd(self._ones, da, gr[f"{pre}dnn_layer_{i}_bias"], None, self._ws)
+            else:
+                gr[f"{pre}dnn_layer_{i}_bias"].copy_(da.sum(0))
             if i == 0:
                 torch.mm(self.xe.t(), da, out=gW[: self.FD])
                 if self.xd is not None and self.Dn:

@@ -356,3 +356,14 @@ def pool_rows_bwd(d_rows_f, g_bias, g_lin, D, offsets, ids, row0, d_table, d_bia
               _chk(ids, "ids", I64), B, int(row0), _chk(d_table, "d_table", F32),
               _chk(d_bias, "d_bias", F32, allow_none=True), _chk(d_lin, "d_lin", F32, allow_none=True),
               _stream())
+
+
+def bias_act_(x, bias, act):
+    B, N = x.shape
+    _lib.call("rm_bias_act", _chk(x, "x", F32), _chk(bias, "bias", F32, (N,), allow_none=True), B, N,
+              ACT_IDS[act], _stream())
+
+
+def act_bwd_(da, a, act):
+    B, N = da.shape
+    _lib.call("rm_act_bwd", _chk(da, "da", F32), _chk(a, "a", F32, (B, N)), B, N, ACT_IDS[act], _stream())
