@@ -115,6 +115,12 @@ __global__ __launch_bounds__(kBlock) void embed_fwd_kernel(
 // cost as much as the 64-byte row gather itself - the gather is bound by line requests,
 // not bytes).  G = LD/4 lanes own an example; lanes sub < GE = D/4 hold the embedding
 // slices, lane sub == GE holds (bias, lin, -, -), lanes above it issue no load.
+// rows in flight per lane: 13 (= half of Criteo's 26 fields) measured 10 % faster than 8; a
+// field-major lane mapping with 512-byte contiguous E stores measured 1.8x SLOWER (fewer rows
+// in flight, cross-group shuffles) - tools/bench_embed.py
+#ifndef RM_FUSED_UNROLL
+#define RM_FUSED_UNROLL 13
+#endif
 template <int G, int GE, bool MASK>
 __global__ __launch_bounds__(kBlock) void embed_fwd_fused_kernel(
     const int64_t *__restrict__ idx, const float *__restrict__ table,
@@ -141,23 +147,23 @@ __global__ __launch_bounds__(kBlock) void embed_fwd_fused_kernel(
     const int64_t *ip = idx + bb * F;
     float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
     float ss = 0.f, y1 = 0.f, lin = 0.f;
-    for (int f0 = 0; f0 < F; f0 += kUnroll) {
-      int64_t r[kUnroll];
-      float4 v[kUnroll];
+    for (int f0 = 0; f0 < F; f0 += RM_FUSED_UNROLL) {
+      int64_t r[RM_FUSED_UNROLL];
+      float4 v[RM_FUSED_UNROLL];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
+      for (int u = 0; u < RM_FUSED_UNROLL; ++u) {
         const int f = f0 + u < F ? f0 + u : F - 1;
         r[u] = ip[f];
       }
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
+      for (int u = 0; u < RM_FUSED_UNROLL; ++u) {
         const int f = f0 + u < F ? f0 + u : F - 1;
         const int64_t row = field_off[f] + r[u];
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (emb || side) v[u] = *reinterpret_cast<const float4 *>(table + row * LD + sub * 4);
       }
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
+      for (int u = 0; u < RM_FUSED_UNROLL; ++u) {
         const int f = f0 + u;
         if (f < F) {
           if (emb) {

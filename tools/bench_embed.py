@@ -42,5 +42,10 @@ for ld in (20, 32):
     res[f"fused rows ld={ld} ({ld*4} B)"] = timeit(lambda: ops.embed_fwd(idx, t, foff, table_ld=ld, D=D, bias_table=flat[D:], bias_ld=ld, lin_w=flat[D + 1:], lin_ld=ld, lin_off=foff, lin_w_dense=lwd, lin_w0=lw0, dense=dense, E=E, fm_sum=S, fm_logit=fm, lin_logit=lin))
     res[f"fused rows ld={ld}, rows only"] = timeit(lambda: ops.embed_fwd(idx, t, foff, table_ld=ld, D=D, E=E, fm_sum=S))
     del t, flat
+# FUSED ENGINE LAYOUT: ld = 2*D with bias/lin in the row -> embed_fwd_fused_kernel
+t = torch.randn(R, 32, device=dev) * 0.01
+res["engine layout (fused kernel, ld=32)"] = timeit(lambda: ops.embed_fwd(idx, t, foff, table_ld=32, D=D, bias_col=D, lin_col=D + 1, lin_w_dense=lwd, lin_w0=lw0, dense=dense, E=E, fm_sum=S, fm_logit=fm, lin_logit=lin))
+res["engine layout, no E write"] = timeit(lambda: ops.embed_fwd(idx, t, foff, table_ld=32, D=D, bias_col=D, lin_col=D + 1, lin_w_dense=lwd, lin_w0=lw0, dense=dense, fm_sum=S, fm_logit=fm, lin_logit=lin))
+del t
 for k, v in res.items():
     print(f"{k:45s} {v:8.1f} us   {alg / v / 1e3:7.1f} GB/s (config-2 algorithmic bytes)")
