@@ -99,8 +99,11 @@ __device__ __forceinline__ void stage_w0(float *dst, int ld, const float *__rest
 // ---------------------------------------------------------------------------
 // forward: all layers + output projection in one kernel
 // ---------------------------------------------------------------------------
+#ifndef RM_MLP_FWD_WAVES
+#define RM_MLP_FWD_WAVES 8
+#endif
 template <int NL>
-__global__ __launch_bounds__(512) void mlp_fwd_kernel(
+__global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
     const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn, MlpW w,
     const float *__restrict__ w_out, const float *__restrict__ w0_out, int act, int64_t B,
     float *__restrict__ h0, float *__restrict__ h1, float *__restrict__ h2,
@@ -112,19 +115,20 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(
   float *W0t = smem;                         // [32][LDW]: W0t[u][k] = W0[k][u]
   float *WA = W0t + 32 * LDW;                // [NL-1][16][2][32]: W_l[u(s,h)][c]
   float *bs = WA + (NL - 1) * 1024;          // [NL][32] biases, then [32] w_out
-  float *xs_all = bs + (NL + 1) * 32;        // [8 waves][32][kLDX]
+  float *xs_all = bs + (NL + 1) * 32;        // [waves][32][kLDX]
+  constexpr int NW = RM_MLP_FWD_WAVES, NTHR = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
 
-  stage_w0<true, 512>(W0t, LDW, w.W[0], K, Kp, w.H[0], tid);
+  stage_w0<true, 64 * RM_MLP_FWD_WAVES>(W0t, LDW, w.W[0], K, Kp, w.H[0], tid);
 #pragma unroll
   for (int l = 1; l < NL; ++l)
-    for (int t = tid; t < 1024; t += 512) {
+    for (int t = tid; t < 1024; t += NTHR) {
       const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
       const int ku = unit_of(s, hh);
       WA[(l - 1) * 1024 + t] =
           (ku < w.H[l - 1] && cc < w.H[l]) ? w.W[l][ku * w.H[l] + cc] : 0.f;
     }
-  for (int t = tid; t < (NL + 1) * 32; t += 512) {
+  for (int t = tid; t < (NL + 1) * 32; t += NTHR) {
     const int l = t >> 5, u = t & 31;
     float v = 0.f;
     if (l < NL) v = u < w.H[l] ? w.b[l][u] : 0.f;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(
   float *xs = xs_all + wave * 32 * kLDX;
   const int nch = Kp / 64;
   const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
+  for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
     const int64_t ex0 = tile * 32;
     f32x16 acc;
 #pragma unroll
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(256) void mlp_small_grads_stage2(const float *__res
 
 size_t mlp_fwd_smem(int K, int NL) {
   const int Kp = ((K + 63) / 64) * 64;
-  return (size_t)(32 * (Kp + 4) + (NL - 1) * 1024 + (NL + 1) * 32 + 8 * 32 * kLDX) * sizeof(float);
+  return (size_t)(32 * (Kp + 4) + (NL - 1) * 1024 + (NL + 1) * 32 + RM_MLP_FWD_WAVES * 32 * kLDX) * sizeof(float);
 }
 size_t mlp_bwd_smem(int K, int NL) {
   const int Kp = ((K + 63) / 64) * 64;
@@ -567,14 +571,14 @@ extern "C" int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int 
   }
   const size_t smem = mlp_fwd_smem(FD + Dn, NL);
   const int64_t ntiles = (B + 31) / 32;
-  dim3 grid((unsigned)rm_grid_cap((ntiles + 7) / 8, 256));
+  dim3 grid((unsigned)rm_grid_cap((ntiles + RM_MLP_FWD_WAVES - 1) / RM_MLP_FWD_WAVES, 256));
   hipStream_t st = (hipStream_t)stream;
   float *h0 = h_out[0], *h1 = NL > 1 ? h_out[1] : nullptr, *h2 = NL > 2 ? h_out[2] : nullptr;
 #define RM_MLP_FWD(NL_)                                                                        \
   {                                                                                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwd_kernel<NL_>),             \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);          \
-    hipLaunchKernelGGL((mlp_fwd_kernel<NL_>), grid, dim3(512), smem, st, xe, xd, FD, Dn, w,    \
+    hipLaunchKernelGGL((mlp_fwd_kernel<NL_>), grid, dim3(64 * RM_MLP_FWD_WAVES), smem, st, xe, xd, FD, Dn, w, \
                        w_out, w0_out, act, B, h0, h1, h2, logit);                              \
   }
   if (NL == 1) RM_MLP_FWD(1) else if (NL == 2) RM_MLP_FWD(2) else RM_MLP_FWD(3)
