@@ -22,8 +22,30 @@ __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
 
-// loads the float4 slice q of x0 = [xe | xd] for example b (zeros past d)
+// loads the float4 slice q of x0 = [xe | xd] for example b (zeros past d), branch-free:
+// unconditional loads from clamped addresses + selects (a per-lane if/else here makes hipcc
+// serialise the slice loads behind s_waitcnt vmcnt(0))
 __device__ __forceinline__ float4 load_x0(const float *__restrict__ xe, const float *__restrict__ xd,
+                                          int64_t b, int FD, int Dn, int q) {
+  const int e0 = 4 * q;
+  const bool in_e = e0 + 3 < FD;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (FD > 0) v = *reinterpret_cast<const float4 *>(xe + b * FD + (in_e ? e0 : 0));
+  if (__builtin_amdgcn_ballot_w64(!in_e) == 0) return v;  // wave-uniform: every lane inside xe
+  float t[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int kk = e0 + c - FD;
+    const bool ok = kk >= 0 && kk < Dn;
+    const float x = Dn > 0 ? xd[b * Dn + (ok ? kk : 0)] : 0.f;
+    t[c] = ok ? x : 0.f;
+  }
+  return in_e ? v : make_float4(t[0], t[1], t[2], t[3]);
+}
+
+// the original per-lane-branch loader: the backward kernel is register-bound and measured
+// faster with it (214 vs 248 us) - the branch-free one above costs it extra spills
+__device__ __forceinline__ float4 load_x0_branchy(const float *__restrict__ xe, const float *__restrict__ xd,
                                           int64_t b, int FD, int Dn, int q) {
   const int e0 = 4 * q;
   if (e0 + 3 < FD) return *reinterpret_cast<const float4 *>(xe + b * FD + e0);
@@ -108,6 +130,9 @@ __global__ __launch_bounds__(kBlock, 3) void cross_fwd_kernel(
   }
 }
 
+// (A dot-product reformulation of this backward - only x0 as vector state, dx0 = sum_j a_j w_j -
+// is algebraically exact (6e-14 vs autograd in fp64) but measured SLOWER here, 274 vs 214 us: its
+// dynamic layer loops spill SGPRs.  Kept out; the numbers are in profiles/r01_p7_loader_ablation.md.)
 template <int T>
 __global__ __launch_bounds__(kBlock, 3) void cross_bwd_kernel(
     const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn,
@@ -135,7 +160,7 @@ __global__ __launch_bounds__(kBlock, 3) void cross_bwd_kernel(
     float4 x0[T], dl[T], acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      x0[t] = load_x0(xe, xd, bb, FD, Dn, sub + 16 * t);
+      x0[t] = load_x0_branchy(xe, xd, bb, FD, Dn, sub + 16 * t);
       const float4 wo = so[sub + 16 * t];
       dl[t] = make_float4(gb * wo.x, gb * wo.y, gb * wo.z, gb * wo.w);  // delta_L = g * w_out
       acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -37,27 +37,47 @@ struct MlpW {
   int H[kMaxNL];
 };
 
+// One float4 of x = [xe | xd] at element k (k % 4 == 0) of example b, WITHOUT per-lane
+// branches: unconditional loads from clamped addresses + selects.  (A per-lane
+// `if (k + 3 < FD) float4 else scalar tail` made hipcc emit a divergent branch per load with
+// s_waitcnt vmcnt(0) in between - the 8 "independent" loads of a chunk ran one after the
+// other, and loads and MFMAs did not overlap at all: rocprof ablation, profiles/r01_p7_loader_ablation.md.)
+__device__ __forceinline__ float4 load_x4_tail(const float *__restrict__ xe,
+                                               const float *__restrict__ xd, int FD, int Dn,
+                                               int64_t b, int k) {
+  const bool in_e = k + 3 < FD;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (FD > 0) v = *reinterpret_cast<const float4 *>(xe + b * FD + (in_e ? k : 0));
+  float t[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int kk = k + e - FD;
+    const bool ok = kk >= 0 && kk < Dn;
+    const float x = Dn > 0 ? xd[b * Dn + (ok ? kk : 0)] : 0.f;
+    t[e] = ok ? x : 0.f;
+  }
+  return in_e ? v : make_float4(t[0], t[1], t[2], t[3]);
+}
+
 // loads the lane's 8 float4 of a 32-example x 64-k chunk of x = [xe | xd]
 __device__ __forceinline__ void load_chunk(float4 (&v)[8], const float *__restrict__ xe,
                                            const float *__restrict__ xd, int FD, int Dn, int64_t B,
                                            int64_t ex0, int k0, int lane) {
   const int c4 = lane & 15;
   const int k = k0 + 4 * c4;
+  if (k0 + 64 <= FD) {  // wave-uniform: the whole chunk lies in xe
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int row = (lane >> 4) + 4 * q;
-    int64_t b = ex0 + row;
-    b = b < B ? b : B - 1;
-    if (k + 3 < FD) {
+    for (int q = 0; q < 8; ++q) {
+      int64_t b = ex0 + (lane >> 4) + 4 * q;
+      b = b < B ? b : B - 1;
       v[q] = *reinterpret_cast<const float4 *>(xe + b * FD + k);
-    } else {
-      float t[4];
+    }
+  } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int kk = k + e;
-        t[e] = (kk >= FD && kk < FD + Dn) ? xd[b * Dn + (kk - FD)] : 0.f;
-      }
-      v[q] = make_float4(t[0], t[1], t[2], t[3]);
+    for (int q = 0; q < 8; ++q) {
+      int64_t b = ex0 + (lane >> 4) + 4 * q;
+      b = b < B ? b : B - 1;
+      v[q] = load_x4_tail(xe, xd, FD, Dn, b, k);
     }
   }
 }
@@ -214,6 +234,8 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
 constexpr int kLDT = 36;  // k-tile slice row stride in LDS (32 + 4 pad)
 constexpr int kWT = 4;    // k-tiles per wave: Kp <= 448 -> 14 tiles over 4 waves
 
+// (per-lane-branch form kept here on purpose: the backward kernel is register-bound and the
+// branch-free loader cost it spills, 113.7 -> 118.7 us; see profiles/r01_p7_loader_ablation.md)
 __device__ __forceinline__ void load_ktile(float4 (&v)[4], const float *__restrict__ xe,
                                            const float *__restrict__ xd, int FD, int Dn, int64_t B,
                                            int64_t ex0, int kb, int lane) {
