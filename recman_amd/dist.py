@@ -65,10 +65,11 @@ class RowExchange:
         self.pos, counts, self.send_ids = route_fn(idx, field_off, world)
         self.coll = world > 1 or (FORCE and dist.is_initialized())
         if self.coll:
-            recv_counts = torch.empty_like(counts)
-            dist.all_to_all_single(recv_counts, counts, group=group)
-            self.send_counts = counts.tolist()  # host sync: split sizes must be host-side
-            self.recv_counts = recv_counts.tolist()
+            both = torch.empty(2, world, dtype=counts.dtype, device=counts.device)
+            both[0].copy_(counts)
+            dist.all_to_all_single(both[1], both[0], group=group)
+            # ONE host sync per batch: the split sizes of the row exchanges must be host-side
+            self.send_counts, self.recv_counts = both.tolist()
             self.recv_ids = torch.empty(sum(self.recv_counts), dtype=self.send_ids.dtype,
                                         device=self.send_ids.device)
             dist.all_to_all_single(self.recv_ids, self.send_ids, self.recv_counts, self.send_counts,
@@ -129,9 +130,33 @@ class ShardedTable:
         return ex.recv_ids, ex.push(bucketed_grads)
 
 
-def allreduce_dense(grads, world, group=None):
-    """One flat all_reduce (sum / world) over every dense-parameter gradient."""
+def flatten_grads(grads):
+    """Re-homes every dense-parameter gradient as a view of ONE flat buffer (16-byte aligned
+    slots) so the data-parallel all_reduce runs in place, without a gather/scatter copy per
+    parameter.  Mutates `grads`; returns the flat buffer."""
+    keys = sorted(grads)
+    offs, n = [], 0
+    for k in keys:
+        offs.append(n)
+        n += (grads[k].numel() + 3) // 4 * 4
+    any_g = grads[keys[0]]
+    flat = torch.zeros(n, dtype=any_g.dtype, device=any_g.device)
+    for k, o in zip(keys, offs):
+        v = flat[o: o + grads[k].numel()].view_as(grads[k])
+        v.copy_(grads[k])
+        grads[k] = v
+    return flat
+
+
+def allreduce_dense(grads, world, group=None, flat=None):
+    """One flat all_reduce (sum / world) over every dense-parameter gradient; in place when
+    the gradients already live in `flat` (flatten_grads)."""
     if world == 1 and not (FORCE and dist.is_initialized()):
+        return
+    if flat is not None:
+        dist.all_reduce(flat, group=group)
+        if world > 1:
+            flat.div_(world)
         return
     keys = sorted(grads)
     flat = torch.cat([grads[k].reshape(-1) for k in keys])
@@ -184,6 +209,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
         def __init__(self):
             self._shard_args = (rank, world, group)
             super().__init__(spec, D, hp, device=device)
+            self._flat_grads = flatten_grads(self.grads)
 
         def _alloc_tables(self):
             dev = self.device
@@ -234,7 +260,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
             ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
                                self.dlogit if self.use_linear else None, self.ex.pos, self.grad_rows)
             self.shard_grad_ids, self.shard_grad_rows = self.st.push_grads(self.ex, self.grad_rows)
-            allreduce_dense(self.grads, world, group)
+            allreduce_dense(self.grads, world, group, self._flat_grads)
             return loss
 
     return Sharded()
