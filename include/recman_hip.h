@@ -252,12 +252,18 @@ int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int x
  * out[b, D+1] = sum over known tags (id >= 1) of the linear weight; the gather kernel then
  * reads that row like any other.  rm_pool_rows_bwd scatters a row gradient (d_rows rows of
  * dr_stride floats, g_bias / g_lin [B] or NULL) back to the tag rows of dense gradient
- * buffers d_table [R,D], d_bias [R], d_lin [R] (float atomics; NULL = skip). */
+ * buffers d_table [R,D], d_bias [R], d_lin [R] (float atomics; NULL = skip).
+ *
+ * vals (float [nnz] or NULL): per-id weights.  With vals the pair implements the
+ * value-weighted lookup of SparseValueFeat (inputs.py:213-278; `feat_embeds * value`,
+ * layers.py:129-142; `one_hot * value`, utils.py:70-71): out[b, 0..D) = sum v*emb,
+ * out[b, D] = sum bias (NOT scaled, as layers.py:136-140), out[b, D+1] = sum v*lin; no sqrtn
+ * factor and slot 0 is kept.  A SparseValueFeat is the CSR with one id per example. */
 int rm_pool_rows(const float *rows, int64_t row0, int LD, int D, const int64_t *offsets,
-                 const int64_t *ids, int64_t B, float *out, rm_stream_t stream);
+                 const int64_t *ids, const float *vals, int64_t B, float *out, rm_stream_t stream);
 int rm_pool_rows_bwd(const float *d_rows, int64_t dr_stride, const float *g_bias, const float *g_lin,
-                     int D, const int64_t *offsets, const int64_t *ids, int64_t B, int64_t row0,
-                     float *d_table, float *d_bias, float *d_lin, rm_stream_t stream);
+                     int D, const int64_t *offsets, const int64_t *ids, const float *vals, int64_t B,
+                     int64_t row0, float *d_table, float *d_bias, float *d_lin, rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Row-wise (lazy) optimizer step on the fused table rows, straight from the IndexedSlices

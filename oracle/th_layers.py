@@ -48,13 +48,16 @@ class Spec:
     (inputs.py:166).  dense_names: DenseFeat columns in dictionary order.
     """
 
-    def __init__(self, sparse_names, feat_sizes, dense_names=(), multi_names=()):
+    def __init__(self, sparse_names, feat_sizes, dense_names=(), multi_names=(), value_names=()):
         self.sparse_names = list(sparse_names)
         self.feat_sizes = [int(v) for v in feat_sizes]
         self.dense_names = list(dense_names)
         # embedding features that are MultiValCsvFeat (inputs.py:380-425): their idx column is
         # ignored, their tag ids come as CSR (offsets [B+1], ids [nnz]) in the `mv` dict
         self.multi_names = list(multi_names)
+        # embedding features that are SparseValueFeat (inputs.py:213-278): idx column ignored,
+        # `mv[name]` = (ids [B], vals [B])
+        self.value_names = list(value_names)
 
     @property
     def F(self):
@@ -67,10 +70,14 @@ class Spec:
     @property
     def lin_offsets(self):
         # one-hot block offsets of LinearCombiner (layers.py:284-293) with the feature order
-        # of utils.py:31-36: sparse feats first, then multi-valued csv feats, dense last.
-        # Returned per embedding feature IN sparse_names ORDER, plus the dense block start.
+        # of utils.py:31-36: sparse feats first, then value feats, then multi-valued csv feats,
+        # dense last.  Returned per embedding feature IN sparse_names ORDER, plus the dense
+        # block start.
         size = dict(zip(self.sparse_names, self.feat_sizes))
-        order = [n for n in self.sparse_names if n not in self.multi_names] + list(self.multi_names)
+        special = set(self.multi_names) | set(self.value_names)
+        order = ([n for n in self.sparse_names if n not in special]
+                 + [n for n in self.sparse_names if n in self.value_names]
+                 + [n for n in self.sparse_names if n in self.multi_names])
         off, at = 0, {}
         for n in order:
             at[n] = off
@@ -170,11 +177,17 @@ def pooled_lookup(table, offsets, ids):
 def feat_embedding_layer(p, spec, idx, use_bias=True, mv=None):
     """FeatEmbeddingLayer.__call__ (layers.py:238-261) over FeatEmbedding.__call__:
     SparseFeat branch (layers.py:117-128) and the sqrtn-pooled MultiValCsvFeat branch
-    (layers.py:144-169): E [B,F,D], bias [B,F,1] or None."""
+    (layers.py:144-169): E [B,F,D], bias [B,F,1] or None.  SparseValueFeat branch
+    (layers.py:129-142): embedding row * value, bias row unscaled - the INTENDED per-example
+    scaling (the reference's `tf.multiply([B,1,D], [B])` cannot run for B != D)."""
     def one(suffix, f, n):
         t = p[f"{n}_feat_{suffix}"]
         if n in spec.multi_names:
             return pooled_lookup(t, *mv[n])
+        if n in spec.value_names:
+            ids, vals = mv[n]
+            rows = _lookup(t, ids)
+            return rows * vals.to(t.dtype).unsqueeze(1) if suffix == "embed" else rows
         return _lookup(t, idx[:, f])
 
     E = torch.stack([one("embed", f, n) for f, n in enumerate(spec.sparse_names)], dim=1)
@@ -205,6 +218,10 @@ def linear_layer(p, spec, idx, dense, manual_weights=None, mv=None):
             seg = torch.repeat_interleave(torch.arange(B), offsets[1:] - offsets[:-1])
             contrib = W[off + ids] * (ids >= 1).to(W.dtype).unsqueeze(1)
             out = out + torch.zeros(B, 1, dtype=W.dtype).index_add(0, seg, contrib)
+            continue
+        if n in spec.value_names:  # one_hot(id) * value (utils.py:70-71)
+            ids, vals = mv[n]
+            out = out + _lookup(W, off + ids) * vals.to(W.dtype).unsqueeze(1)
             continue
         out = out + _lookup(W, off + idx[:, f])
     if spec.Dn:

@@ -7,6 +7,11 @@
 //   col  D+1    : sum_{t: tag_t >= 1} lin[tag_t]  (multi-hot count; slot 0 is zeroed, utils.py:108)
 // and the main kernel then gathers that row like any other (its index is the scratch row).
 // rm_pool_rows_bwd scatters the row gradient back to the tag rows with the same factors.
+//
+// With per-id weights `vals` the same two kernels serve the value-weighted lookup of
+// SparseValueFeat (inputs.py:213-278; layers.py:129-142, utils.py:70-71): one id per example,
+//   cols 0..D-1 : v * emb[id]     col D : bias[id] (not scaled)     col D+1 : v * lin[id]
+// (no sqrtn factor, slot 0 kept).
 #include "rm_common.h"
 
 namespace {
@@ -16,7 +21,8 @@ constexpr int kBlock = 256;
 // 16 lanes per example: lane k handles columns k, k+16, ... of the fused row
 __global__ __launch_bounds__(kBlock) void pool_rows_kernel(
     const float *__restrict__ rows, int64_t row0, int LD, int D, const int64_t *__restrict__ offsets,
-    const int64_t *__restrict__ ids, int64_t B, float *__restrict__ out) {
+    const int64_t *__restrict__ ids, const float *__restrict__ vals, int64_t B,
+    float *__restrict__ out) {
   const int lane = threadIdx.x & 15;
   const int64_t b = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
   if (b >= B) return;
@@ -27,10 +33,14 @@ __global__ __launch_bounds__(kBlock) void pool_rows_kernel(
     if (k < D + 2) {
       for (int64_t t = s; t < e; ++t) {
         const int64_t id = ids[t];
-        if (k == D + 1 && id < 1) continue;
-        acc += rows[(row0 + id) * LD + k];
+        const float x = rows[(row0 + id) * LD + k];
+        if (vals != nullptr) {
+          acc += k == D ? x : vals[t] * x;
+        } else if (k != D + 1 || id >= 1) {
+          acc += x;
+        }
       }
-      if (k <= D) acc *= inv;
+      if (vals == nullptr && k <= D) acc *= inv;
     }
     out[b * LD + k] = acc;
   }
@@ -39,8 +49,8 @@ __global__ __launch_bounds__(kBlock) void pool_rows_kernel(
 __global__ __launch_bounds__(kBlock) void pool_rows_bwd_kernel(
     const float *__restrict__ d_rows, int64_t dr_stride, const float *__restrict__ g_bias,
     const float *__restrict__ g_lin, int D, const int64_t *__restrict__ offsets,
-    const int64_t *__restrict__ ids, int64_t B, int64_t row0, float *__restrict__ d_table,
-    float *__restrict__ d_bias, float *__restrict__ d_lin) {
+    const int64_t *__restrict__ ids, const float *__restrict__ vals, int64_t B, int64_t row0,
+    float *__restrict__ d_table, float *__restrict__ d_bias, float *__restrict__ d_lin) {
   const int lane = threadIdx.x & 15;
   const int64_t b = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
   if (b >= B) return;
@@ -49,10 +59,13 @@ __global__ __launch_bounds__(kBlock) void pool_rows_bwd_kernel(
   const float inv = rsqrtf((float)(e - s));
   for (int64_t t = s; t < e; ++t) {
     const int64_t r = row0 + ids[t];
-    for (int k = lane; k < D; k += 16) atomicAdd(d_table + r * D + k, d_rows[b * dr_stride + k] * inv);
+    const float we = vals != nullptr ? vals[t] : inv;                      // embedding columns
+    const float wb = vals != nullptr ? 1.f : inv;                          // bias column
+    const float wl = vals != nullptr ? vals[t] : (ids[t] >= 1 ? 1.f : 0.f);  // linear column
+    for (int k = lane; k < D; k += 16) atomicAdd(d_table + r * D + k, d_rows[b * dr_stride + k] * we);
     if (lane == 0) {
-      if (d_bias != nullptr && g_bias != nullptr) atomicAdd(d_bias + r, g_bias[b] * inv);
-      if (d_lin != nullptr && g_lin != nullptr && ids[t] >= 1) atomicAdd(d_lin + r, g_lin[b]);
+      if (d_bias != nullptr && g_bias != nullptr) atomicAdd(d_bias + r, g_bias[b] * wb);
+      if (d_lin != nullptr && g_lin != nullptr && wl != 0.f) atomicAdd(d_lin + r, g_lin[b] * wl);
     }
   }
 }
@@ -60,25 +73,26 @@ __global__ __launch_bounds__(kBlock) void pool_rows_bwd_kernel(
 }  // namespace
 
 extern "C" int rm_pool_rows(const float *rows, int64_t row0, int LD, int D, const int64_t *offsets,
-                            const int64_t *ids, int64_t B, float *out, rm_stream_t stream) {
+                            const int64_t *ids, const float *vals, int64_t B, float *out,
+                            rm_stream_t stream) {
   RM_REQUIRE(B >= 0 && D > 0 && LD >= D + 2, "rm_pool_rows: bad sizes");
   if (B == 0) return RM_OK;
   RM_REQUIRE(rows && offsets && out, "rm_pool_rows: NULL argument");
   hipLaunchKernelGGL(pool_rows_kernel, dim3((unsigned)((B * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, rows, row0, LD, D, offsets, ids, B, out);
+                     (hipStream_t)stream, rows, row0, LD, D, offsets, ids, vals, B, out);
   RM_CHECK_LAUNCH("rm_pool_rows");
   return RM_OK;
 }
 
 extern "C" int rm_pool_rows_bwd(const float *d_rows, int64_t dr_stride, const float *g_bias,
                                 const float *g_lin, int D, const int64_t *offsets, const int64_t *ids,
-                                int64_t B, int64_t row0, float *d_table, float *d_bias, float *d_lin,
-                                rm_stream_t stream) {
+                                const float *vals, int64_t B, int64_t row0, float *d_table,
+                                float *d_bias, float *d_lin, rm_stream_t stream) {
   RM_REQUIRE(B >= 0 && D > 0 && dr_stride >= D, "rm_pool_rows_bwd: bad sizes");
   if (B == 0) return RM_OK;
   RM_REQUIRE(d_rows && offsets && d_table, "rm_pool_rows_bwd: NULL argument");
   hipLaunchKernelGGL(pool_rows_bwd_kernel, dim3((unsigned)((B * 16 + kBlock - 1) / kBlock)), dim3(kBlock),
-                     0, (hipStream_t)stream, d_rows, dr_stride, g_bias, g_lin, D, offsets, ids, B, row0,
+                     0, (hipStream_t)stream, d_rows, dr_stride, g_bias, g_lin, D, offsets, ids, vals, B, row0,
                      d_table, d_bias, d_lin);
   RM_CHECK_LAUNCH("rm_pool_rows_bwd");
   return RM_OK;

@@ -116,6 +116,36 @@ class ShardedTable:
         if lin is not None:
             self.shard[:, self.D + 1] = lin[sl].to(self.shard.device)
 
+    # ---- checkpoint: one file per rank (the shard never has to fit one host buffer) ----
+    @staticmethod
+    def shard_path(path, rank, world):
+        return f"{path}.shard{rank}of{world}.pt"
+
+    def save(self, path):
+        """Writes this rank's shard to `<path>.shard<rank>of<world>.pt` (every rank calls it)."""
+        torch.save({"R": self.R, "D": self.D, "rank": self.rank, "world": self.world,
+                    "rows": self.shard.cpu()}, self.shard_path(path, self.rank, self.world))
+
+    def load(self, path, saved_world=None):
+        """Restores the shard.  Same world size: reads this rank's own file.  Different world
+        size (re-sharding): streams the saved shards one at a time and keeps the rows that now
+        belong here (global row r = local * saved_world + saved_rank; it lives here when
+        r % world == rank)."""
+        w0 = saved_world or self.world
+        if w0 == self.world:
+            ck = torch.load(self.shard_path(path, self.rank, self.world), weights_only=True)
+            if (ck["R"], ck["D"]) != (self.R, self.D):
+                raise ValueError(f"checkpoint table is {ck['R']}x{ck['D']}, this one {self.R}x{self.D}")
+            self.shard.copy_(ck["rows"])
+            return
+        for r0 in range(w0):
+            ck = torch.load(self.shard_path(path, r0, w0), weights_only=True)
+            if (ck["R"], ck["D"]) != (self.R, self.D):
+                raise ValueError(f"checkpoint table is {ck['R']}x{ck['D']}, this one {self.R}x{self.D}")
+            g = torch.arange(ck["rows"].shape[0], dtype=torch.int64) * w0 + r0  # global row ids
+            mine = (g % self.world) == self.rank
+            self.shard[(g[mine] // self.world).to(self.shard.device)] = ck["rows"][mine].to(self.shard.device)
+
     def lookup(self, idx, field_off):
         """idx [B,F] -> (rows [n, D+4] in BUCKETED order, the RowExchange): the row of
         occurrence o = b*F+f is rows[ex.pos[o]] - consumers gather through pos, no un-route copy."""

@@ -43,12 +43,14 @@ class FeatureSpec:
     FeatureDictionary order (inputs.py:13-15) with their feat_size (null slot
     included, inputs.py:166) and the dense feature names."""
 
-    def __init__(self, sparse_names, feat_sizes, dense_names=(), multi_names=()):
+    def __init__(self, sparse_names, feat_sizes, dense_names=(), multi_names=(), value_names=()):
         self.sparse_names = list(sparse_names)
         self.feat_sizes = [int(v) for v in feat_sizes]
         self.dense_names = list(dense_names)
         # embedding features that are multi-valued (MultiValCsvFeat): sqrtn-pooled lookup
         self.multi_names = list(multi_names)
+        # embedding features that carry a value (SparseValueFeat): value-weighted lookup
+        self.value_names = list(value_names)
         if len(self.sparse_names) != len(self.feat_sizes):
             raise ValueError("sparse_names and feat_sizes differ in length")
 
@@ -73,10 +75,19 @@ class FeatureSpec:
 
     def lin_ref_blocks(self):
         """(row offset in the table, size) of each feature's one-hot block in the order the
-        reference's linear_w stacks them (utils.py:27-36): sparse feats, then multi-valued."""
+        reference's linear_w stacks them (utils.py:27-36): sparse feats, value feats, then
+        multi-valued."""
         at = dict(zip(self.sparse_names, zip(self.offsets(), self.feat_sizes)))
-        order = [n for n in self.sparse_names if n not in self.multi_names] + list(self.multi_names)
+        special = set(self.multi_names) | set(self.value_names)
+        order = ([n for n in self.sparse_names if n not in special]
+                 + [n for n in self.sparse_names if n in self.value_names]
+                 + [n for n in self.sparse_names if n in self.multi_names])
         return [at[n] for n in order]
+
+    @property
+    def scratch_names(self):
+        """Features whose per-example row is computed into scratch rows before the gather."""
+        return self.multi_names + self.value_names
 
 
 class MLP:
@@ -363,13 +374,13 @@ class Engine:
         return out
 
     def _lin_to_ref(self, v_rows):
-        """[R] in table-row order -> the reference's linear_w block order (sparse, multi-valued)."""
-        if not self.spec.multi_names:
+        """[R] in table-row order -> the reference's linear_w block order (sparse, value, multi-valued)."""
+        if not self.spec.scratch_names:
             return v_rows
         return torch.cat([v_rows[o: o + n] for o, n in self.spec.lin_ref_blocks()])
 
     def _lin_from_ref(self, v_ref):
-        if not self.spec.multi_names:
+        if not self.spec.scratch_names:
             return v_ref
         out = torch.empty_like(v_ref)
         at = 0
@@ -401,7 +412,7 @@ class Engine:
         self.dlogit = torch.empty(B, dtype=F32, device=dev)
         self.loss = torch.zeros(1, dtype=F32, device=dev)
         self.ws = torch.empty(256 * 1024, dtype=F32, device=dev)
-        self.mv_fields = [f for f, n in enumerate(self.spec.sparse_names) if n in self.spec.multi_names]
+        self.mv_fields = [f for f, n in enumerate(self.spec.sparse_names) if n in self.spec.scratch_names]
         if self.mv_fields:
             # per-batch pooled rows of the multi-valued features live in a scratch block that is
             # addressed AS ROWS OF THE TABLE: its start is aligned so that (scratch - table) is a
@@ -432,11 +443,12 @@ class Engine:
         if self.mv_fields:
             mv = self._mv
             if mv is None:
-                raise ValueError(f"multi-valued features {self.spec.multi_names} need their tag ids (mv=...)")
+                raise ValueError(f"features {self.spec.scratch_names} need their ids / values (mv=...)")
             self.idx_mv.copy_(idx)
             for j, f in enumerate(self.mv_fields):
-                offsets, ids = mv[self.spec.sparse_names[f]]
-                ops.pool_rows(self.rows, int(self.field_off_host[f]), D, offsets, ids, self.mv_scratch[j])
+                offsets, ids, vals = self._mv_entry(f)
+                ops.pool_rows(self.rows, int(self.field_off_host[f]), D, offsets, ids, self.mv_scratch[j],
+                              vals=vals)
                 self.idx_mv[:, f] = self._arange
             idx, foff = self.idx_mv, self.field_off_mv
         ops.embed_fwd(
@@ -450,6 +462,17 @@ class Engine:
             E=self.E, fm_sum=self.fm_sum if want_fm else None,
             fm_logit=self.fm_logit if want_fm else None,
             lin_logit=self.lin_logit if self.use_linear else None)
+
+    def _mv_entry(self, f):
+        """(offsets, ids, vals) of scratch-row field f from the mv dict: a multi-valued feature
+        gives (offsets, ids); a value feature (offsets, ids, vals) with one id per example."""
+        name = self.spec.sparse_names[f]
+        ent = self._mv[name]
+        vals = ent[2] if len(ent) > 2 else None
+        if (name in self.spec.value_names) != (vals is not None):
+            raise ValueError(f"feature {name}: value features take (offsets, ids, vals), "
+                             "multi-valued ones (offsets, ids)")
+        return ent[0], ent[1], vals
 
     def forward(self, idx, dense=None, training=False, masks=None, manual_weights=None, mv=None):
         """-> (logit [B], pred [B]).  training=False disables dropout and (as the
@@ -586,13 +609,13 @@ class Engine:
         if self.use_linear:
             ops.scatter_add_rows(d_lin, idx, foff, g_row=self.dlogit)
         for f in self.mv_fields:
-            offsets, ids = self._mv[self.spec.sparse_names[f]]
+            offsets, ids, vals = self._mv_entry(f)
             gb = None
             if d_bias is not None and self._has_fm():
                 gb = g_bias_occ[:, f].contiguous() if g_bias_occ is not None else self.dlogit
             ops.pool_rows_bwd(self.d_rows[:, f, :], gb, self.dlogit if self.use_linear else None, D,
                               offsets, ids, offs[f], d_table, d_bias if gb is not None else None,
-                              d_lin if self.use_linear else None)
+                              d_lin if self.use_linear else None, vals=vals)
         d_table, d_lin = d_table[:R], d_lin[:R]
         if d_bias is not None:
             d_bias = d_bias[:R]

@@ -337,23 +337,35 @@ def sparse_optimizer_step(idx, field_off, d_rows, rows, m_state, v_state, gbuf, 
               1 if reset else 0, _stream())
 
 
-def pool_rows(rows, row0, D, offsets, ids, out):
-    """sqrtn-pooled fused rows of a multi-valued feature (rm_pool_rows): out [B, LD]."""
+def _chk_csr(offsets, ids, vals):
+    if int(offsets.shape[0]) < 1:
+        raise ValueError("CSR offsets must have B+1 entries")
+    if vals is not None and vals.shape != ids.shape:
+        raise ValueError(f"vals {tuple(vals.shape)} must match ids {tuple(ids.shape)}")
+
+
+def pool_rows(rows, row0, D, offsets, ids, out, vals=None):
+    """Pooled fused rows of a multi-valued feature (rm_pool_rows): out [B, LD].  vals=None:
+    sqrtn combiner (MultiValCsvFeat); vals [nnz]: value-weighted (SparseValueFeat)."""
     B = offsets.shape[0] - 1
     LD = rows.shape[1]
+    _chk_csr(offsets, ids, vals)
     _lib.call("rm_pool_rows", _chk(rows, "rows", F32), int(row0), LD, D, _chk(offsets, "offsets", I64),
-              _chk(ids, "ids", I64), B, _chk(out, "out", F32, (B, LD)), _stream())
+              _chk(ids, "ids", I64), _chk(vals, "vals", F32, allow_none=True), B,
+              _chk(out, "out", F32, (B, LD)), _stream())
 
 
-def pool_rows_bwd(d_rows_f, g_bias, g_lin, D, offsets, ids, row0, d_table, d_bias, d_lin):
+def pool_rows_bwd(d_rows_f, g_bias, g_lin, D, offsets, ids, row0, d_table, d_bias, d_lin, vals=None):
     """d_rows_f: [B, D] view (row stride may be larger) of the pooled rows' gradient."""
     B = offsets.shape[0] - 1
+    _chk_csr(offsets, ids, vals)
     if d_rows_f.stride(1) != 1:
         raise ValueError("pool_rows_bwd: d_rows_f must be unit-stride along D")
     _lib.call("rm_pool_rows_bwd", d_rows_f.data_ptr(), d_rows_f.stride(0),
               _chk(g_bias, "g_bias", F32, (B,), allow_none=True),
               _chk(g_lin, "g_lin", F32, (B,), allow_none=True), D, _chk(offsets, "offsets", I64),
-              _chk(ids, "ids", I64), B, int(row0), _chk(d_table, "d_table", F32),
+              _chk(ids, "ids", I64), _chk(vals, "vals", F32, allow_none=True), B, int(row0),
+              _chk(d_table, "d_table", F32),
               _chk(d_bias, "d_bias", F32, allow_none=True), _chk(d_lin, "d_lin", F32, allow_none=True),
               _stream())
 

@@ -65,8 +65,8 @@ class SparseTableOptimizer:
 
         from . import ops
 
-        if engine.spec.multi_names:
-            raise NotImplementedError("the row-wise sparse step does not cover multi-valued features yet")
+        if engine.spec.scratch_names:
+            raise NotImplementedError("the row-wise sparse step does not cover multi-valued / value features yet")
         self.ops, self.e, self.name, self.lr = ops, engine, name, float(lr)
         R, LD = engine.rows.shape
         dev = engine.device

@@ -56,7 +56,8 @@ class DeepModel(BaseEstimator, TransformerMixin):
         spec = eng.FeatureSpec([f.name for f in fd.embedding_feats],
                                [f.feat_size for f in fd.embedding_feats],
                                [f.name for f in fd.dense_feats],
-                               [f.name for f in fd.multi_val_csv_feats])
+                               [f.name for f in fd.multi_val_csv_feats],
+                               [f.name for f in fd.sparse_val_feats])
         hp = dict(self.hparams)
         hp["strict_reference"] = self.strict_reference
         e = eng.ENGINES[self.model](spec, hp["embedding_size"], hp, task=self.task, device=self.device)
@@ -65,7 +66,7 @@ class DeepModel(BaseEstimator, TransformerMixin):
         self._opt = Optimizer(hp.get("optimizer", "adam"), hp.get("learning_rate", 1e-3))
         # row-wise sparse step for the table when nothing forces a dense gradient
         no_l2 = not hp.get("embedding_l2_reg", 0.0) and not hp.get("linear_l2_reg", 0.0)
-        want = hp.get("sparse_optimizer", e.rows.numel() > (1 << 24)) and not spec.multi_names
+        want = hp.get("sparse_optimizer", e.rows.numel() > (1 << 24)) and not spec.scratch_names
         self._sparse_opt = None
         if want and no_l2 and hp.get("optimizer", "adam") in ("adam", "adagrad", "gd", "sgd"):
             self._sparse_opt = SparseTableOptimizer(e, hp.get("optimizer", "adam"),
@@ -98,13 +99,15 @@ class DeepModel(BaseEstimator, TransformerMixin):
         for name, csr in mv_host.items():
             c = csr.slice(s, t)
             out[name] = (torch.from_numpy(c.offsets).to(dev), torch.from_numpy(c.ids).to(dev))
+            if c.vals is not None:  # SparseValueFeat: (offsets, ids, vals)
+                out[name] += (torch.from_numpy(c.vals).to(dev),)
         return out
 
     def _manual_weights(self):
         """Concatenated per-feature manual weights in linear-feature order
         (layers.py:338-345), or None when no feature has any."""
         fd = self.feat_dict
-        feats = fd.linear_feats  # utils.py:31-36: sparse, multi-valued csv, dense
+        feats = fd.linear_feats  # utils.py:31-36: sparse, value, multi-valued csv, dense
         if not any(getattr(f, "_weights", None) for f in feats):
             return None
         w = np.concatenate([np.asarray(f.weights, dtype=np.float64).reshape(-1) for f in feats])
@@ -232,6 +235,17 @@ class DeepModel(BaseEstimator, TransformerMixin):
         return None  # the reference's fit returns None
 
     # --------------------------------------------------------------- checkpoint
+    @classmethod
+    def from_hparams(cls, feat_dict, hparams, **ctor):
+        """Builds the model from a saved hparams dict (BestModelFinder.load): gen-2 classes take
+        the dict itself (xDeepFM.py:26-35), gen-1 classes keyword arguments (DeepFM.py:30-53)."""
+        import inspect
+
+        names = inspect.signature(cls.__init__).parameters
+        if "hparams" in names:
+            return cls(feat_dict, dict(hparams), **ctor)
+        return cls(feat_dict, **{k: v for k, v in hparams.items() if k in names and k not in ctor}, **ctor)
+
     def save(self, path):
         """state_dict with the reference's variable names (tf.train.Checkpoint(**variables),
         BestModelFinder.py:57-68)."""

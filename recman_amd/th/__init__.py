@@ -2,13 +2,14 @@
 stub (recman/th/layers.py is 0 bytes, recman/th/DeepFM.py:12-13 is `pass`), here backed
 by hand-written gfx950 kernels.  Same class names, constructor arguments and
 fit()/predict()/evaluate() signatures as recman/tf/core."""
+from .BestModelFinder import BestModelFinder
 from .DCN import DCN
 from .DeepFM import DeepFM
 from .DeepModel import DeepModel
 from .inputs import (DataInputs, DenseFeat, FeatureDictionary, MultiValCsvFeat, ResilientLabelEncoder,
-                     SparseFeat)
+                     SparseFeat, SparseValueFeat)
 from .xDeepFM import xDeepFM
 from . import hparams
 
-__all__ = ["DCN", "DeepFM", "DeepModel", "xDeepFM", "DataInputs", "DenseFeat", "FeatureDictionary",
-           "MultiValCsvFeat", "ResilientLabelEncoder", "SparseFeat", "hparams"]
+__all__ = ["BestModelFinder", "DCN", "DeepFM", "DeepModel", "xDeepFM", "DataInputs", "DenseFeat", "FeatureDictionary",
+           "MultiValCsvFeat", "ResilientLabelEncoder", "SparseFeat", "SparseValueFeat", "hparams"]

@@ -118,6 +118,70 @@ class SparseFeat:
         return f"SparseFeat({self.name}, {self.feat_size})"
 
 
+class SparseValueFeat:
+    """inputs.py:213-278: one (id, value) pair per example - the column holds pairs (a Series
+    of 2-sequences or an [N,2] array).  Looked up as value * embedding[id] (layers.py:129-142;
+    the bias lookup is NOT scaled, :136-140) and value * linear_w[id] (utils.py:70-71).
+
+    Reference quirks (documented in DESIGN.md, not reproduced): the reference casts the whole
+    [N,2] array to the feature dtype, int64 by default (:264), truncating the values, and then
+    multiplies a float32 [B,1,D] tensor by the int64 [B] column (layers.py:142) - a dtype
+    error in TF, and a mis-broadcast over D even with matching dtypes.  Here the value stays
+    float32 and scales the example's row, which is what the docstring (:214-216) describes."""
+
+    def __init__(self, name, feat_size, weights=None, dtype=None, encoder=None, description=None):
+        self.name = name
+        self.dtype = dtype
+        self.description = description
+        self.encoder = encoder if encoder else ResilientLabelEncoder()
+        self.feat_size = feat_size + 1
+        self._weights = weights
+        self._weights_cache = None
+
+    weights = SparseFeat.weights
+    set_weights = SparseFeat.set_weights
+
+    @staticmethod
+    def _pairs(X):
+        X = np.array(X.tolist(), dtype=object) if isinstance(X, pd.Series) else np.asarray(X, dtype=object)
+        assert X.ndim == 2 and X.shape[1] == 2, "SparseValueFeat takes (id, value) pairs"  # :251,260
+        return X
+
+    def get_shape(self, for_tf=True):
+        return None if for_tf else -1, 2
+
+    def initialize(self, X):
+        if self.encoder:
+            self.encoder.fit(self._ids(self._pairs(X)))
+
+    @staticmethod
+    def _ids(X):
+        ids = X[:, 0]
+        try:  # homogeneous numeric ids keep their numeric dtype (the encoder branches on it)
+            return ids.astype(np.int64) if all(isinstance(v, (int, np.integer)) for v in ids) else ids.astype(str)
+        except (TypeError, ValueError):
+            return ids.astype(str)
+
+    def encode(self, x):
+        """-> CSR with one id per example and vals = the float32 values."""
+        X = self._pairs(x)
+        ids = self._ids(X)
+        if self.encoder:
+            ids = self.encoder.transform(ids).reshape(-1)
+        n = len(X)
+        return CSR(np.arange(n + 1), np.asarray(ids, dtype=np.int64), X[:, 1].astype(np.float32))
+
+    def __call__(self, x):
+        c = self.encode(x)
+        return np.stack([c.ids.astype(np.float64), c.vals.astype(np.float64)], axis=1)
+
+    def decode(self, x):
+        return self.encoder.inverse_transform(x) if self.encoder else x
+
+    def __repr__(self):
+        return f"SparseValueFeat({self.name}, {self.feat_size})"
+
+
 class DenseFeat:
     """inputs.py:281-322: float32 cast -> sklearn scaler -> float32 [B,1].  (The reference's
     default argument `scaler=StandardScaler()` is one shared instance, :287; here every
@@ -153,11 +217,13 @@ class DenseFeat:
 
 
 class CSR:
-    """Ragged tag-id lists of a multi-valued feature: example b owns ids[offsets[b]:offsets[b+1]]."""
+    """Ragged tag-id lists of a multi-valued feature: example b owns ids[offsets[b]:offsets[b+1]]
+    (and, for a value feature, the per-id float32 weights vals)."""
 
-    def __init__(self, offsets, ids):
+    def __init__(self, offsets, ids, vals=None):
         self.offsets = np.asarray(offsets, dtype=np.int64)
         self.ids = np.asarray(ids, dtype=np.int64)
+        self.vals = None if vals is None else np.asarray(vals, dtype=np.float32)
 
     @classmethod
     def from_lists(cls, lists):
@@ -171,7 +237,7 @@ class CSR:
 
     def slice(self, s, t):
         o = self.offsets[s: t + 1]
-        return CSR(o - o[0], self.ids[o[0]: o[-1]])
+        return CSR(o - o[0], self.ids[o[0]: o[-1]], None if self.vals is None else self.vals[o[0]: o[-1]])
 
     def take(self, perm):
         n = self.offsets[1:] - self.offsets[:-1]
@@ -179,7 +245,7 @@ class CSR:
         lens = n[perm]
         offsets = np.concatenate(([0], np.cumsum(lens)))
         pos = np.repeat(starts - offsets[:-1], lens) + np.arange(offsets[-1])
-        return CSR(offsets, self.ids[pos])
+        return CSR(offsets, self.ids[pos], None if self.vals is None else self.vals[pos])
 
 
 class MultiValCsvFeat:
@@ -251,24 +317,30 @@ class FeatureDictionary(OrderedDict):
         return [f for f in self.values() if isinstance(f, DenseFeat)]
 
     @property
+    def sparse_val_feats(self):
+        return [f for f in self.values() if isinstance(f, SparseValueFeat)]
+
+    @property
     def multi_val_csv_feats(self):
         return [f for f in self.values() if isinstance(f, MultiValCsvFeat)]
 
     @property
     def linear_feats(self):
-        """get_linear_features (utils.py:27-36): sparse, then multi-valued csv, then dense."""
-        return self.sparse_feats + self.multi_val_csv_feats + self.dense_feats
+        """get_linear_features (utils.py:27-36): sparse, value, multi-valued csv, then dense."""
+        return self.sparse_feats + self.sparse_val_feats + self.multi_val_csv_feats + self.dense_feats
 
     def initialize(self, X):
         for feat in self.values():
             feat.initialize(X[feat.name])
 
     def check_supported(self):
-        bad = [f for f in self.values() if not isinstance(f, (SparseFeat, DenseFeat, MultiValCsvFeat))]
+        ok = (SparseFeat, SparseValueFeat, DenseFeat, MultiValCsvFeat)
+        bad = [f for f in self.values() if not isinstance(f, ok)]
         if bad:
             raise NotImplementedError(
-                f"features {[f.name for f in bad]}: SparseFeat, DenseFeat and MultiValCsvFeat are on "
-                "the HIP path (value-weighted / hashed multi-valued features are SURVEY.md 8f items)")
+                f"features {[f.name for f in bad]}: SparseFeat, SparseValueFeat, DenseFeat and "
+                "MultiValCsvFeat are on the HIP path (the reference itself raises NotImplementedError "
+                "for MultiValSparseFeat lookups, utils.py:111-115, and for SequenceFeat, inputs.py:443)")
 
 
 class DataInputs(dict):
@@ -284,7 +356,8 @@ class DataInputs(dict):
         dense = feat_dict.dense_feats
         n = len(X)
         # multi-valued features: tag ids as CSR; their idx column is a placeholder
-        self.mv = {f.name: f.encode(X[f.name]) for f in sparse if isinstance(f, MultiValCsvFeat)}
+        self.mv = {f.name: f.encode(X[f.name]) for f in sparse
+                   if isinstance(f, (MultiValCsvFeat, SparseValueFeat))}
         cols = [np.zeros((n, 1), np.int64) if f.name in self.mv else self[f.name] for f in sparse]
         self.idx = np.concatenate(cols, axis=1) if sparse else np.zeros((n, 0), np.int64)
         self.dense = (np.concatenate([self[f.name] for f in dense], axis=1).astype(np.float32)

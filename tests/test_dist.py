@@ -57,6 +57,36 @@ def test_world_one_table_roundtrip():
     assert torch.allclose(dense, want)
 
 
+def test_shard_checkpoint_roundtrip_and_reshard(tmp_path):
+    """Per-rank shard files: same-world restore is exact; a 4-rank checkpoint re-shards onto 3
+    and onto 1 rank with every global row in its new home."""
+    g = torch.Generator().manual_seed(3)
+    R, D = 103, 4
+    full = torch.randn(R, D, generator=g)
+    bias, lin = torch.randn(R, generator=g), torch.randn(R, generator=g)
+    path = str(tmp_path / "table")
+    saved = []
+    for r in range(4):
+        st = rd.ShardedTable(R, D, r, 4, "cpu", cpu_gather, rd.route_torch)
+        st.load_global(full, bias, lin)
+        st.save(path)
+        saved.append(st.shard.clone())
+    for r in range(4):
+        st = rd.ShardedTable(R, D, r, 4, "cpu", cpu_gather, rd.route_torch)
+        st.load(path)
+        assert torch.equal(st.shard, saved[r])
+    for world in (3, 1):
+        for r in range(world):
+            st = rd.ShardedTable(R, D, r, world, "cpu", cpu_gather, rd.route_torch)
+            st.load(path, saved_world=4)
+            want = rd.ShardedTable(R, D, r, world, "cpu", cpu_gather, rd.route_torch)
+            want.load_global(full, bias, lin)
+            assert torch.equal(st.shard, want.shard)
+    other = rd.ShardedTable(R + 1, D, 0, 4, "cpu", cpu_gather, rd.route_torch)
+    with pytest.raises(ValueError):
+        other.load(path)
+
+
 def _worker(rank, world, port, R, D, n):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

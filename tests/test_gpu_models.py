@@ -205,3 +205,71 @@ def test_ml100k_full_feature_set_with_genres(hip_lib):
     has = np.array(["Comedy" in s.split("|") for s in df["genres"].values])
     z0, z1 = np.log(pred1 / (1 - pred1)), np.log(boosted / (1 - boosted))
     assert np.allclose((z1 - z0)[has], -5, atol=2e-3) and np.allclose((z1 - z0)[~has], 0, atol=2e-3)
+
+
+def test_best_model_finder_callback_and_reload(hip_lib, tmp_path):
+    """epoch_callback=BestModelFinder(save_model=True) (BestModelFinder.py:9-68): keeps the best
+    (lowest first metric of the validation results), checkpoints it, and the checkpoint reloads."""
+    import recman_amd.th as th
+
+    df = ml_frame()
+    fd = ml_features(df)
+    m = th.DeepFM(fd, embedding_size=8, deep_dropout=(1, 1, 1), epoch=3, batch_size=256,
+                  learning_rate=0.01, eval_metric=(log_loss,))
+    finder = th.BestModelFinder(save_model=True, directory=str(tmp_path))
+    assert finder.best_model is None and finder.best_score is None
+    tr, va = df.iloc[:768], df.iloc[768:]
+    m.fit(tr, tr["label"].values, va, va["label"].values, epoch_callback=finder,
+          random_seed_for_mini_batch=False)
+    assert finder.best_model is m and finder.best_score is not None
+    assert len(finder.best_eval_results) == 2  # (train, valid)
+    assert finder.best_score == finder.best_eval_results[-1][0]
+    m2 = th.BestModelFinder.load(th.DeepFM, str(tmp_path))
+    assert m2.hparams == m.hparams
+    # the checkpoint is the best epoch's state; when the last epoch is the best it equals m
+    best_valid = log_loss(va["label"].values, m2.predict(va).astype(np.float64))
+    assert abs(best_valid - finder.best_score) < 1e-5
+    x = th.xDeepFM.from_hparams(fd, {"embedding_size": 4, "cin_cross_layer_units": (8, 8)}, epoch=1)
+    assert x.hparams["embedding_size"] == 4 and x.epoch == 1
+
+
+def test_sparse_value_feature_through_fit_predict(hip_lib):
+    """A SparseValueFeat column of (occupation, weight) pairs through the model surface: predict
+    equals the oracle before and after one epoch of training (dense-gradient Adam path)."""
+    import recman_amd.th as th
+
+    df = ml_frame()
+    w = (np.arange(len(df)) % 5).astype(np.float32) / 2.0  # 0, .5, 1, 1.5, 2
+    df["occ_w"] = list(zip(df["occupation"].values, w))
+    fd = ml_features(df)
+    fd["occ_w"] = th.SparseValueFeat(name="occ_w", feat_size=len(np.unique(df["occupation"].values)))
+    fd.initialize(df)
+    m = th.DeepFM(fd, embedding_size=8, deep_dropout=(1, 1, 1), learning_rate=0.01, epoch=1,
+                  batch_size=256, random_seed=2019)
+    e = m._build()
+    assert e.spec.value_names == ["occ_w"] and e.F == 6
+    spec = T.Spec(e.spec.sparse_names, e.spec.feat_sizes, e.spec.dense_names, e.spec.multi_names,
+                  e.spec.value_names)
+    p0 = {k: v.cpu() for k, v in e.state_dict().items()}
+    inp = th.DataInputs().load(fd, df, df["label"].values)
+    idx, dense, y = torch.from_numpy(inp.idx), torch.from_numpy(inp.dense), torch.from_numpy(inp.y)
+    csr = inp.mv["occ_w"]
+    mv = {"occ_w": (torch.from_numpy(csr.ids), torch.from_numpy(csr.vals))}
+    hp = dict(m.hparams)
+    want0 = T.prediction(T.deepfm_logit(p0, spec, idx, dense, hp, training=False, mv=mv)).numpy()
+    assert np.abs(m.predict(df) - want0).max() < 1e-6
+    m.fit(df, df["label"].values, random_seed_for_mini_batch=False)
+    from sklearn.utils import check_random_state
+
+    p, state, t = {k: v.clone() for k, v in p0.items()}, {}, 0
+    perm = np.arange(1024)
+    check_random_state(2019).shuffle(perm)
+    idx2, dense2, y2, csr2 = idx[perm], dense[perm], y[perm], csr.take(perm)
+    for s in range(0, 1024, 256):
+        c = csr2.slice(s, s + 256)
+        mvb = {"occ_w": (torch.from_numpy(c.ids), torch.from_numpy(c.vals))}
+        _, _, _, g = T.fwd_bwd("deepfm", p, spec, idx2[s:s + 256], dense2[s:s + 256], y2[s:s + 256], hp, mv=mvb)
+        t += 1
+        keras_adam_cpu(p, g, state, t, 0.01)
+    want1 = T.prediction(T.deepfm_logit(p, spec, idx, dense, hp, training=False, mv=mv)).numpy()
+    assert np.abs(m.predict(df) - want1).max() < 2e-4

@@ -276,3 +276,42 @@ def test_multi_valued_feature_fwd_bwd_matches_oracle(hip_lib, model, kw):
             _close(grads[k], grads_o[k], what=f"grad {k}")
     logit_i, _ = e.forward(idx.cuda(), dense.cuda(), training=False, mv=mv_d)
     _close(logit_i, logit_o, rtol=0, atol=1e-5, what="inference logit")
+
+
+@pytest.mark.parametrize("model,kw", [("deepfm", {}), ("xdeepfm", dict(cin_units=(8, 4), scale=0.2)),
+                                       ("dcn", dict(cross_layers=2, scale=0.15))])
+def test_value_feature_fwd_bwd_matches_oracle(hip_lib, model, kw):
+    """A SparseValueFeat (value * embedding row, unscaled bias, value * linear weight) next to a
+    MultiValCsvFeat: both go through the scratch-row kernels (rm_pool_rows with / without vals)."""
+    from recman_amd import engine as eng
+
+    spec, p, idx, dense, y, hp = make_case(model, B=37, D=8, **kw)
+    vname, mname = spec.sparse_names[1], spec.sparse_names[3]
+    spec = T.Spec(spec.sparse_names, spec.feat_sizes, spec.dense_names, multi_names=[mname],
+                  value_names=[vname])
+    g = torch.Generator().manual_seed(11)
+    B = 37
+    vids = torch.randint(0, spec.feat_sizes[1], (B,), generator=g)
+    vals = torch.randn(B, generator=g)
+    vals[0] = 0.0  # a zero value switches the feature off for that example
+    n = torch.randint(0, 3, (B,), generator=g)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), n.cumsum(0)])
+    ids = torch.randint(0, spec.feat_sizes[3], (int(n.sum()),), generator=g)
+    mv = {vname: (vids, vals), mname: (offsets, ids)}
+    loss_o, logit_o, pred_o, grads_o = T.fwd_bwd(model, p, spec, idx, dense, y, hp, mv=mv)
+    e = eng.ENGINES[model](eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names,
+                                           spec.multi_names, spec.value_names), 8, hp)
+    e.load_params({k: v for k, v in p.items() if k in e.params or k == "linear_w"})
+    _close(e.state_dict()["linear_w"], p["linear_w"], rtol=0, atol=0, what="linear_w round trip")
+    mv_d = {vname: (torch.arange(B + 1).cuda(), vids.cuda(), vals.cuda()),
+            mname: (offsets.cuda(), ids.cuda())}
+    loss = e.fwd_bwd(idx.cuda(), dense.cuda(), y.cuda(), mv=mv_d)
+    _close(e.logit, logit_o, rtol=0, atol=1e-5, what="logit")
+    _close(loss, loss_o.reshape(1), what="loss")
+    grads = e.dense_grads(idx.cuda(), reference_names=True)
+    for k in grads_o:
+        if k in grads:
+            _close(grads[k], grads_o[k], what=f"grad {k}")
+    with pytest.raises(ValueError):  # a value feature without its values
+        e.forward(idx.cuda(), dense.cuda(), mv={vname: (torch.arange(B + 1).cuda(), vids.cuda()),
+                                                 mname: (offsets.cuda(), ids.cuda())})

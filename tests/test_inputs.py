@@ -134,3 +134,39 @@ def test_linear_feature_order_with_multi_val():
     fd["s1"] = SparseFeat("s1", 3)
     assert [f.name for f in fd.embedding_feats] == ["s0", "mv", "s1"]      # field axis of E
     assert [f.name for f in fd.linear_feats] == ["s0", "s1", "mv", "d0"]    # utils.py:31-36
+
+
+def test_sparse_value_feat_encodes_pairs():
+    """SparseValueFeat (inputs.py:213-278): (id, value) pairs -> encoded id + float32 value; the
+    one-id CSR the scratch-row kernel takes; linear-feature order sparse, value, multi, dense."""
+    import pandas as pd
+
+    from recman_amd.th import (DataInputs, DenseFeat, FeatureDictionary, MultiValCsvFeat, SparseFeat,
+                               SparseValueFeat)
+
+    df = pd.DataFrame({
+        "tagw": [("b", 0.5), ("a", 2.0), ("zz", -1.0), ("b", 0.0)],
+        "city": ["x", "y", "x", "q"],
+        "g": ["p|q", "", "q", "p"],
+        "age": [1.0, 2.0, 3.0, 4.0],
+    })
+    fd = FeatureDictionary()
+    fd["tagw"] = SparseValueFeat("tagw", feat_size=3)
+    fd["g"] = MultiValCsvFeat("g", tags=("p", "q"))
+    fd["age"] = DenseFeat("age")
+    fd["city"] = SparseFeat("city", feat_size=3)
+    fd.initialize(df)
+    assert [f.name for f in fd.linear_feats] == ["city", "tagw", "g", "age"]
+    assert [f.name for f in fd.embedding_feats] == ["tagw", "g", "city"]
+    inp = DataInputs().load(fd, df)
+    c = inp.mv["tagw"]
+    assert c.ids.tolist() == [2, 1, 3, 2] and c.offsets.tolist() == [0, 1, 2, 3, 4]
+    assert c.vals.dtype == np.float32 and c.vals.tolist() == [0.5, 2.0, -1.0, 0.0]
+    assert inp["tagw"].shape == (4, 2) and inp["tagw"][:, 0].tolist() == [2, 1, 3, 2]
+    assert inp.idx.shape == (4, 3) and inp.idx[:, 0].tolist() == [0, 0, 0, 0]  # placeholder column
+    s = c.take(np.array([3, 0])).slice(0, 2)
+    assert s.ids.tolist() == [2, 2] and s.vals.tolist() == [0.0, 0.5]
+    unseen = fd["tagw"].encode(pd.Series([("nope", 1.5)]))
+    assert unseen.ids.tolist() == [0] and unseen.vals.tolist() == [1.5]
+    fd["tagw"].set_weights({"a": 3.0})
+    assert fd["tagw"].weights.tolist() == [0.0, 3.0, 0.0, 0.0]

@@ -156,3 +156,28 @@ def test_multi_val_sqrtn_pooling_and_multi_hot_linear():
     W = p["linear_w"]
     want2 = p["linear_w0"] + W[0 + 0] + W[5 + 0] + 2 * W[11 + 2] + dense[2] @ W[15:16]  # id 0 contributes nothing
     assert torch.allclose(lin[2], want2.reshape(-1))
+
+
+def test_value_feature_reduces_to_plain_lookup_and_scales():
+    """SparseValueFeat branch of the oracle (layers.py:129-142, utils.py:70-71): with value 1 it is
+    the plain SparseFeat lookup; the embedding and linear terms scale with the value, the FM
+    bias does not."""
+    spec, p, idx, dense, y, hp = make_case("deepfm", B=9, D=4)
+    name = spec.sparse_names[1]
+    vspec = T.Spec(spec.sparse_names, spec.feat_sizes, spec.dense_names, value_names=[name])
+    # the linear_w block order changes (sparse, value, ...): permute the plain weights accordingly
+    offs_plain, _ = spec.lin_offsets
+    offs_val, _ = vspec.lin_offsets
+    pv = dict(p)
+    W = p["linear_w"].clone()
+    for f, n in enumerate(spec.sparse_names):
+        W[offs_val[f]: offs_val[f] + spec.feat_sizes[f]] = p["linear_w"][offs_plain[f]: offs_plain[f] + spec.feat_sizes[f]]
+    pv["linear_w"] = W
+    ones = torch.ones(9)
+    plain = T.deepfm_logit(p, spec, idx, dense, hp, training=False)
+    as_val = T.deepfm_logit(pv, vspec, idx, dense, hp, training=False, mv={name: (idx[:, 1], ones)})
+    assert torch.allclose(plain, as_val, atol=1e-6)
+    E1, b1 = T.feat_embedding_layer(pv, vspec, idx, True, mv={name: (idx[:, 1], ones)})
+    E3, b3 = T.feat_embedding_layer(pv, vspec, idx, True, mv={name: (idx[:, 1], 3 * ones)})
+    assert torch.allclose(E3[:, 1], 3 * E1[:, 1]) and torch.equal(b3, b1)
+    assert torch.equal(E3[:, 0], E1[:, 0])
