@@ -244,6 +244,37 @@ int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int x
                      int64_t workspace_floats, rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Wide dense layers on the f32 MFMA (hidden widths > 32: DCN's deep_hidden_units (400, 400),
+ * DCN.py:33; and the matrix form of the cross layer).  Replaces tf.matmul(x, W) + bias +
+ * activation of DNN.__call__ (layers.py:594-602) and the GEMMs of its gradient, with the
+ * dense-input piece, bias, activation and activation gradient fused (csrc/gemm.hip).
+ *
+ * rm_dense_fwd:  C[M,N] = epilogue( [A1 | A2][M, K1+K2] . op(W) )
+ *   A1 [M,K1] (float4 loads when its rows are 16-byte aligned: lda1 % 4 == 0; per-element loads
+ *   otherwise), A2 [M,K2] or NULL (the 13 dense inputs);
+ *   W row-major: [K,N] (w_transposed = 0) or [N,K] (w_transposed = 1, i.e. op(W) = W^T);
+ *   epilogue (acc = the GEMM result, b = bias[col] or 0 when bias is NULL):
+ *     RM_DENSE_BIAS_ACT     C = act(acc + b)
+ *     RM_DENSE_MUL_ACTGRAD  C = (acc + b) * act'(.) taken from the POST-activation values aux1
+ *     RM_DENSE_ADD          C = acc + b (+ aux1 when not NULL)
+ *     RM_DENSE_CROSS        u = acc + b ; C = aux1 * u + aux2 ; C2 = u when not NULL
+ *                           (x_{l+1} = x0 o (W x_l + b) + x_l with aux1 = x0, aux2 = x_l)
+ *   filter_ws: rm_dense_filter_workspace(K1+K2, N) floats (the weights re-laid for the kernel).
+ * rm_dense_wgrad: dW[K1+K2, N] (+)= [A1 | A2]^T . G[M,N]  (reduction over the batch, split
+ *   into slabs + a deterministic second-stage sum); workspace: rm_dense_wgrad_workspace floats. */
+enum { RM_DENSE_BIAS_ACT = 0, RM_DENSE_MUL_ACTGRAD = 1, RM_DENSE_ADD = 2, RM_DENSE_CROSS = 3 };
+int64_t rm_dense_filter_workspace(int K, int N);
+int rm_dense_fwd(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2,
+                 const float *W, int64_t ldw, int w_transposed, int N, const float *bias, int epilogue,
+                 int act, const float *aux1, int64_t ld_aux1, const float *aux2, int64_t ld_aux2,
+                 int64_t M, float *C, int64_t ldc, float *C2, int64_t ldc2, float *filter_ws,
+                 rm_stream_t stream);
+int64_t rm_dense_wgrad_workspace(int K, int N, int64_t M);
+int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2,
+                   const float *G, int64_t ldg, int N, int64_t M, float *dW, int64_t lddw,
+                   int accumulate, float *workspace, int64_t workspace_floats, rm_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Multi-valued tag-list features (MultiValCsvFeat, inputs.py:380-425): the sqrtn-pooled
  * lookup tf.nn.embedding_lookup_sparse(..., combiner="sqrtn") of layers.py:144-169 and the
  * multi-hot linear input of utils.py:86-108.  CSR input: example b owns tag ids

@@ -9,7 +9,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librecman_hip.so")
+# RECMAN_HIP_LIB: load another build of the same library (kernel experiments); default in-tree
+LIB_PATH = os.environ.get("RECMAN_HIP_LIB") or os.path.join(_HERE, "csrc", "librecman_hip.so")
 
 
 class RecmanHipError(RuntimeError):
@@ -52,6 +53,9 @@ SIGNATURES = {
     "rm_pack_grad_rows": [P, P, P, P, I64, c_int, c_int, c_int, P, P],
     "rm_gather_rows": [P, P, I64, c_int, P, P],
     "rm_permute_rows": [P, P, I64, c_int, c_int, P, P],
+    "rm_dense_fwd": [P, I64, c_int, P, I64, c_int, P, I64, c_int, c_int, P, c_int, c_int, P, I64, P, I64,
+                     I64, P, I64, P, I64, P, P],
+    "rm_dense_wgrad": [P, I64, c_int, P, I64, c_int, P, I64, c_int, I64, P, I64, c_int, P, I64, P],
 }
 
 
@@ -61,6 +65,8 @@ SIGNATURES_I64 = {
     "rm_cin_bwd_workspace": [I64, c_int, c_int, c_int, c_int],
     "rm_mlp_bwd_workspace": [c_int, c_int],
     "rm_shard_route_workspace": [c_int],
+    "rm_dense_filter_workspace": [c_int, c_int],
+    "rm_dense_wgrad_workspace": [c_int, c_int, I64],
 }
 
 

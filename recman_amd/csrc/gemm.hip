@@ -1,0 +1,667 @@
+// Wide dense layers on the f32 MFMA (v_mfma_f32_32x32x2_f32) - the GEMMs of a DNN whose hidden
+// widths exceed the fused skinny-MLP kernel (mlp.hip): DCN's deep_hidden_units (400, 400), and
+// the matrix form of the cross layer  x_{l+1} = x0 o (W x_l + b) + x_l.
+// Replaces tf.matmul + bias + activation of DNN.__call__ (recman/tf/core/layers.py:594-602)
+// and the three GEMMs of its gradient.  hipBLASLt ran these shapes at 46-58 % of the f32 MFMA
+// peak and needed extra launches for the K=13 dense-input piece, the bias/activation and the
+// activation gradient; here x = [A1 | A2] is read in place and the epilogues are fused.
+//
+//   rm_dense_fwd   C[M,N]  = epilogue([A1 | A2][M,K] . op(W))      "NN": M = batch
+//   rm_dense_wgrad dW[K,N] = [A1 | A2]^T . G[M,N]                   "TN": reduction over batch
+//
+// NN kernel: block = 8 waves = 4 row groups x 2 column groups; a wave owns 32 rows x NT 32-column
+// blocks (NT <= 7: a 13-block N = 400 splits 7 + 6 over the two waves of one SIMD, so every SIMD
+// issues 13 MFMAs per k-step).  (4-wave blocks, two per CU, were slower: each weight chunk is
+// then staged for 64 rows instead of 128 and the 7/6 split unbalances the SIMDs.)  A is loaded straight into the MFMA operand layout (a lane reads
+// 16 B of its own row per 8 k), the weight chunk [16 k][cols] is staged in LDS, double-buffered,
+// pre-arranged by dense_prep_kernel so that a lane's NT operands are two ds_read_b128.
+// TN kernel: no LDS at all - both operands are row-contiguous along the MFMA's M / N index, so
+// every wave loads them coalesced (128 B per half-wave) in operand layout; the batch is split
+// into slabs, partial tiles go to a workspace and a second kernel reduces them (deterministic).
+#include <type_traits>
+
+#include "rm_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef RM_GEMM_KC
+#define RM_GEMM_KC 16
+#endif
+#ifndef RM_GEMM_SGB
+#define RM_GEMM_SGB 0
+#endif
+constexpr int KC = RM_GEMM_KC;               // k per staged weight chunk
+constexpr int kRowsPerBlock = 128;           // TN kernel: 4 row groups x 32 rows of K
+constexpr int kNNRows = 128;                 // NN kernel: 4 row groups x 32 batch rows per block
+constexpr int kNNThreads = 512;              // 8 waves = 2 per SIMD (one 7-block and one 6-block wave)
+constexpr int kMaxNB = 14;                   // 32-column blocks per column tile (2 x 7)
+constexpr int kTileCols = kMaxNB * 32;       // 448
+constexpr int WCH = KC * 2 * 2 * 32 * 4;     // floats per prepped chunk: [k][g][half][c][4] = 32 KB
+constexpr int kThreads = 512;
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == RM_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ float act_grad_from_out(float o, int act) {
+  if (act == RM_ACT_RELU) return o > 0.f ? 1.f : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return o > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+
+__device__ __forceinline__ bool rm_aligned16_dev(const void *p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+
+struct ColTile {
+  int nb, nt0;  // 32-col blocks in the tile; blocks of column group 0 (group 1 has nb - nt0)
+};
+__host__ __device__ inline ColTile col_tile(int N, int ct) {
+  const int nbt = (N + 31) / 32;
+  int nb = nbt - ct * kMaxNB;
+  nb = nb < kMaxNB ? nb : kMaxNB;
+  return ColTile{nb, (nb + 1) / 2};
+}
+
+// Wp[ct][chunk][k][g][half][c][j] = op(W)[chunk*16 + k][col(ct, g, nt = half*4 + j, c)], zero padded
+__global__ void dense_prep_kernel(const float *__restrict__ W, int64_t ldw, int trans, int K, int N,
+                                  int nch, int nct, float *__restrict__ Wp) {
+  const int64_t total = (int64_t)nct * nch * WCH;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int j = t & 3, c = (t >> 2) & 31, half = (t >> 7) & 1, g = (t >> 8) & 1, k = (t >> 9) & (KC - 1);
+    const int64_t chunk = t / WCH;
+    const int ch = (int)(chunk % nch), ct = (int)(chunk / nch);
+    const ColTile tl = col_tile(N, ct);
+    const int nt = half * 4 + j;
+    const int ntw = g == 0 ? tl.nt0 : tl.nb - tl.nt0;
+    const int col = ct * kTileCols + 32 * (g == 0 ? nt : tl.nt0 + nt) + c;
+    const int kk = ch * KC + k;
+    float v = 0.f;
+    if (nt < ntw && kk < K && col < N) v = trans ? W[(int64_t)col * ldw + kk] : W[(int64_t)kk * ldw + col];
+    Wp[t] = v;
+  }
+}
+
+struct NNArgs {
+  const float *A1, *A2;
+  int64_t lda1, lda2;
+  int K1, K2;
+  int a_vec;  // A1 rows are 16-byte aligned (float4 loads); otherwise every chunk loads per element
+  const float *Wp;
+  int N, nch;
+  const float *bias;
+  int epi, act;
+  const float *aux1, *aux2;
+  int64_t ld1, ld2;
+  int64_t M;
+  float *C, *C2;
+  int64_t ldc, ldc2;
+};
+
+// the lane's KC/8 float4 of A for chunk k0: k = k0 + 8q + 4h + e
+// fast: the whole chunk lies inside A1 (caller guarantees k0 + 16 <= K1)
+constexpr int AQ = KC / 8;  // float4 of A per lane per chunk
+__device__ __forceinline__ void load_a_fast(float4 (&v)[AQ], const NNArgs &a, int64_t row, int k0, int h) {
+#pragma unroll
+  for (int q = 0; q < AQ; ++q)
+    v[q] = *reinterpret_cast<const float4 *>(a.A1 + row * a.lda1 + k0 + 8 * q + 4 * h);
+}
+// tail: any chunk; per element A1 / A2 / zero by selects on clamped addresses - no branches, so
+// the 16 loads issue back to back (a second piece that does not exist aliases A1)
+__device__ __forceinline__ void load_a_tail(float4 (&v)[AQ], const NNArgs &a, int64_t row, int k0, int h) {
+  const float *A2 = a.K2 > 0 ? a.A2 : a.A1;
+  const int64_t lda2 = a.K2 > 0 ? a.lda2 : a.lda1;
+#pragma unroll
+  for (int q = 0; q < AQ; ++q) {
+    float t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + 8 * q + 4 * h + e;
+      const bool in1 = k < a.K1;
+      const int k2 = k - a.K1;
+      const bool in2 = !in1 && k2 < a.K2;
+      const float x1 = a.A1[row * a.lda1 + (in1 ? k : 0)];
+      const float x2 = A2[row * lda2 + (in2 ? k2 : 0)];
+      t[e] = in1 ? x1 : (in2 ? x2 : 0.f);
+    }
+    v[q] = make_float4(t[0], t[1], t[2], t[3]);
+  }
+}
+
+// One wave of the NN kernel with EXACTLY NT accumulators (no conditional MFMAs: a per-MFMA
+// `if (nt < ntw)` cost 16 branches per chunk and fenced the scheduler).  ntw <= NT is the number
+// of column blocks that really exist (the prepped weights of the others are zero).
+template <int NT>
+__device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int c, int h, int rg,
+                                        int cg, int ct, const ColTile tl, int ntw) {
+  const int64_t row0 = (int64_t)blockIdx.x * kNNRows + 32 * rg;
+  int64_t row = row0 + c;
+  row = row < a.M ? row : a.M - 1;
+  const float *Wp = a.Wp + (int64_t)ct * a.nch * WCH;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+  // prologue: chunk 0 of the weights to LDS, chunk 0 of A to registers
+  constexpr int WQ = WCH / 4 / kNNThreads;  // float4 of a weight chunk per thread (8)
+#pragma unroll
+  for (int q = 0; q < WQ; ++q)
+    *reinterpret_cast<float4 *>(Ws + (tid + q * kNNThreads) * 4) =
+        *reinterpret_cast<const float4 *>(Wp + (tid + q * kNNThreads) * 4);
+  float4 acur[AQ];
+  const int nfull = a.a_vec ? a.K1 / KC : 0;  // chunks inside A1 that float4 loads can take
+  if (nfull > 0) load_a_fast(acur, a, row, 0, h);
+  else load_a_tail(acur, a, row, 0, h);
+  __syncthreads();
+
+  // B operands of one k-step: the lane's NT weights = two ds_read_b128
+  auto read_b = [&](const float *Wb, int s, float4 &t0, float4 &t1) {
+    const int k = 8 * (s >> 2) + 4 * h + (s & 3);
+    const float *wp = Wb + ((k * 2 + cg) * 2) * 128 + c * 4;
+    t0 = *reinterpret_cast<const float4 *>(wp);
+    if constexpr (NT > 4) t1 = *reinterpret_cast<const float4 *>(wp + 128);
+  };
+  // one chunk: prefetch the next chunk (always - the last iteration re-loads its own chunk into
+  // the idle buffer: a conditional prefetch made hipcc park the registers in scratch behind an
+  // s_waitcnt vmcnt(0)), KC/2 k-steps of MFMAs with the B operands read one step ahead,
+  // commit the prefetch, barrier
+  auto chunk = [&](int ch, auto fast_next) {
+    const int nx = ch + 1 < a.nch ? ch + 1 : ch;
+    const float *wsrc = Wp + (int64_t)nx * WCH + tid * 4;
+    static_assert(WQ <= 8, "the prefetch below is written out for up to 8 float4 per thread");
+    // named registers: a float4 w[WQ] array captured by this lambda went to scratch
+#define RM_W(q) \
+  const float4 w##q = q < WQ ? *reinterpret_cast<const float4 *>(wsrc + (q < WQ ? q : 0) * kNNThreads * 4) : float4{}
+    RM_W(0); RM_W(1); RM_W(2); RM_W(3); RM_W(4); RM_W(5); RM_W(6); RM_W(7);
+#undef RM_W
+    float4 anext[AQ];
+    if constexpr (decltype(fast_next)::value) load_a_fast(anext, a, row, nx * KC, h);
+    else load_a_tail(anext, a, row, nx * KC, h);
+    // keep the prefetch HERE: without the fence the scheduler sinks the global loads to their
+    // first use (the ds_write at the end of the chunk) and the whole L2 latency is exposed
+    __builtin_amdgcn_sched_barrier(0);
+    const float *Wb = Ws + (ch & 1) * WCH;
+    float4 b0[2], b1[2];
+    read_b(Wb, 0, b0[0], b1[0]);
+#pragma unroll
+    for (int s = 0; s < KC / 2; ++s) {
+      if (s + 1 < KC / 2) read_b(Wb, s + 1, b0[(s + 1) & 1], b1[(s + 1) & 1]);
+      const float4 aq = acur[s >> 2];
+      const float av = (s & 3) == 0 ? aq.x : ((s & 3) == 1 ? aq.y : ((s & 3) == 2 ? aq.z : aq.w));
+      const float4 t0 = b0[s & 1], t1 = b1[s & 1];
+      const float bv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt], acc[nt], 0, 0, 0);
+      // emit "next step's LDS reads, then this step's MFMAs": left alone the scheduler reads
+      // just in time and every step starts with an exposed ds_read latency
+#if RM_GEMM_SGB
+      __builtin_amdgcn_sched_group_barrier(0x100, NT > 4 ? 2 : 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+#endif
+    }
+    float *wdst = Ws + ((ch + 1) & 1) * WCH + tid * 4;
+#define RM_W(q) \
+  if constexpr (q < WQ) *reinterpret_cast<float4 *>(wdst + q * kNNThreads * 4) = w##q
+    RM_W(0); RM_W(1); RM_W(2); RM_W(3); RM_W(4); RM_W(5); RM_W(6); RM_W(7);
+#undef RM_W
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) acur[q] = anext[q];
+    __syncthreads();
+  };
+  int ch = 0;
+  for (; ch + 1 < nfull; ++ch) chunk(ch, std::true_type{});   // next chunk also inside A1
+  for (; ch < a.nch; ++ch) chunk(ch, std::false_type{});      // next chunk is (or is past) the K tail
+
+  // ---- epilogue: one straight-line pass per column block - all aux loads of a block are
+  // issued before the first use and the epilogue kind is switched ONCE per wave.  (The first
+  // version tested a.epi per element: every element became load -> s_waitcnt vmcnt(0) ->
+  // store, which also drains the earlier stores - 22 % of the kernel.)
+  auto run = [&](auto epi_tag) {
+    constexpr int EPI = decltype(epi_tag)::value;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (nt >= ntw) continue;
+      const int col = ct * kTileCols + 32 * (cg == 0 ? nt : tl.nt0 + nt) + c;
+      const bool colok = col < a.N;
+      const int colc = colok ? col : a.N - 1;
+      const float bn = a.bias != nullptr ? a.bias[colc] : 0.f;
+      float x1[16], x2[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        rr = rr < a.M ? rr : a.M - 1;
+        if constexpr (EPI == RM_DENSE_MUL_ACTGRAD || EPI == RM_DENSE_CROSS) x1[r] = a.aux1[rr * a.ld1 + colc];
+        if constexpr (EPI == RM_DENSE_ADD) x1[r] = a.aux1 != nullptr ? a.aux1[rr * a.ld1 + colc] : 0.f;
+        if constexpr (EPI == RM_DENSE_CROSS) x2[r] = a.aux2[rr * a.ld2 + colc];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[nt][r] + bn;
+        const bool ok = colok && rr < a.M;
+        if constexpr (EPI == RM_DENSE_BIAS_ACT) v = act_apply(v, a.act);
+        if constexpr (EPI == RM_DENSE_MUL_ACTGRAD) v *= act_grad_from_out(x1[r], a.act);
+        if constexpr (EPI == RM_DENSE_ADD) v += x1[r];
+        if constexpr (EPI == RM_DENSE_CROSS) {
+          if (a.C2 != nullptr && ok) a.C2[rr * a.ldc2 + col] = v;  // u, kept for the backward
+          v = x1[r] * v + x2[r];
+        }
+        if (ok) a.C[rr * a.ldc + col] = v;
+      }
+    }
+  };
+  if (a.epi == RM_DENSE_BIAS_ACT) run(std::integral_constant<int, RM_DENSE_BIAS_ACT>{});
+  else if (a.epi == RM_DENSE_MUL_ACTGRAD) run(std::integral_constant<int, RM_DENSE_MUL_ACTGRAD>{});
+  else if (a.epi == RM_DENSE_ADD) run(std::integral_constant<int, RM_DENSE_ADD>{});
+  else run(std::integral_constant<int, RM_DENSE_CROSS>{});
+}
+
+// P0 / P1: accumulators of the waves of column group 0 / 1 (the two waves that share a SIMD):
+// (7,6) for a 13-block N = 400, (7,7) for 14 blocks, (n,n) otherwise.  Both bodies execute the
+// same number of barriers.
+template <int P0, int P1>
+__global__ __launch_bounds__(kNNThreads, 1) void dense_nn_kernel(NNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float Ws[];  // [2][WCH]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPR
+  const int c = lane & 31, h = lane >> 5, rg = wave & 3, cg = wave >> 2;
+  const int ct = blockIdx.y;
+  const ColTile tl = col_tile(a.N, ct);
+  if (cg == 0) nn_wave<P0>(a, Ws, tid, c, h, rg, 0, ct, tl, tl.nt0);
+  else nn_wave<P1>(a, Ws, tid, c, h, rg, 1, ct, tl, tl.nb - tl.nt0);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct TNArgs {
+  const float *A1, *A2;
+  int64_t lda1, lda2;
+  int K1, K2;
+  const float *G;
+  int64_t ldg;
+  int N;
+  int64_t M;
+  int slabs, kts;      // batch slabs, 128-row tiles of K
+  int kts_fast;        // K tiles [0, kts_fast) lie inside A1 with 16-byte rows (float4 staging)
+  int a_vec;           // A1 rows are 16-byte aligned and K1 % 4 == 0
+  int64_t slab_rows;   // multiple of TRC
+  float *ws;           // [slabs][K][N]
+};
+
+// TN: one block = 128 rows of K (4 row groups) x one column tile, one slab of the batch.  Per
+// chunk of 32 batch rows the A piece [32][128] and the G piece [32][cols] are staged in LDS with
+// wide coalesced loads (ONE global read per block; the first version let every wave load its
+// operands straight from global - 4x / 2x redundant dword loads, 70 % of the wave time in
+// s_waitcnt vmcnt) and all 8 waves read their MFMA operands from there (conflict-free b32).
+constexpr int TRC = 32;                         // batch rows per chunk
+constexpr int TLDA = kRowsPerBlock + 4;         // LDS row stride of the A piece (floats)
+constexpr int TLDG = kTileCols + 4;             // LDS row stride of the G piece
+constexpr int kTnSmemFloats = TRC * (TLDA + TLDG);
+constexpr int TAQ = TRC * kRowsPerBlock / 4 / kThreads;          // float4 of A per thread per chunk (2)
+constexpr int TGQ = (TRC * kTileCols / 4 + kThreads - 1) / kThreads;  // float4 of G per thread (7)
+
+// k-steps of one staged chunk; the B operands of step s+1 are read before the MFMAs of step s
+template <int NT>
+__device__ __forceinline__ void tn_compute(const float *As, const float *Gs, f32x16 (&acc)[NT], int c,
+                                           int h, int rg, int colb) {
+  const float *ap = As + h * TLDA + 32 * rg + c;
+  const float *gp = Gs + h * TLDG + colb + c;
+  float av[2], bv[2][NT];
+  av[0] = ap[0];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[0][nt] = gp[32 * nt];
+#pragma unroll
+  for (int s = 0; s < TRC / 2; ++s) {
+    if (s + 1 < TRC / 2) {
+      av[(s + 1) & 1] = ap[(2 * s + 2) * TLDA];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[(s + 1) & 1][nt] = gp[(2 * s + 2) * TLDG + 32 * nt];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][nt], acc[nt], 0, 0, 0);
+    // "next step's LDS reads, then this step's MFMAs" (left alone, hipcc read two operands,
+    // waited, issued two MFMAs, ... - an exposed LDS latency per pair of MFMAs)
+    __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+  }
+}
+
+// The whole wave program with exactly NT accumulators (both column groups run the same number
+// of barriers); colb = first column of this wave's group inside the tile.
+// FASTA: the block's A piece lies inside A1 with 16-byte rows; FASTG: G rows are 16-byte aligned
+// and N % 4 == 0 (float4 staging, 32-bit offsets from scalar row pointers); otherwise
+// per-element loads (the ragged last K tile: x = [A1 | A2] boundary and the end of K).
+// Staged values outside [K] x [N] need no zeroing: an MFMA output row / column depends only on
+// its own A row / B column, and those outputs are never stored.  Batch rows past the end ARE
+// zeroed (peeled last chunk).
+template <int NT, bool FASTA, bool FASTG>
+__device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, int c, int h, int rg,
+                                        int ntw, int colb, int slab, int kt) {
+  float *As = smem;                 // [TRC][TLDA]
+  float *Gs = smem + TRC * TLDA;    // [TRC][TLDG]
+  const int ct = blockIdx.y;
+  const int K = a.K1 + a.K2;
+  const int ka0 = kt * kRowsPerBlock, col0 = ct * kTileCols;
+  const int ncols = min(a.N - col0, kTileCols);  // real columns of this tile
+  const int64_t b_begin = (int64_t)slab * a.slab_rows;
+  int64_t b_end = b_begin + a.slab_rows;
+  b_end = b_end < a.M ? b_end : a.M;
+
+  // per-thread staging coordinates (constant over the chunks)
+  uint32_t offA[TAQ], offG[TGQ];
+  int ldsA[TAQ], ldsG[TGQ];
+#pragma unroll
+  for (int q = 0; q < TAQ; ++q) {
+    const int f = tid + q * kThreads, bl = f / (kRowsPerBlock / 4), k4 = f % (kRowsPerBlock / 4);
+    offA[q] = (uint32_t)(bl * (FASTA ? a.lda1 : 0)) + (uint32_t)(ka0 + 4 * k4);
+    ldsA[q] = bl * TLDA + 4 * k4;
+  }
+#pragma unroll
+  for (int q = 0; q < TGQ; ++q) {
+    const int f = tid + q * kThreads, bl = f / (kTileCols / 4), c4 = f % (kTileCols / 4);
+    const int n = 4 * c4 < ncols ? 4 * c4 : 0;  // columns past the tile: any in-bounds address
+    offG[q] = (uint32_t)(bl * a.ldg) + (uint32_t)(col0 + n);
+    ldsG[q] = bl * TLDG + 4 * c4;
+  }
+  const float *A2 = a.K2 > 0 ? a.A2 : a.A1;
+  const int64_t lda2 = a.K2 > 0 ? a.lda2 : a.lda1;
+
+  // staged values live in NAMED registers (float4 arrays captured by a lambda went to scratch)
+  static_assert(TAQ == 2 && TGQ == 7, "the staging below is written out for 2 + 7 float4 per thread");
+  float4 pa0, pa1, pg0, pg1, pg2, pg3, pg4, pg5, pg6;
+  auto load_a = [&](int q, uint32_t off, int64_t r0, int rows_left, bool full) -> float4 {
+    const int bl = (tid + q * kThreads) / (kRowsPerBlock / 4);
+    const bool rok = full || bl < rows_left;
+    float4 v;
+    if constexpr (FASTA) {
+      const float *Ap = a.A1 + r0 * a.lda1;  // wave-uniform row pointer
+      v = *reinterpret_cast<const float4 *>(Ap + (rok ? off : off - bl * (uint32_t)a.lda1));
+    } else {
+      // ragged K tile: columns from A1, from the second piece A2, or past the end of K (any
+      // finite value will do there - those output rows are never stored)
+      const int64_t b = r0 + (rok ? bl : 0);
+      const int k = (int)off;
+      float t1[4], t2[4];
+      if (a.a_vec) {  // A1 rows 16-byte aligned and K1 % 4 == 0: one float4 + 4 dwords of A2
+        const int kc = k < a.K1 ? k : a.K1 - 4;
+        const float4 v1 = *reinterpret_cast<const float4 *>(a.A1 + b * a.lda1 + kc);
+        t1[0] = v1.x; t1[1] = v1.y; t1[2] = v1.z; t1[3] = v1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t1[e] = a.A1[b * a.lda1 + (k + e < a.K1 ? k + e : 0)];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k2 = k + e - a.K1;
+        t2[e] = A2[b * lda2 + ((k2 >= 0 && k2 < a.K2) ? k2 : 0)];
+      }
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = k + e < a.K1 ? t1[e] : t2[e];
+      v = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    return rok ? v : make_float4(0.f, 0.f, 0.f, 0.f);  // batch rows past the end contribute 0
+  };
+  auto load_g = [&](int q, uint32_t off0, int64_t r0, int rows_left, bool full) -> float4 {
+    const int bl = (tid + q * kThreads) / (kTileCols / 4);
+    const bool rok = full || bl < rows_left;
+    const uint32_t off = rok ? off0 : off0 - bl * (uint32_t)a.ldg;
+    const float *Gp = a.G + r0 * a.ldg;
+    if constexpr (FASTG) {
+      return *reinterpret_cast<const float4 *>(Gp + off);
+    } else {
+      const int c4 = (tid + q * kThreads) % (kTileCols / 4);
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = Gp[off + ((4 * c4 + e < ncols) ? e : 0)];
+      return make_float4(t[0], t[1], t[2], t[3]);
+    }
+  };
+#define RM_TN_PREFETCH(r0_, full_)                                                          \
+  {                                                                                         \
+    const int64_t r0v = (r0_);                                                              \
+    const int rl = (int)(b_end - r0v);                                                      \
+    pa0 = load_a(0, offA[0], r0v, rl, full_); pa1 = load_a(1, offA[1], r0v, rl, full_);      \
+    pg0 = load_g(0, offG[0], r0v, rl, full_); pg1 = load_g(1, offG[1], r0v, rl, full_);      \
+    pg2 = load_g(2, offG[2], r0v, rl, full_); pg3 = load_g(3, offG[3], r0v, rl, full_);      \
+    pg4 = load_g(4, offG[4], r0v, rl, full_); pg5 = load_g(5, offG[5], r0v, rl, full_);      \
+    pg6 = load_g(6, offG[6], r0v, rl, full_);                                               \
+  }
+#define RM_TN_COMMIT()                                                                      \
+  {                                                                                         \
+    *reinterpret_cast<float4 *>(As + ldsA[0]) = pa0; *reinterpret_cast<float4 *>(As + ldsA[1]) = pa1; \
+    *reinterpret_cast<float4 *>(Gs + ldsG[0]) = pg0; *reinterpret_cast<float4 *>(Gs + ldsG[1]) = pg1; \
+    *reinterpret_cast<float4 *>(Gs + ldsG[2]) = pg2; *reinterpret_cast<float4 *>(Gs + ldsG[3]) = pg3; \
+    *reinterpret_cast<float4 *>(Gs + ldsG[4]) = pg4; *reinterpret_cast<float4 *>(Gs + ldsG[5]) = pg5; \
+    *reinterpret_cast<float4 *>(Gs + ldsG[6]) = pg6;                                        \
+  }
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  const bool rg_live = ka0 + 32 * rg < K;  // a row group past the end of K only helps staging
+
+  const int64_t nrows = b_end > b_begin ? b_end - b_begin : 0;
+  const int64_t nfull = nrows / TRC;  // full chunks; a partial one may follow
+  const bool partial = nrows % TRC != 0;
+  if (nfull > 0) RM_TN_PREFETCH(b_begin, true)
+  for (int64_t ci = 0; ci < nfull; ++ci) {
+    __syncthreads();  // previous chunk fully consumed
+    RM_TN_COMMIT()
+    __syncthreads();
+    // the next chunk's global loads fly during this chunk's MFMAs (unconditional: the last
+    // iteration re-loads its own chunk - a conditional prefetch parks the registers in scratch)
+    const int64_t nx = ci + 1 < nfull ? ci + 1 : ci;
+    RM_TN_PREFETCH(b_begin + nx * TRC, true)
+    __builtin_amdgcn_sched_barrier(0);
+    if (rg_live) tn_compute<NT>(As, Gs, acc, c, h, rg, colb);
+  }
+  if (partial) {  // the batch's ragged end (last slab only): rows past the end staged as zeros
+    RM_TN_PREFETCH(b_begin + nfull * TRC, false)
+    __syncthreads();
+    RM_TN_COMMIT()
+    __syncthreads();
+    if (rg_live) tn_compute<NT>(As, Gs, acc, c, h, rg, colb);
+  }
+  if (!rg_live) return;
+  float *out = a.ws + (int64_t)slab * K * a.N;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = col0 + colb + 32 * nt + c;
+    if (nt >= ntw || col >= a.N) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kr = ka0 + 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (kr < K) out[(int64_t)kr * a.N + col] = acc[nt][r];
+    }
+  }
+}
+
+#undef RM_TN_PREFETCH
+#undef RM_TN_COMMIT
+
+template <int P0, int P1, bool FASTG>
+__global__ __launch_bounds__(kThreads, 1) void dense_tn_kernel(TNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5, rg = wave & 3, cg = wave >> 2;
+  const ColTile tl = col_tile(a.N, blockIdx.y);
+  // XCD-aware order: the K tiles of one slab run next to each other on ONE XCD (they re-read
+  // the same G rows: 3 of 4 reads then hit that XCD's L2)
+  int64_t L = blockIdx.x;
+  const int64_t total = (int64_t)a.slabs * a.kts;
+  if (total % 8 == 0) L = (L % 8) * (total / 8) + L / 8;
+  const int slab = (int)(L / a.kts), kt = (int)(L % a.kts);
+  const bool fa = kt < a.kts_fast;  // block-uniform: this K tile lies inside A1 with 16-byte rows
+  const int ntw = cg == 0 ? tl.nt0 : tl.nb - tl.nt0, colb = cg == 0 ? 0 : 32 * tl.nt0;
+  if (cg == 0) {
+    if (fa) tn_wave<P0, true, FASTG>(a, smem, tid, c, h, rg, ntw, colb, slab, kt);
+    else tn_wave<P0, false, FASTG>(a, smem, tid, c, h, rg, ntw, colb, slab, kt);
+  } else {
+    if (fa) tn_wave<P1, true, FASTG>(a, smem, tid, c, h, rg, ntw, colb, slab, kt);
+    else tn_wave<P1, false, FASTG>(a, smem, tid, c, h, rg, ntw, colb, slab, kt);
+  }
+}
+
+// dW[k][n] (+)= sum_slab ws[slab][k][n]
+__global__ void dense_tn_reduce(const float *__restrict__ ws, int slabs, int64_t KN, int N, float *dW,
+                                int64_t lddw, int accumulate) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < KN;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int q = 0; q < slabs; ++q) s += ws[(int64_t)q * KN + t];
+    const int64_t k = t / N, n = t - k * N;
+    float *d = dW + k * lddw + n;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+int tn_slabs(int64_t M, int kts, int ncts) {
+  int64_t s = 256 / ((int64_t)kts * ncts);  // ONE round of blocks over the 256 CUs (1 block per CU)
+  const int64_t cap = (M + 511) / 512;            // at least 512 batch rows per slab
+  s = s < cap ? s : cap;
+  s = s < 1 ? 1 : s;
+  if (s >= 8) s = s / 8 * 8;  // multiple of 8 so the XCD remap applies
+  return (int)s;
+}
+
+}  // namespace
+
+extern "C" int64_t rm_dense_filter_workspace(int K, int N) {
+  if (K <= 0 || N <= 0) return 0;
+  const int nch = (K + KC - 1) / KC;
+  const int nct = ((N + 31) / 32 + kMaxNB - 1) / kMaxNB;
+  return (int64_t)nct * nch * WCH;
+}
+
+extern "C" int rm_dense_fwd(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2,
+                            const float *W, int64_t ldw, int w_transposed, int N, const float *bias,
+                            int epilogue, int act, const float *aux1, int64_t ld_aux1,
+                            const float *aux2, int64_t ld_aux2, int64_t M, float *C, int64_t ldc,
+                            float *C2, int64_t ldc2, float *filter_ws, rm_stream_t stream) {
+  RM_REQUIRE(M >= 0 && K1 > 0 && K2 >= 0 && N > 0, "rm_dense_fwd: bad sizes");
+  if (M == 0) return RM_OK;
+  RM_REQUIRE(A1 && W && C && filter_ws, "rm_dense_fwd: NULL argument");
+  RM_REQUIRE(K2 == 0 || A2, "rm_dense_fwd: K2 > 0 needs A2");
+  RM_REQUIRE(lda1 >= K1, "rm_dense_fwd: lda1 < K1");
+  RM_REQUIRE(K2 == 0 || lda2 >= K2, "rm_dense_fwd: lda2 < K2");
+  RM_REQUIRE(rm_aligned16(filter_ws), "rm_dense_fwd: filter_ws must be 16-byte aligned");
+  RM_REQUIRE(epilogue >= RM_DENSE_BIAS_ACT && epilogue <= RM_DENSE_CROSS, "rm_dense_fwd: bad epilogue id");
+  RM_REQUIRE(act >= RM_ACT_IDENTITY && act <= RM_ACT_LEAKY_RELU, "rm_dense_fwd: bad activation id");
+  RM_REQUIRE(epilogue != RM_DENSE_MUL_ACTGRAD || aux1, "rm_dense_fwd: MUL_ACTGRAD needs aux1");
+  RM_REQUIRE(epilogue != RM_DENSE_CROSS || (aux1 && aux2), "rm_dense_fwd: CROSS needs aux1 (x0) and aux2 (x_l)");
+  RM_REQUIRE(ldc >= N && (!aux1 || ld_aux1 >= N) && (!aux2 || ld_aux2 >= N) && (!C2 || ldc2 >= N),
+             "rm_dense_fwd: a leading dimension is smaller than N");
+  const int K = K1 + K2;
+  // K1 itself may be ragged only when there is no second piece (tail handled by the loader)
+  const int nch = (K + KC - 1) / KC;
+  const int nbt = (N + 31) / 32;
+  const int nct = (nbt + kMaxNB - 1) / kMaxNB;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dense_prep_kernel, dim3(rm_grid_cap(((int64_t)nct * nch * WCH + 255) / 256, 1024)),
+                     dim3(256), 0, st, W, ldw, w_transposed, K, N, nch, nct, filter_ws);
+  RM_CHECK_LAUNCH("rm_dense_fwd(prep)");
+  NNArgs a{A1, A2, lda1, lda2, K1, K2, (rm_aligned16(A1) && lda1 % 4 == 0) ? 1 : 0, filter_ws, N, nch, bias, epilogue, act, aux1, aux2,
+           ld_aux1, ld_aux2, M, C, C2, ldc, ldc2};
+  const dim3 grid((unsigned)((M + kNNRows - 1) / kNNRows), (unsigned)nct);
+  const size_t smem = 2 * WCH * sizeof(float);  // 128 KB: one block per CU
+  const int nb0 = nbt < kMaxNB ? nbt : kMaxNB;  // blocks of the widest (first) column tile
+#define RM_NN(P0, P1)                                                                         \
+  {                                                                                         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_nn_kernel<P0, P1>),      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);       \
+    hipLaunchKernelGGL((dense_nn_kernel<P0, P1>), grid, dim3(kNNThreads), smem, st, a);     \
+  }
+  if (nb0 <= 2) RM_NN(1, 1)
+  else if (nb0 <= 4) RM_NN(2, 2)
+  else if (nb0 <= 6) RM_NN(3, 3)
+  else if (nb0 <= 8) RM_NN(4, 4)
+  else if (nb0 <= 10) RM_NN(5, 5)
+  else if (nb0 <= 12) RM_NN(6, 6)
+  else if (nb0 == 13) RM_NN(7, 6)
+  else RM_NN(7, 7)
+#undef RM_NN
+  RM_CHECK_LAUNCH("rm_dense_fwd");
+  return RM_OK;
+}
+
+extern "C" int64_t rm_dense_wgrad_workspace(int K, int N, int64_t M) {
+  if (K <= 0 || N <= 0 || M <= 0) return 0;
+  const int kts = (K + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int nct = ((N + 31) / 32 + kMaxNB - 1) / kMaxNB;
+  return (int64_t)tn_slabs(M, kts, nct) * K * N;
+}
+
+extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2,
+                              int K2, const float *G, int64_t ldg, int N, int64_t M, float *dW,
+                              int64_t lddw, int accumulate, float *workspace, int64_t workspace_floats,
+                              rm_stream_t stream) {
+  RM_REQUIRE(M >= 0 && K1 > 0 && K2 >= 0 && N > 0, "rm_dense_wgrad: bad sizes");
+  RM_REQUIRE(A1 && G && dW && workspace, "rm_dense_wgrad: NULL argument");
+  RM_REQUIRE(K2 == 0 || A2, "rm_dense_wgrad: K2 > 0 needs A2");
+  RM_REQUIRE(lda1 >= K1 && (K2 == 0 || lda2 >= K2) && ldg >= N && lddw >= N,
+             "rm_dense_wgrad: a leading dimension is too small");
+  const int K = K1 + K2;
+  RM_REQUIRE(workspace_floats >= rm_dense_wgrad_workspace(K, N, M > 0 ? M : 1),
+             "rm_dense_wgrad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int kts = (K + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int nbt = (N + 31) / 32;
+  const int nct = (nbt + kMaxNB - 1) / kMaxNB;
+  const int slabs = M > 0 ? tn_slabs(M, kts, nct) : 0;
+  if (M > 0) {
+    int64_t slab_rows = (M + slabs - 1) / slabs;
+    slab_rows = (slab_rows + TRC - 1) / TRC * TRC;
+    const int nb0 = nbt < kMaxNB ? nbt : kMaxNB;
+    const size_t smem = kTnSmemFloats * sizeof(float);
+    // K tiles whose A piece lies inside A1 with 16-byte rows are staged with float4 loads, the
+    // ragged last tile per element (block-uniform branch); G likewise when its rows allow it
+    const bool g_fast = ldg % 4 == 0 && rm_aligned16(G) && (N % 4 == 0);
+    const bool a_al = lda1 % 4 == 0 && rm_aligned16(A1);
+    const int kts_fast = a_al ? K1 / kRowsPerBlock : 0;
+    RM_REQUIRE(slab_rows * (ldg > lda1 ? ldg : lda1) < ((int64_t)1 << 30),
+               "rm_dense_wgrad: rows too long for 32-bit slab offsets");
+    TNArgs a{A1, A2, lda1, lda2, K1, K2, G, ldg, N, M, slabs, kts, kts_fast, (a_al && K1 % 4 == 0 && K1 >= 4) ? 1 : 0,
+             slab_rows, workspace};
+    const dim3 grid((unsigned)(slabs * kts), (unsigned)nct);
+#define RM_TN(P0, P1, FAST_)                                                                      \
+  {                                                                                               \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_tn_kernel<P0, P1, FAST_>),     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);             \
+    hipLaunchKernelGGL((dense_tn_kernel<P0, P1, FAST_>), grid, dim3(kThreads), smem, st, a);      \
+  }
+#define RM_TN_DISPATCH(FAST_)                \
+  if (nb0 <= 2) RM_TN(1, 1, FAST_)           \
+  else if (nb0 <= 4) RM_TN(2, 2, FAST_)      \
+  else if (nb0 <= 6) RM_TN(3, 3, FAST_)      \
+  else if (nb0 <= 8) RM_TN(4, 4, FAST_)      \
+  else if (nb0 <= 10) RM_TN(5, 5, FAST_)     \
+  else if (nb0 <= 12) RM_TN(6, 6, FAST_)     \
+  else if (nb0 == 13) RM_TN(7, 6, FAST_)     \
+  else RM_TN(7, 7, FAST_)
+    if (g_fast) {
+      RM_TN_DISPATCH(true)
+    } else {
+      RM_TN_DISPATCH(false)
+    }
+#undef RM_TN_DISPATCH
+#undef RM_TN
+    RM_CHECK_LAUNCH("rm_dense_wgrad");
+  }
+  const int64_t KN = (int64_t)K * N;
+  hipLaunchKernelGGL(dense_tn_reduce, dim3(rm_grid_cap((KN + 255) / 256, 2048)), dim3(256), 0, st,
+                     workspace, slabs, KN, N, dW, lddw, accumulate);
+  RM_CHECK_LAUNCH("rm_dense_wgrad(reduce)");
+  return RM_OK;
+}

@@ -113,8 +113,9 @@ class MLP:
         self._B = None
         self._ws = None
         self._ones = None
-        # hand-written fused f32-MFMA path for skinny MLPs (csrc/mlp.hip); wider ones
-        # (DCN's [400,400]) are library GEMMs
+        # hand-written fused f32-MFMA path for skinny MLPs (csrc/mlp.hip); wider ones (DCN's
+        # [400,400]) and any MLP under dropout run layer by layer on the wide dense kernels
+        # (csrc/gemm.hip: bias / activation / activation-gradient fused, x = [xe | xd] in place)
         self.fused_ok = bool(FD % 4 == 0 and ops.mlp_supported(FD, Dn, self.hidden))
         self.fused = False
 
@@ -162,29 +163,31 @@ class MLP:
             xe = xe * m[:, : self.FD]
             xd = xd * m[:, self.FD:] if xd is not None else None
             self.xe, self.xd = xe, xd
+        self._alloc_dense(xe.device)
         for i in range(n):
             W, b = p[f"{pre}dnn_layer_{i}_weights"], p[f"{pre}dnn_layer_{i}_bias"]
             a = self.a[i]
-            fuse = a.shape[1] % 4 == 0  # bias + activation in one pass (rm_bias_act)
             if i == 0:
-                if fuse:
-                    torch.mm(xe, W[: self.FD], out=a)
-                else:
-                    torch.addmm(b, xe, W[: self.FD], out=a)
-                if xd is not None and self.Dn:
-                    a.addmm_(xd, W[self.FD:])
-            elif fuse:
-                torch.mm(self.a[i - 1], W, out=a)
+                ops.dense_fwd(xe, xd if self.Dn else None, W, a, self._fws, bias=b, act=self.act)
             else:
-                torch.addmm(b, self.a[i - 1], W, out=a)
-            if fuse:
-                ops.bias_act_(a, b, self.act)
-            else:
-                self._act_(a)
+                ops.dense_fwd(self.a[i - 1], None, W, a, self._fws, bias=b, act=self.act)
             if self.keep[i + 1] < 1 and self.masks[i + 1] is not None:
                 a.mul_(self.masks[i + 1] / self.keep[i + 1])
         ops.rowdot(self.a[-1], p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"], self.out.view(B))
         return self.out.view(B)
+
+    def _alloc_dense(self, device):
+        if getattr(self, "_fws", None) is not None and self._fws.device == device and self._wws_B == self._B:
+            return
+        dims = [self.FD + self.Dn] + self.hidden
+        fw = max(ops.dense_filter_workspace(max(dims[i], dims[i + 1]), max(dims[i], dims[i + 1]))
+                 for i in range(len(self.hidden)))
+        ww = max(ops.dense_wgrad_workspace(dims[i], dims[i + 1], self._B) for i in range(len(self.hidden)))
+        self._fws = torch.empty(fw, dtype=F32, device=device)
+        self._wws = torch.empty(max(ww, 1), dtype=F32, device=device)
+        self._wws_B = self._B
+        self._ws = torch.empty(256 * 1024, dtype=F32, device=device)
+        self._ones = torch.ones(self._B, dtype=F32, device=device)
 
     def backward(self, g, dxe, fm_sum=None):
         """g [B] = dLoss/dlogit; writes dLoss/dxe into dxe [B,FD] and the parameter
@@ -201,46 +204,44 @@ class MLP:
                         db=[gr[f"{pre}dnn_layer_{i}_bias"] for i in range(n)],
                         d_w_out=gr[f"{pre}dnn_w"].view(-1), d_w0_out=gr[f"{pre}dnn_w0"])
             return fm_sum is not None
-        g2 = g.view(-1, 1)
-        if self._ws is None or self._ws.device != g.device:
-            self._ws = torch.empty(256 * 1024, dtype=F32, device=g.device)
         ops.linear_dense_bwd(g, self.a[-1], gr[f"{pre}dnn_w"].view(-1), gr[f"{pre}dnn_w0"], self._ws)
+        # d(pre-activation of the last layer) = (g w_out^T) o mask o act'(a): a K = 1 GEMM whose
+        # epilogue applies the activation gradient (the mask multiplies in between)
         da = self.da[-1]
-        torch.mm(g2, p[f"{pre}dnn_w"].t(), out=da)
-        for i in range(n - 1, -1, -1):
-            a = self.a[i]
-            if self.keep[i + 1] < 1 and self.masks[i + 1] is not None:
-                # a holds the dropped activations; the mask is 0 where a was zeroed
-                da.mul_(self.masks[i + 1] / self.keep[i + 1])
+        last_drop = self.keep[n] < 1 and self.masks[n] is not None
+        ops.dense_fwd(g.view(-1, 1), None, p[f"{pre}dnn_w"], da, self._fws, transposed=True,
+                      epilogue=ops.DENSE_ADD if (last_drop or self.act == "identity") else ops.DENSE_MUL_ACTGRAD,
+                      act=self.act, aux1=None if (last_drop or self.act == "identity") else self.a[-1])
+        if last_drop:
+            da.mul_(self.masks[n] / self.keep[n])
             if self.act != "identity":
-                # act'(pre-activation) from the stored post-activation: same sign, and
-                # dropped positions (a == 0) already have da == 0
-                if (da.numel() % 4) == 0:
-                    ops.act_bwd_(da, a, self.act)
-                else:
-                    slope = _ACTS[self.act]
-                    da.mul_(torch.where(a > 0, 1.0, slope)) if slope else da.mul_(a > 0)
+                ops.act_bwd_(da, self.a[-1], self.act) if da.numel() % 4 == 0 else da.mul_(
+                    torch.where(self.a[-1] > 0, 1.0, _ACTS[self.act] or 0.0))
+        for i in range(n - 1, -1, -1):
             W = p[f"{pre}dnn_layer_{i}_weights"]
             gW = gr[f"{pre}dnn_layer_{i}_weights"]
             if da.shape[1] <= 1023:
-                if self._ones is None or self._ones.shape[0] != da.shape[0]:
-                    self._ones = torch.ones(da.shape[0], dtype=F32, device=da.device)
                 ops.linear_dense_bwd(self._ones, da, gr[f"{pre}dnn_layer_{i}_bias"], None, self._ws)
             else:
                 gr[f"{pre}dnn_layer_{i}_bias"].copy_(da.sum(0))
             if i == 0:
-                torch.mm(self.xe.t(), da, out=gW[: self.FD])
-                if self.xd is not None and self.Dn:
-                    torch.mm(self.xd.t(), da, out=gW[self.FD:])
-                # hipBLASLt's NN kernels run ~94 TFLOP/s here, its B-transposed ones ~71: feed the
-                # (small) weight pre-transposed
-                torch.mm(da, W[: self.FD].t().contiguous(), out=dxe)
+                ops.dense_wgrad(self.xe, self.xd if self.Dn else None, da, gW, self._wws)
+                # dLoss/dxe = da W[:FD]^T (the dense inputs need no gradient)
+                ops.dense_fwd(da, None, W[: self.FD], dxe, self._fws, transposed=True, epilogue=ops.DENSE_ADD)
                 if self.keep[0] < 1 and self.masks[0] is not None:
                     dxe.mul_(self.masks[0][:, : self.FD] / self.keep[0])
             else:
-                torch.mm(self.a[i - 1].t(), da, out=gW)
-                torch.mm(da, W.t().contiguous(), out=self.da[i - 1])
+                prev = self.a[i - 1]
+                ops.dense_wgrad(prev, None, da, gW, self._wws)
+                dropped = self.keep[i] < 1 and self.masks[i] is not None
+                # d(pre-activation of layer i-1) = (da W^T) o mask o act'(prev), act' from the stored
+                # post-activation values (dropped positions are zeroed by the mask)
+                ops.dense_fwd(da, None, W, self.da[i - 1], self._fws, transposed=True,
+                              epilogue=ops.DENSE_MUL_ACTGRAD if self.act != "identity" else ops.DENSE_ADD,
+                              act=self.act, aux1=prev if self.act != "identity" else None)
                 da = self.da[i - 1]
+                if dropped:
+                    da.mul_(self.masks[i] / self.keep[i])
         return False
 
     def l2(self, reg):

@@ -379,3 +379,71 @@ def bias_act_(x, bias, act):
 def act_bwd_(da, a, act):
     B, N = da.shape
     _lib.call("rm_act_bwd", _chk(da, "da", F32), _chk(a, "a", F32, (B, N)), B, N, ACT_IDS[act], _stream())
+
+
+# ---- wide dense layers (csrc/gemm.hip) -------------------------------------------------------
+DENSE_BIAS_ACT, DENSE_MUL_ACTGRAD, DENSE_ADD, DENSE_CROSS = 0, 1, 2, 3
+
+
+def _rows2d(t, name, allow_none=False):
+    """A 2-D f32 tensor with unit column stride -> (pointer, leading dimension, columns)."""
+    if t is None:
+        if allow_none:
+            return None, 0, 0
+        raise ValueError(f"{name} is required")
+    if t.dtype != F32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a 2-D float32 device tensor with unit column stride, got "
+                         f"{t.dtype} {tuple(t.shape)} strides {t.stride()}")
+    return t.data_ptr(), t.stride(0), t.shape[1]
+
+
+def dense_filter_workspace(K, N):
+    return int(_lib.lib().rm_dense_filter_workspace(int(K), int(N)))
+
+
+def dense_wgrad_workspace(K, N, M):
+    return int(_lib.lib().rm_dense_wgrad_workspace(int(K), int(N), int(M)))
+
+
+def dense_fwd(a1, a2, W, out, filter_ws, *, transposed=False, bias=None, epilogue=DENSE_BIAS_ACT,
+              act="identity", aux1=None, aux2=None, out2=None):
+    """out[M,N] = epilogue([a1 | a2] @ (W.T if transposed else W)) (rm_dense_fwd)."""
+    p1, lda1, K1 = _rows2d(a1, "a1")
+    p2, lda2, K2 = _rows2d(a2, "a2", allow_none=True)
+    M = a1.shape[0]
+    if a2 is not None and a2.shape[0] != M:
+        raise ValueError("a1 and a2 differ in rows")
+    pw, ldw, wc = _rows2d(W, "W")
+    K = K1 + K2
+    N = W.shape[0] if transposed else wc
+    if (wc if transposed else W.shape[0]) != K:
+        raise ValueError(f"W {tuple(W.shape)} does not match K={K} (transposed={transposed})")
+    pc, ldc, nc = _rows2d(out, "out")
+    if out.shape[0] != M or nc != N:
+        raise ValueError(f"out {tuple(out.shape)} must be [{M},{N}]")
+    px1, ld1, _ = _rows2d(aux1, "aux1", allow_none=True)
+    px2, ld2, _ = _rows2d(aux2, "aux2", allow_none=True)
+    pc2, ldc2, _ = _rows2d(out2, "out2", allow_none=True)
+    for t, nm in ((aux1, "aux1"), (aux2, "aux2"), (out2, "out2")):
+        if t is not None and tuple(t.shape) != (M, N):
+            raise ValueError(f"{nm} {tuple(t.shape)} must be [{M},{N}]")
+    if filter_ws.numel() < dense_filter_workspace(K, N):
+        raise ValueError("filter_ws too small (rm_dense_filter_workspace)")
+    _lib.call("rm_dense_fwd", p1, lda1, K1, p2, lda2, K2, pw, ldw, int(bool(transposed)), N,
+              _chk(bias, "bias", F32, (N,), allow_none=True), int(epilogue), ACT_IDS[act], px1, ld1, px2, ld2,
+              M, pc, ldc, pc2, ldc2, _chk(filter_ws, "filter_ws", F32), _stream())
+
+
+def dense_wgrad(a1, a2, G, dW, ws, accumulate=False):
+    """dW[K,N] (+)= [a1 | a2].T @ G (rm_dense_wgrad)."""
+    p1, lda1, K1 = _rows2d(a1, "a1")
+    p2, lda2, K2 = _rows2d(a2, "a2", allow_none=True)
+    pg, ldg, N = _rows2d(G, "G")
+    M = a1.shape[0]
+    if G.shape[0] != M or (a2 is not None and a2.shape[0] != M):
+        raise ValueError("a1 / a2 / G differ in rows")
+    pd, lddw, nd = _rows2d(dW, "dW")
+    if dW.shape[0] != K1 + K2 or nd != N:
+        raise ValueError(f"dW {tuple(dW.shape)} must be [{K1 + K2},{N}]")
+    _lib.call("rm_dense_wgrad", p1, lda1, K1, p2, lda2, K2, pg, ldg, N, M, pd, lddw, int(bool(accumulate)),
+              _chk(ws, "ws", F32), ws.numel(), _stream())

@@ -1,0 +1,163 @@
+"""GPU: the wide dense-layer kernels (rm_dense_fwd / rm_dense_wgrad, csrc/gemm.hip) against a
+float64 torch reference of the same op.  Tolerance: f32 accumulation over K (or over the
+batch for wgrad) - 2e-5 relative to the output scale."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_act(x, act):
+    if act == "relu":
+        return torch.relu(x)
+    if act == "leaky_relu":
+        return torch.nn.functional.leaky_relu(x, 0.2)
+    return x
+
+
+def _close(got, want, tol=2e-5, what=""):
+    want = want.to(torch.float64)
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got.detach().cpu().to(torch.float64) - want).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e})"
+
+
+SHAPES = [  # M, K1, K2, N
+    (37, 40, 3, 50),        # everything ragged, one column tile, NTMAX=2
+    (300, 416, 13, 400),    # DCN layer 0: x = [E | dense], 13 column blocks (7 + 6)
+    (129, 400, 0, 400),     # DCN layer 1, M tail of one row
+    (64, 429, 0, 429),      # matrix cross: K tail inside A1 (lda 432), 14 column blocks
+    (200, 64, 0, 900),      # three column tiles (14 + 14 + 1 blocks)
+    (70, 24, 5, 200),       # NTMAX=4
+]
+
+
+def _dev_padded(a1):
+    """Device copy of [M,K1] whose row stride is padded to a multiple of 4 floats."""
+    M, K1 = a1.shape
+    buf = torch.zeros(M, (K1 + 3) // 4 * 4, device="cuda")
+    buf[:, :K1] = a1.cuda()
+    return buf[:, :K1]
+
+
+def _inputs(M, K1, K2, N, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    lda1 = (K1 + 3) // 4 * 4
+    a1 = torch.randn(M, lda1, generator=g)[:, :K1]
+    a2 = torch.randn(M, K2, generator=g) if K2 else None
+    W = torch.randn(K1 + K2, N, generator=g) / (K1 + K2) ** 0.5
+    bias = torch.randn(N, generator=g)
+    return a1, a2, W, bias
+
+
+@pytest.mark.parametrize("M,K1,K2,N", SHAPES)
+@pytest.mark.parametrize("act", ["relu", "leaky_relu", "identity"])
+def test_dense_fwd_bias_act(hip_lib, M, K1, K2, N, act):
+    from recman_amd import ops
+
+    a1, a2, W, bias = _inputs(M, K1, K2, N)
+    x = torch.cat([a1] + ([a2] if a2 is not None else []), dim=1).double()
+    want = _ref_act(x @ W.double() + bias.double(), act)
+    a1d = _dev_padded(a1)
+    assert a1d.stride(0) % 4 == 0
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ws = torch.empty(ops.dense_filter_workspace(K1 + K2, N), device="cuda")
+    ops.dense_fwd(a1d, a2.cuda() if a2 is not None else None, W.cuda(), out, ws, bias=bias.cuda(), act=act)
+    _close(out, want, what="bias_act")
+    # op(W) = W^T given as [N, K]
+    out.fill_(float("nan"))
+    ops.dense_fwd(a1d, a2.cuda() if a2 is not None else None, W.t().contiguous().cuda(), out, ws,
+                  transposed=True, bias=bias.cuda(), act=act)
+    _close(out, want, what="bias_act, transposed W")
+
+
+@pytest.mark.parametrize("M,K1,K2,N", SHAPES[:4])
+def test_dense_fwd_other_epilogues(hip_lib, M, K1, K2, N):
+    from recman_amd import ops
+
+    a1, a2, W, bias = _inputs(M, K1, K2, N, seed=1)
+    g = torch.Generator().manual_seed(5)
+    aux1, aux2 = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    x = torch.cat([a1] + ([a2] if a2 is not None else []), dim=1).double()
+    z = x @ W.double()
+    a1d, a2d = _dev_padded(a1), (a2.cuda() if a2 is not None else None)
+    ws = torch.empty(ops.dense_filter_workspace(K1 + K2, N), device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    # dX of a hidden layer: (dh @ W^T) * act'(h) from the post-activation h
+    ops.dense_fwd(a1d, a2d, W.cuda(), out, ws, epilogue=ops.DENSE_MUL_ACTGRAD, act="leaky_relu",
+                  aux1=aux1.cuda())
+    _close(out, z * torch.where(aux1 > 0, 1.0, 0.2).double(), what="mul_actgrad")
+    ops.dense_fwd(a1d, a2d, W.cuda(), out, ws, epilogue=ops.DENSE_ADD, aux1=aux1.cuda())
+    _close(out, z + aux1.double(), what="add")
+    ops.dense_fwd(a1d, a2d, W.cuda(), out, ws, epilogue=ops.DENSE_ADD)
+    _close(out, z, what="plain")
+    # padded output / aux rows (ld > N)
+    outp = torch.zeros(M, N + 7, device="cuda")
+    u = torch.empty(M, N, device="cuda")
+    auxp = torch.zeros(M, N + 5)
+    auxp[:, :N] = aux1
+    ops.dense_fwd(a1d, a2d, W.cuda(), outp[:, :N], ws, bias=bias.cuda(), epilogue=ops.DENSE_CROSS,
+                  aux1=auxp.cuda()[:, :N], aux2=aux2.cuda(), out2=u)
+    uu = z + bias.double()
+    _close(u, uu, what="cross u")
+    _close(outp[:, :N], aux1.double() * uu + aux2.double(), what="cross")
+    assert float(outp[:, N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,K1,K2,N", SHAPES + [(5000, 416, 13, 400), (3, 8, 0, 8)])
+def test_dense_wgrad(hip_lib, M, K1, K2, N):
+    from recman_amd import ops
+
+    a1, a2, _, _ = _inputs(M, K1, K2, N, seed=2)
+    g = torch.Generator().manual_seed(7)
+    G = torch.randn(M, N, generator=g)
+    x = torch.cat([a1] + ([a2] if a2 is not None else []), dim=1).double()
+    want = x.t() @ G.double()
+    K = K1 + K2
+    ws = torch.empty(ops.dense_wgrad_workspace(K, N, M), device="cuda")
+    dW = torch.full((K, N), float("nan"), device="cuda")
+    a1d, a2d = _dev_padded(a1), (a2.cuda() if a2 is not None else None)
+    ops.dense_wgrad(a1d, a2d, G.cuda(), dW, ws)
+    _close(dW, want, tol=3e-5, what="wgrad")
+    first = dW.clone()
+    ops.dense_wgrad(a1d, a2d, G.cuda(), dW, ws)
+    assert torch.equal(dW, first)  # deterministic
+    ops.dense_wgrad(a1d, a2d, G.cuda(), dW, ws, accumulate=True)
+    _close(dW, 2 * want, tol=3e-5, what="wgrad accumulate")
+
+
+def test_dense_fwd_unaligned_rows_and_k1(hip_lib):
+    """Rows that are not 16-byte aligned (hidden width 30) and the K = 1 outer product of the
+    output projection's backward take the per-element loader."""
+    from recman_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(77, 30, generator=g)
+    W = torch.randn(30, 45, generator=g)
+    ws = torch.empty(ops.dense_filter_workspace(30, 45), device="cuda")
+    out = torch.empty(77, 45, device="cuda")
+    ops.dense_fwd(a.cuda(), None, W.cuda(), out, ws, act="relu")
+    _close(out, torch.relu(a.double() @ W.double()), what="unaligned rows")
+    gv, w = torch.randn(77, 1, generator=g), torch.randn(45, 1, generator=g)
+    h = torch.randn(77, 45, generator=g)
+    ops.dense_fwd(gv.cuda(), None, w.cuda(), out, ws, transposed=True, epilogue=ops.DENSE_MUL_ACTGRAD,
+                  act="relu", aux1=h.cuda())
+    _close(out, (gv.double() @ w.double().t()) * (h > 0).double(), what="K=1 outer product")
+
+
+def test_dense_argument_checks(hip_lib):
+    from recman_amd import ops
+    from recman_amd._lib import RecmanHipError
+
+    a = torch.randn(8, 8, device="cuda")
+    W = torch.randn(8, 8, device="cuda")
+    out = torch.empty(8, 8, device="cuda")
+    ws = torch.empty(ops.dense_filter_workspace(8, 8), device="cuda")
+    with pytest.raises(ValueError):
+        ops.dense_fwd(a, None, torch.randn(9, 8, device="cuda"), out, ws)
+    with pytest.raises(ValueError):
+        ops.dense_fwd(a, None, W, out, ws[:10])
+    with pytest.raises(RecmanHipError):
+        ops.dense_fwd(a, None, W, out, ws, epilogue=ops.DENSE_CROSS)  # needs aux1/aux2
+    with pytest.raises(RecmanHipError):
+        ops.dense_fwd(a, None, W, out, ws, epilogue=ops.DENSE_MUL_ACTGRAD)  # needs aux1
