@@ -418,10 +418,15 @@ __device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, i
     if constexpr (FASTG) {
       return *reinterpret_cast<const float4 *>(Gp + off);
     } else {
+      // per-element path (N % 4 != 0 or unaligned rows - typically a skinny G such as the 7
+      // coefficient columns of the cross-net gradients): lanes whose columns lie past the tile
+      // load nothing (their LDS slots feed only outputs that are never stored)
       const int c4 = (tid + q * kThreads) % (kTileCols / 4);
-      float t[4];
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+      if (4 * c4 < ncols) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = Gp[off + ((4 * c4 + e < ncols) ? e : 0)];
+        for (int e = 0; e < 4; ++e) t[e] = Gp[off + ((4 * c4 + e < ncols) ? e : 0)];
+      }
       return make_float4(t[0], t[1], t[2], t[3]);
     }
   };

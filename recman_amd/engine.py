@@ -739,6 +739,10 @@ class DCNEngine(Engine):
         self.cross_logit = torch.empty(B, dtype=F32, device=dev)
         self.cross_s = torch.empty(B, L, dtype=F32, device=dev)
         self.coef = torch.empty(B, 2 * L + 2, dtype=F32, device=dev)
+        self._coef_sum = torch.empty(2 * L + 2, dtype=F32, device=dev)
+        self._ones_b = torch.ones(B, dtype=F32, device=dev)
+        self._cross_wws = torch.empty(max(1, ops.dense_wgrad_workspace(self.FD + self.Dn, L + 1, B)),
+                                      dtype=F32, device=dev)
         self.P = torch.empty(self.FD + self.Dn, L + 1, dtype=F32, device=dev)
         self.dxe_dnn = torch.empty(B, self.FD, dtype=F32, device=dev)
 
@@ -769,10 +773,11 @@ class DCNEngine(Engine):
                       self.cross_s, self.d_rows.view(-1, self.FD), None, self.coef,
                       dx_in_e=self.dxe_dnn)
         L = self.L
-        torch.mm(xe.t(), self.coef[:, : L + 1], out=self.P[: self.FD])
-        if self.Dn:
-            torch.mm(xd.t(), self.coef[:, : L + 1], out=self.P[self.FD:])
-        colsum = self.coef[:, L + 1:].sum(0)
+        # P = x0^T coef[:, :L+1]: a batch-reduction GEMM with x0 = [xe | xd] read in place, and the
+        # column sums of coef in one pass (rm_linear_dense_bwd with unit weights)
+        ops.dense_wgrad(xe, xd if self.Dn else None, self.coef[:, : L + 1], self.P, self._cross_wws)
+        ops.linear_dense_bwd(self._ones_b, self.coef, self._coef_sum, None, self.ws)
+        colsum = self._coef_sum[L + 1:]
         ops.cross_param_grads(self.P, colsum, p["cross_w"], p["cross_b"],
                               p["cross_w_out"].view(-1), gr["cross_w"], gr["cross_b"],
                               gr["cross_w_out"].view(-1))
