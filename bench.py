@@ -14,6 +14,7 @@ embedding_l2_reg 0, weights N(0, 0.01), indices uniform over each field's vocabu
   deepfm  (default) configs[1]: 26 sparse x 1,000,001 rows + 13 dense, D=16, MLP (32,32) relu, B=65536
   xdeepfm           configs[2]: same inputs, CIN [128,128] leaky_relu, MLP (32,32) leaky_relu
   dcn               configs[3]: 6 vector cross layers + MLP [400,400] relu, B=131072
+  dcn_matrix        (extra)    : the same with matrix cross layers x0 o (W x_l + b) + x_l
 """
 import argparse
 import json
@@ -37,6 +38,10 @@ WORKLOADS = {
                             cin_cross_layer_units=(128, 128), cin_activation="leaky_relu")),
     "dcn": dict(model="dcn", B=131072, D=16, F=26, V=1_000_001, Dn=13,
                 hp=dict(deep_hidden_units=(400, 400), deep_activation="relu", cross_layer_num=6)),
+    # not a BASELINE config: the matrix form of the cross layers (x0 o (W x_l + b) + x_l), same shapes
+    "dcn_matrix": dict(model="dcn", B=131072, D=16, F=26, V=1_000_001, Dn=13,
+                       hp=dict(deep_hidden_units=(400, 400), deep_activation="relu", cross_layer_num=6,
+                               cross_type="matrix")),
 }
 
 
@@ -235,7 +240,9 @@ def main():
         "value": round(value, 1), "unit": "examples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{a.workload} (BASELINE configs[{1 + ['deepfm', 'xdeepfm', 'dcn'].index(a.workload)}])",
+        "config": {"workload": (f"{a.workload} (BASELINE configs[{1 + ['deepfm', 'xdeepfm', 'dcn'].index(a.workload)}])"
+                                if a.workload in ("deepfm", "xdeepfm", "dcn") else
+                                f"{a.workload} (extra workload, not a BASELINE config)"),
                    "batch_per_gpu": B, "batch_all_gpus": B * world, "sparse_fields": w["F"],
                    "rows_per_field": V,
                    "dense_fields": w["Dn"], "emb_dim": w["D"], "hp": {k: v for k, v in w["hp"].items()},

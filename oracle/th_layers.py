@@ -307,12 +307,18 @@ def cin_l2(p, n_layers, l2_reg):
 
 
 def cross_net(p, x0):
-    """CrossNet is ABSENT from the reference (DCN.py:7,134-137); DCN-v1 vector form,
-    arXiv 1708.05123 eq. (3): x_{l+1} = x0 * (x_l . w_l) + b_l + x_l; logit = x_L @ w_out."""
+    """CrossNet is ABSENT from the reference (DCN.py:7,134-137).  cross_w [L,d]: DCN-v1 vector
+    form, arXiv 1708.05123 eq. (3): x_{l+1} = x0 * (x_l . w_l) + b_l + x_l.  cross_w [L,d,d]: the
+    matrix form (DCN-v2, arXiv 2008.13535 eq. (1)): x_{l+1} = x0 o (W_l x_l + b_l) + x_l.
+    logit = x_L @ w_out."""
     x = x0
-    for l in range(p["cross_w"].shape[0]):
-        s = (x * p["cross_w"][l]).sum(dim=1, keepdim=True)
-        x = x0 * s + p["cross_b"][l] + x
+    W = p["cross_w"]
+    for l in range(W.shape[0]):
+        if W.dim() == 3:
+            x = x0 * (x @ W[l].t() + p["cross_b"][l]) + x
+        else:
+            s = (x * W[l]).sum(dim=1, keepdim=True)
+            x = x0 * s + p["cross_b"][l] + x
     return x @ p["cross_w_out"]
 
 

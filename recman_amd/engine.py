@@ -280,7 +280,7 @@ def init_reference(engine, seed=2019):
             b = math.sqrt(6.0 / (t.shape[0] + t.shape[1]))
             t.uniform_(-b, b, generator=g)
         elif name in ("cross_w",):
-            tn(t, t.shape[1], 1)
+            tn(t, t.shape[1], t.shape[2] if t.dim() == 3 else 1)
         elif name == "cross_w_out":
             tn(t, t.shape[0], 1)
         else:
@@ -715,7 +715,9 @@ class DCNEngine(Engine):
     """DCN._init_graph (DCN.py:99-144): dnn_input feeds the DNN and the CrossNet;
     final = dnn + cross (+ dnn again under strict_reference, DCN.py:140-142)
     (+ linear if use_linear).  CrossNet is absent from the reference (DCN.py:7):
-    DCN-v1 vector form, see csrc/cross.hip."""
+    cross_type "vector" = DCN-v1, x_{l+1} = x0 (x_l . w_l) + b_l + x_l, all layers fused in
+    csrc/cross.hip; cross_type "matrix" = x_{l+1} = x0 o (W_l x_l + b_l) + x_l, one f32-MFMA
+    GEMM per layer with the cross update as its epilogue (csrc/gemm.hip, RM_DENSE_CROSS)."""
 
     model = "dcn"
     use_bias_tables = False
@@ -729,7 +731,12 @@ class DCNEngine(Engine):
         dev = self.device
         self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
                        hp.get("deep_activation", "relu"), dev)
-        for nm, shape in (("cross_w", (self.L, d)), ("cross_b", (self.L, d)), ("cross_w_out", (d, 1))):
+        self.cross_type = hp.get("cross_type", "vector")
+        if self.cross_type not in ("vector", "matrix"):
+            raise ValueError(f"cross_type {self.cross_type!r}: 'vector' or 'matrix'")
+        self.matrix = self.cross_type == "matrix"
+        wshape = (self.L, d, d) if self.matrix else (self.L, d)
+        for nm, shape in (("cross_w", wshape), ("cross_b", (self.L, d)), ("cross_w_out", (d, 1))):
             self.params[nm] = torch.zeros(shape, dtype=F32, device=dev)
             self.grads[nm] = torch.zeros(shape, dtype=F32, device=dev)
 
@@ -745,6 +752,55 @@ class DCNEngine(Engine):
                                       dtype=F32, device=dev)
         self.P = torch.empty(self.FD + self.Dn, L + 1, dtype=F32, device=dev)
         self.dxe_dnn = torch.empty(B, self.FD, dtype=F32, device=dev)
+        if self.matrix:
+            # activations of the matrix cross: rows padded to a multiple of 4 floats (16-byte rows
+            # for the GEMM loaders); the pad columns stay zero
+            d = self.FD + self.Dn
+            dp = (d + 3) // 4 * 4
+            z = lambda: torch.zeros(B, dp, dtype=F32, device=dev)  # noqa: E731
+            self.cx = [z() for _ in range(L + 1)]   # x_0 .. x_L
+            self.cu = [z() for _ in range(L)]       # u_l = W_l x_l + b_l
+            self.cg = [z(), z()]                    # dLoss/dx_l, ping-pong
+            self.cdu, self.cdx0 = z(), z()
+            self.w_out_p = torch.zeros(dp, dtype=F32, device=dev)
+            self._dcol = torch.empty(dp, dtype=F32, device=dev)
+            self._cfws = torch.empty(ops.dense_filter_workspace(d, d), dtype=F32, device=dev)
+            self._cwws = torch.empty(max(1, ops.dense_wgrad_workspace(d, d, B)), dtype=F32, device=dev)
+
+    # ---- matrix cross (DCN-v2 form): one GEMM per layer, cross update in the epilogue ----
+    def _cross_matrix_fwd(self, xe, xd):
+        p, d = self.params, self.FD + self.Dn
+        x0 = self.cx[0]
+        x0[:, : self.FD].copy_(xe)
+        if self.Dn:
+            x0[:, self.FD: d].copy_(xd)
+        for l in range(self.L):
+            ops.dense_fwd(self.cx[l][:, :d], None, p["cross_w"][l], self.cx[l + 1][:, :d], self._cfws,
+                          transposed=True, bias=p["cross_b"][l], epilogue=ops.DENSE_CROSS,
+                          aux1=x0[:, :d], aux2=self.cx[l][:, :d], out2=self.cu[l][:, :d])
+        self.w_out_p[:d].copy_(p["cross_w_out"].view(-1))
+        ops.rowdot(self.cx[self.L], self.w_out_p, None, self.cross_logit)
+
+    def _cross_matrix_bwd(self, g):
+        p, gr, d, L = self.params, self.grads, self.FD + self.Dn, self.L
+        x0 = self.cx[0]
+        ops.linear_dense_bwd(g, self.cx[L], self._dcol, None, self.ws)  # d_w_out = x_L^T g
+        gr["cross_w_out"].view(-1).copy_(self._dcol[:d])
+        gc, gn = self.cg
+        torch.mul(g.view(-1, 1), self.w_out_p.view(1, -1), out=gc)  # dLoss/dx_L
+        self.cdx0.zero_()
+        for l in range(L - 1, -1, -1):
+            torch.mul(gc, x0, out=self.cdu)                 # dLoss/du_l = g_{l+1} o x0
+            self.cdx0.addcmul_(gc, self.cu[l])              # dLoss/dx0 += g_{l+1} o u_l
+            ops.dense_wgrad(self.cdu[:, :d], None, self.cx[l][:, :d], gr["cross_w"][l], self._cwws)
+            ops.linear_dense_bwd(self._ones_b, self.cdu, self._dcol, None, self.ws)
+            gr["cross_b"][l].copy_(self._dcol[:d])
+            # dLoss/dx_l = du_l W_l + g_{l+1}
+            ops.dense_fwd(self.cdu[:, :d], None, p["cross_w"][l], gn[:, :d], self._cfws,
+                          epilogue=ops.DENSE_ADD, aux1=gc[:, :d])
+            gc, gn = gn, gc
+        self.cdx0.add_(gc)
+        torch.add(self.cdx0[:, : self.FD], self.dxe_dnn, out=self.d_rows.view(-1, self.FD))
 
     def _branches_fwd(self, idx, dense, training, masks, lin_w):
         hp = self.hp
@@ -755,8 +811,11 @@ class DCNEngine(Engine):
         keep = list(hp.get("deep_dropout", [1] * (n + 1))) if training else [1] * (n + 1)
         self.dnn_logit = self.mlp.forward(xe, xd, keep, m.get("dnn"))
         p = self.params
-        ops.cross_fwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1),
-                      self.cross_logit, self.cross_s)
+        if self.matrix:
+            self._cross_matrix_fwd(xe, xd)
+        else:
+            ops.cross_fwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1),
+                          self.cross_logit, self.cross_s)
         branches = [(self.dnn_logit, self.dnn_coef), (self.cross_logit, 1.0)]
         if self.use_linear:
             branches.append((self.lin_logit, 1.0))
@@ -767,6 +826,10 @@ class DCNEngine(Engine):
         xe, xd = self.E.view(-1, self.FD), (dense if self.Dn else None)
         g_dnn = g if self.dnn_coef == 1.0 else g * self.dnn_coef
         self.mlp.backward(g_dnn, self.dxe_dnn)
+        if self.matrix:
+            self._cross_matrix_bwd(g)
+            self._cross_l2_grads()
+            return
         # cross backward adds the DNN's dx and writes straight into the row-gradient
         # buffer: with no FM term d_rows IS dLoss/dE (no separate embed_bwd launch)
         ops.cross_bwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1), g,
@@ -781,6 +844,29 @@ class DCNEngine(Engine):
         ops.cross_param_grads(self.P, colsum, p["cross_w"], p["cross_b"],
                               p["cross_w_out"].view(-1), gr["cross_w"], gr["cross_b"],
                               gr["cross_w_out"].view(-1))
+        self._cross_l2_grads()
+
+    def _dominant_kernel(self, idx, dense):
+        # the MLP GEMMs dominate the DCN step: layer 0 of the wide DNN, x = [xe | xd] -> H0
+        # (bias + activation fused), on the f32 MFMA roofline
+        if self.mlp.fused_ok:
+            return super()._dominant_kernel(idx, dense)
+        B = idx.shape[0]
+        self._embed(idx, dense, False, None)
+        xe, xd = self.E.view(-1, self.FD), (dense if self.Dn else None)
+        self.mlp.forward(xe, xd)
+        W, b = self.params["dnn_layer_0_weights"], self.params["dnn_layer_0_bias"]
+        m = self.mlp
+
+        def fn():
+            ops.dense_fwd(xe, xd, W, m.a[0], m._fws, bias=b, act=m.act)
+
+        K, N = W.shape
+        return (f"dense_nn_kernel (rm_dense_fwd, DNN layer 0: [{B},{K}] x [{K},{N}] + bias + {m.act})", fn,
+                2.0 * B * K * N, "mfma")
+
+    def _cross_l2_grads(self):
+        p, gr = self.params, self.grads
         reg = self.hp.get("deep_l2_reg", 0.0)
         if reg:
             self.mlp.add_l2_grads(reg)

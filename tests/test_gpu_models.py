@@ -273,3 +273,19 @@ def test_sparse_value_feature_through_fit_predict(hip_lib):
         keras_adam_cpu(p, g, state, t, 0.01)
     want1 = T.prediction(T.deepfm_logit(p, spec, idx, dense, hp, training=False, mv=mv)).numpy()
     assert np.abs(m.predict(df) - want1).max() < 2e-4
+
+
+def test_dcn_matrix_cross_trains_through_model_surface(hip_lib):
+    import recman_amd.th as th
+
+    df = ml_frame()
+    fd = ml_features(df)
+    m = th.DCN(fd, embedding_size=8, deep_dropout=(1, 1, 1), cross_layer_num=2, epoch=3, batch_size=128,
+               learning_rate=0.01, cross_type="matrix")
+    assert m._build().params["cross_w"].dim() == 3
+    before = log_loss(df["label"].values, m.predict(df).astype(np.float64))
+    m.fit(df, df["label"].values)
+    after = log_loss(df["label"].values, m.predict(df).astype(np.float64))
+    assert after < before
+    with pytest.raises(ValueError):
+        th.DCN(fd, cross_type="tensor")._build()
