@@ -58,6 +58,14 @@ def parse():
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent for indices (0 = uniform)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded engine even at world size 1 (rehearsal)")
+    ap.add_argument("--graph-sharded", action="store_true",
+                    help="EXPERIMENTAL: capture the row-sharded step (fixed-capacity exchange, RCCL calls "
+                         "included) in one hipGraph; off by default - a replayed RCCL all_to_all of "
+                         "100+ MB faulted on the one-GPU rehearsal box")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "fixed", "dynamic"],
+                    help="row-sharded exchange layout: fixed capacity (equal splits, no host sync, one "
+                         "hipGraph per step; falls back when a batch overflows) or dynamic split sizes; "
+                         "auto = fixed for uniform indices, dynamic for --zipf")
     return ap.parse_args()
 
 
@@ -175,7 +183,9 @@ def main():
     if sharded:
         from recman_amd import dist as rdist
 
-        engine = rdist.make_sharded_engine(w["model"], spec, w["D"], hp, dev, rank, world)
+        fixed = a.exchange == "fixed" or (a.exchange == "auto" and a.zipf == 0)
+        engine = rdist.make_sharded_engine(w["model"], spec, w["D"], hp, dev, rank, world,
+                                           capacity_factor=1.0 if fixed else None)
     else:
         engine = eng.ENGINES[w["model"]](spec, w["D"], hp, device=dev)
     init_engine(engine, 2019)
@@ -185,10 +195,27 @@ def main():
         return engine.fwd_bwd(idx, dense, y)
 
     # ---- optional hipGraph capture of the whole step (launch-bound otherwise) ----
-    use_graph = not a.no_graph and not sharded  # the exchange needs host-side split sizes
+    # (the dynamic exchange needs host-side split sizes and cannot be captured)
+    fixed = sharded and engine.st.capacity_factor is not None
+    use_graph = not a.no_graph and (not sharded or (fixed and a.graph_sharded))
     graph = None
     step()
     torch.cuda.synchronize()
+
+    def any_overflow():
+        """Fixed-capacity exchange only: did a batch on ANY rank exceed its bucket capacity?"""
+        if not fixed:
+            return False
+        hit = torch.tensor([1.0 if engine.overflowed() else 0.0], device=dev)
+        if dist is not None and world > 1:
+            dist.all_reduce(hit, op=dist.ReduceOp.MAX)
+        return bool(hit.item() > 0)
+
+    if any_overflow():  # skewed indices: the fixed layout does not fit, use exact split sizes
+        print("[bench] fixed-capacity exchange overflowed, using dynamic split sizes", file=sys.stderr)
+        engine.st.capacity_factor, engine._B, fixed, use_graph = None, None, False, False
+        step()
+        torch.cuda.synchronize()
     if use_graph:
         try:
             side = torch.cuda.Stream()
@@ -219,6 +246,8 @@ def main():
         run()
     barrier()
     elapsed = time.perf_counter() - t0
+    if any_overflow():
+        raise SystemExit("[bench] a timed batch overflowed the fixed-capacity exchange: rerun with --exchange dynamic")
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -249,7 +278,9 @@ def main():
                    "indices": "uniform" if a.zipf == 0 else f"zipf({a.zipf})",
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
                    "hipgraph": graph is not None,
-                   "table": f"row-sharded mod {world}, fused [D+4] rows, all_to_all over xGMI" if sharded
+                   "table": (f"row-sharded mod {world}, fused [D+4] rows, all_to_all over xGMI, "
+                             + ("fixed-capacity exchange (equal splits, no host sync)" if fixed
+                                else "dynamic split sizes (one host sync per batch)")) if sharded
                    else "single GPU"},
         "roofline": roof,
     }

@@ -325,6 +325,14 @@ int64_t rm_shard_route_workspace(int world);
 int rm_shard_route(const int64_t *idx, const int64_t *field_off, int64_t B, int F, int world,
                    int64_t *pos, int64_t *send_ids, int64_t *counts, int32_t *workspace,
                    rm_stream_t stream);
+/* Fixed-capacity variant: bucket w occupies slots [w*cap, (w+1)*cap) of pos / send_ids
+ * (send_ids has world*cap entries; unused slots hold -1, which rm_gather_rows answers with a
+ * zero row).  Every rank then exchanges equal splits: no count exchange, no host sync, and the
+ * whole step can be captured in one hipGraph.  A bucket that needs more than cap slots sets
+ * *overflow = 1 (sticky; the caller clears it) and the step's result must be discarded. */
+int rm_shard_route_padded(const int64_t *idx, const int64_t *field_off, int64_t B, int F, int world,
+                          int64_t cap, int64_t *pos, int64_t *send_ids, int64_t *counts,
+                          int32_t *overflow, int32_t *workspace, rm_stream_t stream);
 
 /* out[pos[o], :] = [d_rows[o, 0..D) | g_bias[b] | g_lin[b] | 0 ..] (width floats per row): the
  * per-occurrence gradient rows of the fused table rows, written straight in bucketed order
@@ -334,7 +342,7 @@ int rm_pack_grad_rows(const float *d_rows, const float *g_bias, const float *g_l
                       rm_stream_t stream);
 
 /* rows_out[i,:] = table[rows[i],:] for i < n (owner-side gather of the requested
- * local rows; width floats per row, width % 4 == 0). */
+ * local rows; width floats per row, width % 4 == 0); rows[i] < 0 gives a zero row. */
 int rm_gather_rows(const float *table, const int64_t *rows, int64_t n, int width,
                    float *rows_out, rm_stream_t stream);
 

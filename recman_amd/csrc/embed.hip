@@ -340,7 +340,8 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const int64_t i = t / G;
     const int sub = (int)(t - i * G);
-    out[t] = table[rows[i] * G + sub];
+    const int64_t r = rows[i];  // r < 0: an empty slot of the fixed-capacity exchange -> zero row
+    out[t] = r >= 0 ? table[r * G + sub] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 

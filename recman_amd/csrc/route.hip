@@ -81,10 +81,17 @@ __global__ void route_last_count_kernel(const int *__restrict__ cnt, int nblk, i
 __global__ __launch_bounds__(kBlock) void route_place_kernel(
     const int64_t *__restrict__ idx, const int64_t *__restrict__ field_off, int64_t n, int F, int W,
     int64_t per_block, const int *__restrict__ base /* [W][nblk] exclusive */,
-    int64_t *__restrict__ pos, int64_t *__restrict__ send_ids) {
+    int64_t *__restrict__ pos, int64_t *__restrict__ send_ids, int64_t cap,
+    int32_t *__restrict__ overflow) {
   __shared__ int run[kMaxW];          // running offset of each bucket within this block
   __shared__ int wcnt[kBlock / 64][kMaxW];
-  if (threadIdx.x < W) run[threadIdx.x] = base[threadIdx.x * gridDim.x + blockIdx.x];
+  // cap > 0 (fixed-capacity layout): bucket w starts at w*cap instead of at the packed offset
+  if (threadIdx.x < W) {
+    const int w = threadIdx.x;
+    int r = base[w * gridDim.x + blockIdx.x];
+    if (cap > 0) r = r - base[w * gridDim.x] + (int)(w * cap);
+    run[w] = r;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t o0 = (int64_t)blockIdx.x * per_block;
@@ -109,7 +116,11 @@ __global__ __launch_bounds__(kBlock) void route_place_kernel(
     if (valid) {
       int off = run[w];
       for (int v = 0; v < wave; ++v) off += wcnt[v][w];
-      const int64_t p = off + rank_in_wave;
+      int64_t p = off + rank_in_wave;
+      if (cap > 0 && p >= (int64_t)(w + 1) * cap) {  // bucket over capacity: flag it, stay in bounds
+        *overflow = 1;
+        p = (int64_t)(w + 1) * cap - 1;
+      }
       pos[o] = p;
       send_ids[p] = g / W;
     }
@@ -150,14 +161,15 @@ __global__ __launch_bounds__(kBlock) void pack_grad_rows_kernel(
 
 extern "C" int64_t rm_shard_route_workspace(int world) { return (int64_t)world * 1024 + 64; }
 
-extern "C" int rm_shard_route(const int64_t *idx, const int64_t *field_off, int64_t B, int F,
-                              int world, int64_t *pos, int64_t *send_ids, int64_t *counts,
-                              int32_t *workspace, rm_stream_t stream) {
+static int shard_route_impl(const int64_t *idx, const int64_t *field_off, int64_t B, int F, int world,
+                            int64_t cap, int64_t *pos, int64_t *send_ids, int64_t *counts,
+                            int32_t *overflow, int32_t *workspace, rm_stream_t stream) {
   RM_REQUIRE(B >= 0 && F > 0 && world >= 1 && world <= kMaxW, "rm_shard_route: bad sizes (world <= %d)", kMaxW);
   RM_REQUIRE(idx && field_off && pos && send_ids && counts && workspace, "rm_shard_route: NULL argument");
   const int64_t n = B * F;
-  RM_REQUIRE(n < (1ll << 31), "rm_shard_route: too many occurrences");
+  RM_REQUIRE(n < (1ll << 31) && cap * world < (1ll << 31), "rm_shard_route: too many occurrences");
   hipStream_t st = (hipStream_t)stream;
+  if (cap > 0) hipMemsetAsync(send_ids, 0xFF, sizeof(int64_t) * world * cap, st);  // empty slots: id -1
   if (n == 0) {
     hipMemsetAsync(counts, 0, sizeof(int64_t) * world, st);
     return RM_OK;
@@ -170,9 +182,24 @@ extern "C" int rm_shard_route(const int64_t *idx, const int64_t *field_off, int6
                      counts);
   hipLaunchKernelGGL(route_last_count_kernel, dim3(1), dim3(64), 0, st, workspace, nblk, world, n, counts);
   hipLaunchKernelGGL(route_place_kernel, dim3(nblk), dim3(kBlock), 0, st, idx, field_off, n, F, world,
-                     per_block, workspace, pos, send_ids);
+                     per_block, workspace, pos, send_ids, cap, overflow);
   RM_CHECK_LAUNCH("rm_shard_route");
   return RM_OK;
+}
+
+extern "C" int rm_shard_route(const int64_t *idx, const int64_t *field_off, int64_t B, int F,
+                              int world, int64_t *pos, int64_t *send_ids, int64_t *counts,
+                              int32_t *workspace, rm_stream_t stream) {
+  return shard_route_impl(idx, field_off, B, F, world, 0, pos, send_ids, counts, nullptr, workspace, stream);
+}
+
+extern "C" int rm_shard_route_padded(const int64_t *idx, const int64_t *field_off, int64_t B, int F,
+                                     int world, int64_t cap, int64_t *pos, int64_t *send_ids,
+                                     int64_t *counts, int32_t *overflow, int32_t *workspace,
+                                     rm_stream_t stream) {
+  RM_REQUIRE(cap > 0 && overflow, "rm_shard_route_padded: cap > 0 and an overflow flag are required");
+  return shard_route_impl(idx, field_off, B, F, world, cap, pos, send_ids, counts, overflow, workspace,
+                          stream);
 }
 
 extern "C" int rm_pack_grad_rows(const float *d_rows, const float *g_bias, const float *g_lin,

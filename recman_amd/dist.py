@@ -20,6 +20,16 @@ One step (one process per GPU, torch.distributed; backend "nccl" is RCCL over xG
 There is no collective in the dense compute; xGMI is a full mesh, so the all_to_all
 uses all 7 links of a GPU at once.
 
+Two exchange layouts:
+  dynamic (default)   exact split sizes: a count all_to_all + ONE host sync per batch
+  fixed capacity      every bucket has `cap` slots (cap = capacity_factor * n / W): equal
+                      splits, no count exchange, no host sync - the whole step (routing,
+                      RCCL calls, compute) replays as one hipGraph.  Unused slots carry id -1
+                      (zero rows).  A batch that needs more than cap slots for some rank sets
+                      a sticky device flag (`overflowed()`): its result must be discarded and
+                      redone with the dynamic layout.  Cyclic sharding keeps uniform / hashed
+                      ids within a few sigma of n/W; heavily skewed ids need the dynamic path.
+
 The routing/exchange logic below is device- and backend-agnostic torch code (it is the
 same on gloo/CPU, where tests/test_dist.py runs it with world_size 2); the row gather and
 routing are injected callables - HIP kernels in the product, plain torch indexing only in
@@ -41,29 +51,52 @@ def shard_rows(R, rank, world):
     return (R - rank + world - 1) // world
 
 
-def route_torch(idx, field_off, world):
+def route_torch(idx, field_off, world, cap=0):
     """Reference routing in plain torch (any device; what the CPU tests inject):
     idx [B,F], field_off [F] -> (pos [n], counts [world], send_ids [n]) with
     pos[o] = position of occurrence o in the owner-bucketed order (stable),
-    send_ids[pos[o]] = local row of occurrence o on its owner."""
+    send_ids[pos[o]] = local row of occurrence o on its owner.
+    cap > 0: fixed-capacity layout - bucket w owns slots [w*cap, (w+1)*cap), send_ids has
+    world*cap entries (-1 = empty); returns a 4th value, the overflow flag tensor."""
     g = (idx + field_off).reshape(-1)
     owner = g % world
     order = torch.argsort(owner, stable=True)
     counts = torch.bincount(owner, minlength=world)
     pos = torch.empty_like(order)
     pos[order] = torch.arange(g.numel(), device=g.device)
-    return pos, counts, (g // world)[order]
+    if not cap:
+        return pos, counts, (g // world)[order]
+    starts = torch.cumsum(counts, 0) - counts
+    rank_in = pos - starts[owner]
+    over = (rank_in >= cap).any().to(torch.int32).reshape(1)
+    ppos = owner * cap + torch.clamp(rank_in, max=cap - 1)
+    send = torch.full((world * cap,), -1, dtype=g.dtype, device=g.device)
+    send[ppos] = g // world
+    return ppos, counts, send, over
 
 
 class RowExchange:
     """The all_to_all plumbing of one batch: built once per batch from its indices, used
     for the forward row fetch and the backward gradient push."""
 
-    def __init__(self, idx, field_off, world, route_fn, group=None):
+    def __init__(self, idx, field_off, world, route_fn, group=None, cap=0):
         self.world, self.group = world, group
         self.n = idx.numel()
-        self.pos, counts, self.send_ids = route_fn(idx, field_off, world)
+        self.cap = int(cap)
         self.coll = world > 1 or (FORCE and dist.is_initialized())
+        if self.cap:
+            # fixed capacity: equal splits, nothing crosses to the host
+            self.pos, _, self.send_ids, self.overflow = route_fn(idx, field_off, world, self.cap)
+            self.slots = world * self.cap
+            self.send_counts = self.recv_counts = None
+            if self.coll:
+                self.recv_ids = torch.empty_like(self.send_ids)
+                dist.all_to_all_single(self.recv_ids, self.send_ids, group=group)
+            else:
+                self.recv_ids = self.send_ids
+            return
+        self.pos, counts, self.send_ids = route_fn(idx, field_off, world)
+        self.slots = self.n
         if self.coll:
             both = torch.empty(2, world, dtype=counts.dtype, device=counts.device)
             both[0].copy_(counts)
@@ -83,7 +116,7 @@ class RowExchange:
         [n, W] rows for this rank's occurrences in BUCKETED order: occurrence o is row pos[o]."""
         if not self.coll:
             return owner_rows
-        out = torch.empty(self.n, owner_rows.shape[1], dtype=owner_rows.dtype, device=owner_rows.device)
+        out = torch.empty(self.slots, owner_rows.shape[1], dtype=owner_rows.dtype, device=owner_rows.device)
         dist.all_to_all_single(out, owner_rows, self.send_counts, self.recv_counts, group=self.group)
         return out
 
@@ -101,9 +134,10 @@ class RowExchange:
 class ShardedTable:
     """This rank's shard [R_local, D+4] of the fused table + the lookup / gradient routing."""
 
-    def __init__(self, R, D, rank, world, device, gather_fn, route_fn, group=None):
+    def __init__(self, R, D, rank, world, device, gather_fn, route_fn, group=None, capacity_factor=None):
         self.R, self.D, self.W = R, D, D + PAD
         self.rank, self.world, self.group = rank, world, group
+        self.capacity_factor = capacity_factor  # None: dynamic split sizes
         self.shard = torch.zeros(shard_rows(R, rank, world), self.W, dtype=torch.float32, device=device)
         self.gather_fn, self.route_fn = gather_fn, route_fn
 
@@ -149,10 +183,19 @@ class ShardedTable:
     def lookup(self, idx, field_off):
         """idx [B,F] -> (rows [n, D+4] in BUCKETED order, the RowExchange): the row of
         occurrence o = b*F+f is rows[ex.pos[o]] - consumers gather through pos, no un-route copy."""
-        ex = RowExchange(idx, field_off, self.world, self.route_fn, self.group)
+        ex = RowExchange(idx, field_off, self.world, self.route_fn, self.group, self.capacity(idx.numel()))
         served = torch.empty(len(ex.recv_ids), self.W, dtype=torch.float32, device=self.shard.device)
         self.gather_fn(self.shard, ex.recv_ids, served)
         return ex.fetch(served), ex
+
+    def capacity(self, n):
+        """Slots per owner bucket for n occurrences (0 = dynamic layout): capacity_factor * n / W
+        plus 6 sigma of the binomial spread, rounded up to 64."""
+        if not self.capacity_factor:
+            return 0
+        mean = n / self.world
+        cap = self.capacity_factor * mean + 6.0 * (mean * (1 - 1 / self.world)) ** 0.5 + 1
+        return int(-(-cap // 64) * 64)
 
     def push_grads(self, ex, bucketed_grads):
         """bucketed_grads [n, D+4] (row pos[o] = gradient of occurrence o) -> (local row ids,
@@ -212,23 +255,29 @@ class HipRouter:
         self.device = device
         self._n = None
 
-    def __call__(self, idx, field_off, world):
+    def __call__(self, idx, field_off, world, cap=0):
         from . import ops
 
         n = idx.numel()
-        if self._n != (n, world):
-            self._n = (n, world)
+        if self._n != (n, world, cap):
+            self._n = (n, world, cap)
             self.pos = torch.empty(n, dtype=torch.int64, device=self.device)
-            self.ids = torch.empty(n, dtype=torch.int64, device=self.device)
+            self.ids = torch.empty(world * cap if cap else n, dtype=torch.int64, device=self.device)
             self.counts = torch.empty(world, dtype=torch.int64, device=self.device)
+            self.overflow = torch.zeros(1, dtype=torch.int32, device=self.device)  # sticky
             self.ws = torch.empty(ops._lib.lib().rm_shard_route_workspace(world), dtype=torch.int32,
                                   device=self.device)
+        if cap:
+            ops.shard_route_padded(idx, field_off, world, cap, self.pos, self.ids, self.counts,
+                                   self.overflow, self.ws)
+            return self.pos, self.counts, self.ids, self.overflow
         ops.shard_route(idx, field_off, world, self.pos, self.ids, self.counts, self.ws)
         return self.pos, self.counts, self.ids
 
 
-def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
-    """An engine whose embedding table is row-sharded over `world` ranks (bench.py --gpus N)."""
+def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, capacity_factor=None):
+    """An engine whose embedding table is row-sharded over `world` ranks (bench.py --gpus N).
+    capacity_factor: fixed-capacity exchange layout (hipGraph-capturable), see the module doc."""
     from . import engine as eng
 
     base = eng.ENGINES[model]
@@ -244,7 +293,8 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
         def _alloc_tables(self):
             dev = self.device
             R = self.spec.rows
-            self.st = ShardedTable(R, self.D, rank, world, dev, hip_gather, HipRouter(dev), group)
+            self.st = ShardedTable(R, self.D, rank, world, dev, hip_gather, HipRouter(dev), group,
+                                   capacity_factor)
             self.table = self.st.shard  # [R_local, D+4] fused rows
             self.linear_w_dense = torch.zeros(self.Dn, dtype=torch.float32, device=dev)
             self.field_off = torch.tensor(self.spec.offsets(), dtype=torch.int64, device=dev)
@@ -257,8 +307,8 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
             super()._alloc(B)
             if first:
                 self._zoff = torch.zeros(self.F, dtype=torch.int64, device=self.device)
-                self.grad_rows = torch.empty(B * self.F, self.D + PAD, dtype=torch.float32,
-                                             device=self.device)
+                slots = world * self.st.capacity(B * self.F) or B * self.F
+                self.grad_rows = torch.empty(slots, self.D + PAD, dtype=torch.float32, device=self.device)
 
         def _embed(self, idx, dense, want_fm, masks, lin_w=None):
             from . import ops
@@ -292,5 +342,15 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None):
             self.shard_grad_ids, self.shard_grad_rows = self.st.push_grads(self.ex, self.grad_rows)
             allreduce_dense(self.grads, world, group, self._flat_grads)
             return loss
+
+        def overflowed(self):
+            """True when a fixed-capacity batch did not fit (host sync; clears the flag): every
+            result since the last call must be discarded and redone with the dynamic layout."""
+            flag = getattr(self.st.route_fn, "overflow", None)
+            if flag is None or not self.st.capacity_factor:
+                return False
+            hit = bool(int(flag.item()))
+            flag.zero_()
+            return hit
 
     return Sharded()

@@ -303,14 +303,27 @@ def shard_route(idx, field_off, world, pos, send_ids, counts, workspace):
               _chk(counts, "counts", I64, (world,)), workspace.data_ptr(), _stream())
 
 
+def shard_route_padded(idx, field_off, world, cap, pos, send_ids, counts, overflow, workspace):
+    B, F = idx.shape
+    n = B * F
+    need = int(_lib.lib().rm_shard_route_workspace(world))
+    if workspace.dtype != torch.int32 or workspace.numel() < need:
+        raise ValueError(f"shard_route_padded: workspace must be int32 with >= {need} elements")
+    if overflow.dtype != torch.int32 or overflow.numel() < 1:
+        raise ValueError("shard_route_padded: overflow must be an int32 flag")
+    _lib.call("rm_shard_route_padded", _chk(idx, "idx", I64), _chk(field_off, "field_off", I64, (F,)), B, F,
+              world, int(cap), _chk(pos, "pos", I64, (n,)), _chk(send_ids, "send_ids", I64, (world * cap,)),
+              _chk(counts, "counts", I64, (world,)), overflow.data_ptr(), workspace.data_ptr(), _stream())
+
+
 def pack_grad_rows(d_rows, g_bias, g_lin, pos, out):
     B, F, D = d_rows.shape
     n, width = out.shape
-    if n != B * F:
-        raise ValueError("pack_grad_rows: out must have B*F rows")
+    if n < B * F:
+        raise ValueError("pack_grad_rows: out must have at least B*F rows")
     _lib.call("rm_pack_grad_rows", _chk(d_rows, "d_rows", F32),
               _chk(g_bias, "g_bias", F32, (B,), allow_none=True),
-              _chk(g_lin, "g_lin", F32, (B,), allow_none=True), _chk(pos, "pos", I64, (n,)), B, F, D,
+              _chk(g_lin, "g_lin", F32, (B,), allow_none=True), _chk(pos, "pos", I64, (B * F,)), B, F, D,
               width, _chk(out, "out", F32), _stream())
 
 

@@ -11,7 +11,7 @@ from recman_amd import dist as rd
 
 
 def cpu_gather(table, rows, out):
-    out.copy_(table[rows])
+    out.copy_(table[rows.clamp(min=0)] * (rows >= 0).unsqueeze(1))  # id -1 = empty slot -> zero row
 
 
 ZOFF = torch.zeros(1, dtype=torch.int64)
@@ -120,6 +120,63 @@ def _worker(rank, world, port, R, D, n):
         assert torch.allclose(gd["b"], torch.full((3,), mean)) and torch.allclose(gd["a"], torch.full((2, 2), 10 * mean))
     finally:
         dist.destroy_process_group()
+
+
+def test_fixed_capacity_routing_matches_dynamic_and_flags_overflow():
+    """The fixed-capacity layout: every occurrence at owner*cap + its rank inside the bucket,
+    empty slots id -1; a bucket that does not fit raises the overflow flag."""
+    g = torch.Generator().manual_seed(5)
+    world, R = 4, 4000
+    rows = torch.randint(0, R, (1000,), generator=g)
+    st = rd.ShardedTable(R, 4, 0, world, "cpu", cpu_gather, rd.route_torch, capacity_factor=1.2)
+    cap = st.capacity(1000)
+    assert cap % 64 == 0 and cap >= 300
+    pos, counts, send, over = rd.route_torch(rows.view(-1, 1), ZOFF, world, cap)
+    assert int(over) == 0 and send.numel() == world * cap
+    assert torch.equal(pos // cap, rows % world)              # right bucket
+    assert torch.equal(send[pos], rows // world)              # right local row
+    assert int((send >= 0).sum()) == len(torch.unique(pos)) == 1000
+    dpos, dcounts, dsend = rd.route_torch(rows.view(-1, 1), ZOFF, world)
+    starts = torch.cumsum(dcounts, 0) - dcounts
+    assert torch.equal(pos % cap, dpos - starts[rows % world])  # same order inside each bucket
+    skew = torch.zeros(1000, dtype=torch.int64)                # every occurrence on rank 0
+    _, _, _, over = rd.route_torch(skew.view(-1, 1), ZOFF, world, cap)
+    assert int(over) == 1
+
+
+def _worker_padded(rank, world, port, R, D, n):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.randn(R, D, generator=torch.Generator().manual_seed(123))
+        st = rd.ShardedTable(R, D, rank, world, "cpu", cpu_gather, rd.route_torch, capacity_factor=1.3)
+        st.load_global(full)
+        all_rows = [torch.randint(0, R, (n,), generator=torch.Generator().manual_seed(10 + r))
+                    for r in range(world)]
+        rows = all_rows[rank]
+        buck, ex = st.lookup(rows.view(-1, 1), ZOFF)
+        assert ex.cap > 0 and buck.shape[0] == world * ex.cap and int(ex.overflow) == 0
+        assert torch.equal(buck[ex.pos][:, :D], full[rows]), "padded lookup mismatch"
+        grads = [torch.cat([full[rw] * (r + 1), torch.ones(len(rw), rd.PAD)], 1) for r, rw in enumerate(all_rows)]
+        bucketed = torch.full((world * ex.cap, D + rd.PAD), float("nan"))  # empty slots: never read
+        bucketed[ex.pos] = grads[rank]
+        ids, grows = st.push_grads(ex, bucketed)
+        live = ids >= 0
+        mine = torch.zeros(st.shard.shape[0], D + rd.PAD, dtype=torch.float64).index_add_(
+            0, ids[live], grows[live].double())
+        want = torch.zeros(R, D + rd.PAD, dtype=torch.float64)
+        for rw, gr in zip(all_rows, grads):
+            want.index_add_(0, rw, gr.double())
+        assert torch.allclose(mine, want[rank::world], atol=1e-9), "padded gradient push mismatch"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_fixed_capacity_exchange(world):
+    port = 29640 + world
+    mp.spawn(_worker_padded, args=(world, port, 501, 4, 200), nprocs=world, join=True)
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -344,3 +344,34 @@ def test_dcn_matrix_cross_fwd_bwd_matches_oracle(hip_lib, B, L, use_linear):
     assert {"cross_w", "cross_b", "cross_w_out"} <= set(grads)
     logit_i, _ = e.forward(idx.cuda(), dense.cuda(), training=False)
     _close(logit_i, logit_o, rtol=0, atol=1e-5, what="inference logit")
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_shard_route_padded_matches_torch_reference(hip_lib, world):
+    """rm_shard_route_padded: fixed-capacity buckets, -1 in empty slots, sticky overflow flag."""
+    from recman_amd import dist as rd
+
+    g = torch.Generator().manual_seed(world)
+    B, F = 777, 5
+    idx = torch.randint(0, 5000, (B, F), generator=g)
+    foff = torch.arange(F) * 5000
+    r = rd.HipRouter("cuda")
+    st = rd.ShardedTable(25000, 8, 0, world, "cuda", rd.hip_gather, r, capacity_factor=1.1)
+    cap = st.capacity(B * F)
+    pos_t, counts_t, send_t, over_t = rd.route_torch(idx, foff, world, cap)
+    pos, counts, send, over = r(idx.cuda(), foff.cuda(), world, cap)
+    torch.cuda.synchronize()
+    assert int(over.item()) == int(over_t) == 0
+    assert torch.equal(pos.cpu(), pos_t) and torch.equal(send.cpu(), send_t)
+    assert torch.equal(counts.cpu(), counts_t)
+    # gather answers the empty slots with zero rows
+    table = torch.randn(25000 // world + 1, 12, generator=g).cuda()
+    out = torch.empty(world * cap, 12, device="cuda")
+    rd.hip_gather(table, send, out)
+    empty = (send < 0).cpu()
+    assert float(out.cpu()[empty].abs().max() if empty.any() else 0.0) == 0.0
+    assert torch.equal(out.cpu()[~empty], table.cpu()[send_t[~empty]])
+    if world > 1:  # too small a capacity: flagged, positions stay in bounds
+        pos2, _, send2, over2 = r(idx.cuda(), foff.cuda(), world, 64)
+        torch.cuda.synchronize()
+        assert int(over2.item()) == 1 and int(pos2.max()) < world * 64
