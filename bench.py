@@ -62,6 +62,9 @@ def parse():
                     help="EXPERIMENTAL: capture the row-sharded step (fixed-capacity exchange, RCCL calls "
                          "included) in one hipGraph; off by default - a replayed RCCL all_to_all of "
                          "100+ MB faulted on the one-GPU rehearsal box")
+    ap.add_argument("--micro-batches", type=int, default=0,
+                    help="row-sharded engine: pipeline the step over this many micro-batches so the "
+                         "all_to_alls overlap the compute (0 = auto: 2 when N > 1, else 1)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "fixed", "dynamic"],
                     help="row-sharded exchange layout: fixed capacity (equal splits, no host sync, one "
                          "hipGraph per step; falls back when a batch overflows) or dynamic split sizes; "
@@ -184,8 +187,9 @@ def main():
         from recman_amd import dist as rdist
 
         fixed = a.exchange == "fixed" or (a.exchange == "auto" and a.zipf == 0)
+        micro = a.micro_batches or (2 if world > 1 else 1)
         engine = rdist.make_sharded_engine(w["model"], spec, w["D"], hp, dev, rank, world,
-                                           capacity_factor=1.0 if fixed else None)
+                                           capacity_factor=1.0 if fixed else None, micro_batches=micro)
     else:
         engine = eng.ENGINES[w["model"]](spec, w["D"], hp, device=dev)
     init_engine(engine, 2019)
@@ -280,7 +284,8 @@ def main():
                    "hipgraph": graph is not None,
                    "table": (f"row-sharded mod {world}, fused [D+4] rows, all_to_all over xGMI, "
                              + ("fixed-capacity exchange (equal splits, no host sync)" if fixed
-                                else "dynamic split sizes (one host sync per batch)")) if sharded
+                                else "dynamic split sizes (one host sync per batch)")
+                             + f", {engine.micro_batches} micro-batch(es) per step") if sharded
                    else "single GPU"},
         "roofline": roof,
     }

@@ -111,24 +111,28 @@ class RowExchange:
             self.send_counts = self.recv_counts = [self.n]
             self.recv_ids = self.send_ids
 
-    def fetch(self, owner_rows):
+    def fetch(self, owner_rows, async_op=False):
         """owner_rows [len(recv_ids), W]: the rows this rank serves, in recv_ids order ->
-        [n, W] rows for this rank's occurrences in BUCKETED order: occurrence o is row pos[o]."""
+        [n, W] rows for this rank's occurrences in BUCKETED order: occurrence o is row pos[o].
+        async_op: returns (rows, work) - the caller calls work.wait() before it reads the rows,
+        and whatever it enqueues in between overlaps the exchange."""
         if not self.coll:
-            return owner_rows
+            return (owner_rows, None) if async_op else owner_rows
         out = torch.empty(self.slots, owner_rows.shape[1], dtype=owner_rows.dtype, device=owner_rows.device)
-        dist.all_to_all_single(out, owner_rows, self.send_counts, self.recv_counts, group=self.group)
-        return out
+        work = dist.all_to_all_single(out, owner_rows, self.send_counts, self.recv_counts, group=self.group,
+                                      async_op=async_op)
+        return (out, work) if async_op else out
 
-    def push(self, bucketed_rows):
+    def push(self, bucketed_rows, async_op=False):
         """bucketed_rows [n, W] (this rank's per-occurrence gradient rows in bucketed order)
         -> [len(recv_ids), W]: the gradient rows for the local rows recv_ids of this shard."""
         if not self.coll:
-            return bucketed_rows
+            return (bucketed_rows, None) if async_op else bucketed_rows
         out = torch.empty(len(self.recv_ids), bucketed_rows.shape[1], dtype=bucketed_rows.dtype,
                           device=bucketed_rows.device)
-        dist.all_to_all_single(out, bucketed_rows, self.recv_counts, self.send_counts, group=self.group)
-        return out
+        work = dist.all_to_all_single(out, bucketed_rows, self.recv_counts, self.send_counts,
+                                      group=self.group, async_op=async_op)
+        return (out, work) if async_op else out
 
 
 class ShardedTable:
@@ -183,10 +187,24 @@ class ShardedTable:
     def lookup(self, idx, field_off):
         """idx [B,F] -> (rows [n, D+4] in BUCKETED order, the RowExchange): the row of
         occurrence o = b*F+f is rows[ex.pos[o]] - consumers gather through pos, no un-route copy."""
+        ex = self.lookup_start(idx, field_off)
+        return self.lookup_finish(ex), ex
+
+    def lookup_start(self, idx, field_off):
+        """Routes, exchanges the ids, gathers this shard's rows and STARTS the row exchange; what
+        the caller enqueues before lookup_finish(ex) runs while the rows travel."""
         ex = RowExchange(idx, field_off, self.world, self.route_fn, self.group, self.capacity(idx.numel()))
         served = torch.empty(len(ex.recv_ids), self.W, dtype=torch.float32, device=self.shard.device)
         self.gather_fn(self.shard, ex.recv_ids, served)
-        return ex.fetch(served), ex
+        ex.served = served  # keeps the send buffer alive until the exchange is done
+        ex.rows, ex.rows_work = ex.fetch(served, async_op=True)
+        return ex
+
+    def lookup_finish(self, ex):
+        if ex.rows_work is not None:
+            ex.rows_work.wait()  # the current stream waits; the host does not
+            ex.rows_work = None
+        return ex.rows
 
     def capacity(self, n):
         """Slots per owner bucket for n occurrences (0 = dynamic layout): capacity_factor * n / W
@@ -249,11 +267,15 @@ def hip_gather(table, rows, out):
 
 
 class HipRouter:
-    """rm_shard_route with its buffers (counting sort by owner on the GPU)."""
+    """rm_shard_route with its buffers (counting sort by owner on the GPU).  The outputs rotate
+    through `ring` buffer sets: with micro-batching the routing of batch c+1 is computed while
+    batch c still reads its own pos / ids."""
 
-    def __init__(self, device):
+    def __init__(self, device, ring=1):
         self.device = device
+        self.ring = max(1, int(ring))
         self._n = None
+        self._turn = 0
 
     def __call__(self, idx, field_off, world, cap=0):
         from . import ops
@@ -261,12 +283,15 @@ class HipRouter:
         n = idx.numel()
         if self._n != (n, world, cap):
             self._n = (n, world, cap)
-            self.pos = torch.empty(n, dtype=torch.int64, device=self.device)
-            self.ids = torch.empty(world * cap if cap else n, dtype=torch.int64, device=self.device)
-            self.counts = torch.empty(world, dtype=torch.int64, device=self.device)
-            self.overflow = torch.zeros(1, dtype=torch.int32, device=self.device)  # sticky
+            dev = self.device
+            self._sets = [(torch.empty(n, dtype=torch.int64, device=dev),
+                           torch.empty(world * cap if cap else n, dtype=torch.int64, device=dev),
+                           torch.empty(world, dtype=torch.int64, device=dev)) for _ in range(self.ring)]
+            self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)  # sticky
             self.ws = torch.empty(ops._lib.lib().rm_shard_route_workspace(world), dtype=torch.int32,
-                                  device=self.device)
+                                  device=dev)
+        self._turn = (self._turn + 1) % self.ring
+        self.pos, self.ids, self.counts = self._sets[self._turn]
         if cap:
             ops.shard_route_padded(idx, field_off, world, cap, self.pos, self.ids, self.counts,
                                    self.overflow, self.ws)
@@ -275,9 +300,12 @@ class HipRouter:
         return self.pos, self.counts, self.ids
 
 
-def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, capacity_factor=None):
+def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, capacity_factor=None,
+                        micro_batches=1):
     """An engine whose embedding table is row-sharded over `world` ranks (bench.py --gpus N).
-    capacity_factor: fixed-capacity exchange layout (hipGraph-capturable), see the module doc."""
+    capacity_factor: fixed-capacity exchange layout, see the module doc.  micro_batches > 1:
+    the step is software-pipelined over that many micro-batches so that the row / gradient-row
+    exchanges overlap the dense compute."""
     from . import engine as eng
 
     base = eng.ENGINES[model]
@@ -287,14 +315,17 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
 
         def __init__(self):
             self._shard_args = (rank, world, group)
+            self._pending = None
+            self.micro_batches = int(micro_batches)
             super().__init__(spec, D, hp, device=device)
             self._flat_grads = flatten_grads(self.grads)
+            self._acc = torch.zeros_like(self._flat_grads)
 
         def _alloc_tables(self):
             dev = self.device
             R = self.spec.rows
-            self.st = ShardedTable(R, self.D, rank, world, dev, hip_gather, HipRouter(dev), group,
-                                   capacity_factor)
+            self.st = ShardedTable(R, self.D, rank, world, dev, hip_gather,
+                                   HipRouter(dev, ring=self.micro_batches + 1), group, capacity_factor)
             self.table = self.st.shard  # [R_local, D+4] fused rows
             self.linear_w_dense = torch.zeros(self.Dn, dtype=torch.float32, device=dev)
             self.field_off = torch.tensor(self.spec.offsets(), dtype=torch.int64, device=dev)
@@ -309,6 +340,10 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 self._zoff = torch.zeros(self.F, dtype=torch.int64, device=self.device)
                 slots = world * self.st.capacity(B * self.F) or B * self.F
                 self.grad_rows = torch.empty(slots, self.D + PAD, dtype=torch.float32, device=self.device)
+                # one send buffer per micro-batch: its exchange is still in flight while the
+                # next micro-batch packs
+                self.grad_rows_m = [self.grad_rows] + [torch.empty_like(self.grad_rows)
+                                                       for _ in range(self.micro_batches - 1)]
 
         def _embed(self, idx, dense, want_fm, masks, lin_w=None):
             from . import ops
@@ -317,7 +352,11 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             fm_masks = m.get("fm", (None, None))
             B = idx.shape[0]
             # rows arrive owner-bucketed; the gather kernel reads occurrence (b,f) at row pos[b,f]
-            self.rows, self.ex = self.st.lookup(idx, self.field_off)
+            if self._pending is not None:   # a micro-batch whose exchange was started earlier
+                self.ex, self._pending = self._pending, None
+                self.rows = self.st.lookup_finish(self.ex)
+            else:
+                self.rows, self.ex = self.st.lookup(idx, self.field_off)
             W = self.D + PAD
             flat = self.rows.view(-1)
             ops.embed_fwd(
@@ -332,16 +371,65 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 fm_logit=self.fm_logit if want_fm else None,
                 lin_logit=self.lin_logit if self.use_linear else None)
 
-        def fwd_bwd(self, idx, dense, y, masks=None):
+        def _one(self, idx, dense, y, masks, grad_rows):
+            """fwd+bwd of one (micro-)batch; its gradient rows are packed into grad_rows and their
+            exchange is started: returns (loss, ids, rows, work)."""
             from . import ops
 
-            loss = super().fwd_bwd(idx, dense, y, masks)
+            loss = base.fwd_bwd(self, idx, dense, y, masks)
             # gradient rows [dE | g_fm | g_lin | 0 0], written straight in bucketed order -> owners
             ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
-                               self.dlogit if self.use_linear else None, self.ex.pos, self.grad_rows)
-            self.shard_grad_ids, self.shard_grad_rows = self.st.push_grads(self.ex, self.grad_rows)
+                               self.dlogit if self.use_linear else None, self.ex.pos, grad_rows)
+            out, work = self.ex.push(grad_rows, async_op=True)
+            return loss, self.ex.recv_ids, out, work
+
+        def fwd_bwd(self, idx, dense, y, masks=None):
+            """One step.  micro_batches = M > 1 splits the batch into M equal micro-batches and
+            software-pipelines them: while micro-batch c computes, the rows of c+1 and the gradient
+            rows of c-1 travel over xGMI (RCCL runs them on its own stream).  The gradients are the
+            full-batch means either way: shard_grad_ids / shard_grad_rows (lists of M IndexedSlices
+            pieces when M > 1) and self.grads."""
+            M = self.micro_batches
+            B = idx.shape[0]
+            self._alloc(B if M <= 1 else B // M)
+            if M <= 1:
+                loss, ids, rows, work = self._one(idx, dense, y, masks, self.grad_rows)
+                if work is not None:
+                    work.wait()
+                self.shard_grad_ids, self.shard_grad_rows = ids, rows
+                allreduce_dense(self.grads, world, group, self._flat_grads)
+                return loss
+            if B % M or masks is not None:
+                raise ValueError("micro-batching needs a batch divisible by micro_batches and no dropout masks")
+            if any(self.hp.get(k, 0.0) for k in ("deep_l2_reg", "cin_l2_reg", "cross_layer_l2_reg",
+                                                  "embedding_l2_reg", "linear_l2_reg")):
+                raise NotImplementedError("micro-batching with l2 terms (they would be added once per micro-batch)")
+            b = B // M
+            parts = [(idx[c * b: (c + 1) * b], dense[c * b: (c + 1) * b], y[c * b: (c + 1) * b]) for c in range(M)]
+            self.grad_scale = 1.0 / M
+            started = self.st.lookup_start(parts[0][0], self.field_off)
+            outs, total = [], None
+            for c in range(M):
+                self._pending = started
+                # start the NEXT micro-batch's exchange before this one's compute is enqueued
+                started = self.st.lookup_start(parts[c + 1][0], self.field_off) if c + 1 < M else None
+                loss, ids, rows, work = self._one(*parts[c], None, self.grad_rows_m[c])
+                outs.append((ids, rows, work))
+                if c == 0:
+                    self._acc.copy_(self._flat_grads)
+                    total = loss.clone()
+                else:
+                    self._acc.add_(self._flat_grads)
+                    total.add_(loss)
+            self.grad_scale = 1.0
+            self._flat_grads.copy_(self._acc)  # every chunk already carries the 1/M factor
+            for _, _, work in outs:
+                if work is not None:
+                    work.wait()
+            self.shard_grad_ids = [o[0] for o in outs]
+            self.shard_grad_rows = [o[1] for o in outs]
             allreduce_dense(self.grads, world, group, self._flat_grads)
-            return loss
+            return total.div_(M)
 
         def overflowed(self):
             """True when a fixed-capacity batch did not fit (host sync; clears the flag): every

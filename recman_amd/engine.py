@@ -513,6 +513,10 @@ class Engine:
         yk = dict(y=y) if y.dtype == I64 else dict(y_f=y)
         ops.logit_loss(branches, task=self.task, logit=self.logit, pred=self.pred,
                        dlogit=self.dlogit, loss=self.loss, workspace=self.ws, **yk)
+        if getattr(self, "grad_scale", 1.0) != 1.0:
+            # this batch is one of several micro-batches of a step: its gradients are its share
+            # of the full-batch mean (recman_amd/dist.py)
+            self.dlogit.mul_(self.grad_scale)
         self._branches_bwd(idx, dense, self.dlogit, masks)
         if self.use_linear:
             ops.linear_dense_bwd(self.dlogit, dense if self.Dn else None,

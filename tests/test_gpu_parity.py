@@ -375,3 +375,48 @@ def test_shard_route_padded_matches_torch_reference(hip_lib, world):
         pos2, _, send2, over2 = r(idx.cuda(), foff.cuda(), world, 64)
         torch.cuda.synchronize()
         assert int(over2.item()) == 1 and int(pos2.max()) < world * 64
+
+
+@pytest.mark.parametrize("model,kw", [("deepfm", {}), ("dcn", dict(cross_layers=2, scale=0.15))])
+@pytest.mark.parametrize("fixed", [False, True])
+def test_sharded_engine_micro_batches_match_single_pass(hip_lib, model, kw, fixed):
+    """micro_batches = 3 (software-pipelined exchange, both exchange layouts): same loss, same
+    dense gradients and the same table gradient as the one-pass sharded step, up to f32
+    reassociation of the batch mean."""
+    from recman_amd import dist as rd
+    from recman_amd import engine as eng
+
+    spec, p, idx, dense, y, hp = make_case(model, B=48, D=16, **kw)
+    hp = dict(hp, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=0.0, cross_layer_l2_reg=0.0)
+    espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names)
+    full = torch.cat([p[f"{n}_feat_embed"] for n in spec.sparse_names])
+    bias = torch.cat([p[f"{n}_feat_bias"].reshape(-1) for n in spec.sparse_names]) if model == "deepfm" else None
+    R, D = full.shape[0], 16
+    idx_d, dense_d, y_d = idx.cuda(), dense.cuda(), y.cuda()
+
+    def run(micro):
+        s = rd.make_sharded_engine(model, espec, 16, hp, torch.device("cuda"), 0, 1,
+                                   capacity_factor=1.0 if fixed else None, micro_batches=micro)
+        s.load_params({k: v for k, v in p.items() if k in s.params})
+        s.st.load_global(full, bias=bias, lin=p["linear_w"].reshape(-1)[:R])
+        s.linear_w_dense.copy_(p["linear_w"].reshape(-1)[R:])
+        loss = s.fwd_bwd(idx_d, dense_d, y_d).clone()
+        ids, rows = s.shard_grad_ids, s.shard_grad_rows
+        if not isinstance(ids, list):
+            ids, rows = [ids], [rows]
+        dt = torch.zeros(R, D + rd.PAD, device="cuda")
+        for i, r in zip(ids, rows):
+            live = i >= 0  # fixed capacity: empty slots carry id -1
+            dt.index_add_(0, i[live], r[live])
+        assert not s.overflowed()
+        return loss, dt, {k: v.clone() for k, v in s.grads.items()}
+
+    loss1, dt1, g1 = run(1)
+    loss3, dt3, g3 = run(3)
+    _close(loss3, loss1, what="loss")
+    _close(dt3, dt1, what="table / bias / linear row gradients")
+    for k in g1:
+        _close(g3[k], g1[k], what=f"grad {k}")
+    with pytest.raises(ValueError):
+        rd.make_sharded_engine(model, espec, 16, hp, torch.device("cuda"), 0, 1, micro_batches=5).fwd_bwd(
+            idx_d, dense_d, y_d)  # 48 is not divisible by 5
