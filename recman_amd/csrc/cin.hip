@@ -112,14 +112,19 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
   const int prow = wave * 32 * MT + c;  // + mt*32
   const int nchunks = Kp / 32;
   int i_cur = 0, j_cur = 0;  // (i, even j) of the running k' pair: wave-uniform
+  static_assert(PF <= 2, "the filter prefetch below is written out for at most 2 float4 per thread");
+  const int pfi0 = tid < NT * 256 ? tid : NT * 256 - 1;                     // clamped: loads are
+  const int pfi1 = tid + NTHR < NT * 256 ? tid + NTHR : NT * 256 - 1;       // always in bounds
   for (int ch = 0; ch < nchunks; ++ch) {
-    float4 pf[PF];
-    if (ch + 1 < nchunks) {
-#pragma unroll
-      for (int q = 0; q < PF; ++q)
-        if (tid + q * NTHR < NT * 256)
-          pf[q] = *reinterpret_cast<const float4 *>(Wp + (int64_t)(ch + 1) * WCH + (tid + q * NTHR) * 4);
-    }
+    // The next filter chunk is prefetched UNCONDITIONALLY into two named registers (the last
+    // iteration re-loads its own chunk).  As a conditional load into a float4 pf[PF] array the
+    // prefetch lived in scratch: global_load -> s_waitcnt vmcnt(0) -> scratch_store, i.e. the
+    // whole L2 latency exposed twice per chunk (rocprof: 26 % of wave-cycles waiting).
+    const int nx = ch + 1 < nchunks ? ch + 1 : ch;
+    const float4 pf0 = *reinterpret_cast<const float4 *>(Wp + (int64_t)nx * WCH + pfi0 * 4);
+    float4 pf1 = pf0;
+    if constexpr (PF > 1) pf1 = *reinterpret_cast<const float4 *>(Wp + (int64_t)nx * WCH + pfi1 * 4);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads here, ahead of the MFMA steps
     const float *Wb = Ws + (ch & 1) * WCH;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -148,11 +153,15 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
       j_cur += 2;
       if (j_cur >= He) { j_cur = 0; ++i_cur; }
     }
-    if (ch + 1 < nchunks) {
+    {
+      // stores are unconditional wherever the chunk divides evenly over the threads: a store
+      // inside `if (tid + ... < NT*256)` let the compiler sink the prefetch LOAD into that branch
       float *Wn = Ws + ((ch + 1) & 1) * WCH;
-#pragma unroll
-      for (int q = 0; q < PF; ++q)
-        if (tid + q * NTHR < NT * 256) *reinterpret_cast<float4 *>(Wn + (tid + q * NTHR) * 4) = pf[q];
+      constexpr bool kExact = (NT * 256) % NTHR == 0;
+      if (kExact || tid < NT * 256) *reinterpret_cast<float4 *>(Wn + tid * 4) = pf0;
+      if constexpr (PF > 1) {
+        if (kExact || tid + NTHR < NT * 256) *reinterpret_cast<float4 *>(Wn + (tid + NTHR) * 4) = pf1;
+      }
     }
     __syncthreads();
   }
@@ -342,15 +351,21 @@ __global__ __launch_bounds__(ROWS * 2) void cin_dx_kernel(
     float dx0 = 0.f;
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb, ++kt) {
-      float4 pf[F4];
-      if (kt + 1 < ntiles) {
-#pragma unroll
-        for (int q = 0; q < F4; ++q) {
-          const int f = tid + q * NTHR, row = f / (Np / 4), c4 = f - row * (Np / 4);
-          if (f < CF4)
-            pf[q] = *reinterpret_cast<const float4 *>(Wq + ((int64_t)(kt + 1) * 32 + row) * Np + 4 * c4);
-        }
-      }
+      // next filter tile -> NAMED registers, unconditionally (the last tile re-loads itself,
+      // threads past the tile re-load its last float4): the conditional float4 pf[F4] array
+      // of the first version lived in scratch behind an s_waitcnt vmcnt(0) per load
+      static_assert(F4 <= 4, "the filter prefetch is written out for at most 4 float4 per thread");
+      const int ktn = kt + 1 < ntiles ? kt + 1 : kt;
+      const float *wsrc = Wq + (int64_t)ktn * 32 * Np;
+#define RM_PF(q)                                                                         \
+  float4 pf##q = z4;                                                                     \
+  if constexpr (q < F4) {                                                                \
+    const int f_ = (tid + q * NTHR) < CF4 ? (tid + q * NTHR) : CF4 - 1;                  \
+    pf##q = *reinterpret_cast<const float4 *>(wsrc + (int64_t)(f_ / (Np / 4)) * Np + 4 * (f_ % (Np / 4))); \
+  }
+      RM_PF(0) RM_PF(1) RM_PF(2) RM_PF(3)
+#undef RM_PF
+      __builtin_amdgcn_sched_barrier(0);
       const float *Wb = Wt + (kt & 1) * 32 * LDW;
       f32x16 acc;
 #pragma unroll
@@ -369,13 +384,17 @@ __global__ __launch_bounds__(ROWS * 2) void cin_dx_kernel(
         dx0 += acc[r] * xkr[jb][r];
         dxk[jb][r] += acc[r] * x0v;
       }
-      if (kt + 1 < ntiles) {
+      {
         float *Wn = Wt + ((kt + 1) & 1) * 32 * LDW;
-#pragma unroll
-        for (int q = 0; q < F4; ++q) {
-          const int f = tid + q * NTHR, row = f / (Np / 4), c4 = f - row * (Np / 4);
-          if (f < CF4) *reinterpret_cast<float4 *>(Wn + row * LDW + 4 * c4) = pf[q];
-        }
+        constexpr bool kExact = CF4 % NTHR == 0;  // unconditional stores keep the loads from sinking
+#define RM_ST(q)                                                                         \
+  if constexpr (q < F4) {                                                                \
+    const int f_ = tid + q * NTHR;                                                       \
+    if (kExact || f_ < CF4)                                                              \
+      *reinterpret_cast<float4 *>(Wn + (f_ / (Np / 4)) * LDW + 4 * (f_ % (Np / 4))) = pf##q; \
+  }
+        RM_ST(0) RM_ST(1) RM_ST(2) RM_ST(3)
+#undef RM_ST
       }
       __syncthreads();
     }
