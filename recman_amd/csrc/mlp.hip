@@ -234,13 +234,25 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
 constexpr int kLDT = 36;  // k-tile slice row stride in LDS (32 + 4 pad)
 constexpr int kWT = 4;    // k-tiles per wave: Kp <= 448 -> 14 tiles over 4 waves
 
-// (per-lane-branch form kept here on purpose: the backward kernel is register-bound and the
-// branch-free loader cost it spills, 113.7 -> 118.7 us; see profiles/r01_p7_loader_ablation.md)
+// A k-tile that lies entirely inside xe (wave-uniform test; every tile but the last for the
+// Criteo shape) is four unconditional float4 loads issued back to back.  Only a tile that touches
+// the xe / xd boundary takes the per-lane-branch form below - hipcc serialises those loads
+// (branch + s_waitcnt vmcnt(0) per load), but it keeps their register footprint small, and the
+// kernel is register-bound (a branch-free tail cost it spills: profiles/r01_p7_loader_ablation.md).
 __device__ __forceinline__ void load_ktile(float4 (&v)[4], const float *__restrict__ xe,
                                            const float *__restrict__ xd, int FD, int Dn, int64_t B,
                                            int64_t ex0, int kb, int lane) {
   const int c4 = lane & 7;
   const int k = kb + 4 * c4;
+  if (kb + 32 <= FD) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int64_t b = ex0 + (lane >> 3) + 8 * q;
+      b = b < B ? b : B - 1;
+      v[q] = *reinterpret_cast<const float4 *>(xe + b * FD + k);
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = (lane >> 3) + 8 * q;
