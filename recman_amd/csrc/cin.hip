@@ -621,7 +621,9 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(
     // branch-free hot loop when both tile slots are real; the checked variant only runs in
     // the partially filled last group
     auto steps = [&](auto checked) {
-#pragma unroll 4
+      // unroll 2, not 4: at 4 the kernel spilled 4 VGPRs (row pointers), and their scratch reloads
+      // in the prefetch put an s_waitcnt vmcnt(0) between the chunk's global loads
+#pragma unroll 2
       for (int t = 0; t < kRC / 2; ++t) {
         const int pl = 2 * t + h;
         float bv[NT];
