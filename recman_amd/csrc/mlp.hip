@@ -225,14 +225,14 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
 
 // ---------------------------------------------------------------------------
 // backward: dh chain in registers, dX (+ FM term) -> d_rows, dW0 accumulated on the MFMA.
-// The 4 waves of a block share one 32-example tile and split its k-tiles (wave w owns
-// k-tiles w, w+4, ...): each wave loads only its own 32 x 32 slices of x (private LDS,
-// no block barrier in the loop), keeps 4 dW0 accumulators (64 registers instead of 224,
-// so 2 waves per SIMD and a deeper prefetch fit) and owns disjoint rows of the block's
-// dW0 partial (no end-of-kernel reduction).  The cheap dh chain is recomputed per wave.
+// The 8 waves of a block share one 32-example tile and split its k-tiles (wave w owns
+// k-tiles w and w+8): each wave loads only its own 32 x 32 slices of x (private LDS, no
+// block barrier in the loop), keeps 2 dW0 accumulators (32 registers instead of 224) and
+// owns disjoint rows of the block's dW0 partial (no end-of-kernel reduction).  The cheap
+// dh chain is recomputed per wave.
 // ---------------------------------------------------------------------------
 constexpr int kLDT = 36;  // k-tile slice row stride in LDS (32 + 4 pad)
-constexpr int kWT = 4;    // k-tiles per wave: Kp <= 448 -> 14 tiles over 4 waves
+constexpr int kWT = 2;    // k-tiles per wave: Kp <= 448 -> 14 tiles over the block's 8 waves
 
 // A k-tile that lies entirely inside xe (wave-uniform test; every tile but the last for the
 // Criteo shape) is four unconditional float4 loads issued back to back.  Only a tile that touches
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
     const float *__restrict__ w_out, int act, int64_t B, const float *__restrict__ g,
     const float *__restrict__ h0, const float *__restrict__ h1, const float *__restrict__ h2,
     const float *__restrict__ fm_sum, int D, float *__restrict__ d_rows, float *__restrict__ dh0,
-    float *__restrict__ dh1, float *__restrict__ dh2, float *__restrict__ dW0_part) {
+    float *__restrict__ dh1, float *__restrict__ dh2, float *__restrict__ dW0_part, int s_lds) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = FD + Dn;
   const int Kp = ((K + 63) / 64) * 64;
@@ -298,9 +298,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
   float *wo = WB + (NL - 1) * 1024;          // [32] w_out
   float *xs_all = wo + 32;                   // [8 waves][32][kLDT]
   float *dT_all = xs_all + 8 * 32 * kLDT;    // [8 waves][32][33]: dh0 as [example][unit]
-  // 8 waves = two groups of 4; a group shares one 32-example tile, wave `wave` of the group
-  // owns k-tiles wave, wave+4, ...
-  const int tid = threadIdx.x, lane = tid & 63, wv8 = tid >> 6, wave = wv8 & 3, grp = wv8 >> 2;
+  float *gS_all = dT_all + 8 * 32 * 33;      // [8 waves][32][D]: g[b] * S[b][:] of the wave's tile (s_lds)
+  // The 8 waves share one 32-example tile; wave w owns k-tiles w and w+8: 2 dW0 accumulators
+  // (32 registers).  With two groups of 4 waves and 4 accumulators each the kernel sat at 256
+  // VGPRs and every change to its epilogue spilled (profiles/r01_p9_mlp_bwd.md).
+  const int tid = threadIdx.x, lane = tid & 63, wv8 = tid >> 6, wave = wv8;
   const int h = lane >> 5, c = lane & 31;
 
   stage_w0<false, 512>(W0r, LDR, w.W[0], K, Kp, w.H[0], tid);
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
 
   float *xs = xs_all + wv8 * 32 * kLDT;
   float *dT = dT_all + wv8 * 32 * 33;
+  float *gS = gS_all + wv8 * 32 * D;
   f32x16 accw[kWT];
 #pragma unroll
   for (int t = 0; t < kWT; ++t)
@@ -324,21 +327,72 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
     for (int r = 0; r < 16; ++r) accw[t][r] = 0.f;
 
   const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 2 + grp; tile < ntiles; tile += (int64_t)gridDim.x * 2) {
+  // x slices are prefetched ONE EXAMPLE TILE ahead: pf[j] always holds (or has in flight) the
+  // wave's j-th k-tile of the tile about to be processed; it is re-issued for the next example
+  // tile as soon as it has been copied to LDS (unconditionally - the last tile re-loads itself)
+  float4 pf[kWT][4];
+  {
+    const int64_t e0 = (int64_t)(blockIdx.x < ntiles ? blockIdx.x : 0) * 32;
+#pragma unroll
+    for (int j = 0; j < kWT; ++j)
+      if (wave + 8 * j < nkt) load_ktile(pf[j], xe, xd, FD, Dn, B, e0, (wave + 8 * j) * 32, lane);
+  }
+  // ... and so are the tile's g and post-activation h values (the dh chain's inputs): without
+  // this every tile started with two exposed global-load latencies (ablation: 40 us floor)
+  const float *hptr[3] = {h0, h1, h2};
+  float4 hn[NL][4];
+  float gn;
+  {
+    int64_t bn = (int64_t)(blockIdx.x < ntiles ? blockIdx.x : 0) * 32 + c;
+    bn = bn < B ? bn : B - 1;
+    gn = g[bn];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        hn[l][gq] = *reinterpret_cast<const float4 *>(hptr[l] + bn * 32 + 8 * gq + 4 * h);
+  }
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t ex0 = tile * 32;
+    const int64_t ex_next = (tile + gridDim.x < ntiles ? tile + gridDim.x : tile) * 32;
     const int64_t b = ex0 + c;
     const bool valid = b < B;
-    const int64_t bb = valid ? b : B - 1;
-    float4 pf[4];
-    if (wave < nkt) load_ktile(pf, xe, xd, FD, Dn, B, ex0, wave * 32, lane);
-    const float gb = valid ? g[bb] : 0.f;
+    const float gb = valid ? gn : 0.f;
+    float4 hc[NL][4];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) hc[l][gq] = hn[l][gq];
+    {  // next tile's values (the last tile re-loads its own)
+      int64_t bn = ex_next + c;
+      bn = bn < B ? bn : B - 1;
+      gn = g[bn];
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          hn[l][gq] = *reinterpret_cast<const float4 *>(hptr[l] + bn * 32 + 8 * gq + 4 * h);
+    }
+    if (s_lds) {
+      // g[b] * S[b][:] of this tile, once per tile: every k-tile's epilogue adds the same 16-byte
+      // piece of it (k % D repeats), read back row-major from LDS instead of from global memory
+      const int D4 = D >> 2;
+      for (int f = lane; f < 32 * D4; f += 64) {
+        const int row = f / D4, p4 = f - row * D4;
+        int64_t br = ex0 + row;
+        br = br < B ? br : B - 1;
+        const float gr = g[br];
+        const float4 s4 = *reinterpret_cast<const float4 *>(fm_sum + br * D + 4 * p4);
+        *reinterpret_cast<float4 *>(gS + row * D + 4 * p4) =
+            make_float4(gr * s4.x, gr * s4.y, gr * s4.z, gr * s4.w);
+      }
+    }
     // ---- dh chain (recomputed by every wave; wave 0 stores dh_l) ----
     float dh[16];
     {
-      const float *hl = NL == 1 ? h0 : (NL == 2 ? h1 : h2);
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const float4 hv = *reinterpret_cast<const float4 *>(hl + bb * 32 + 8 * gq + 4 * h);
+        const float4 hv = hc[NL - 1][gq];
         dh[4 * gq + 0] = gb * wo[8 * gq + 4 * h + 0] * actg(hv.x, act);
         dh[4 * gq + 1] = gb * wo[8 * gq + 4 * h + 1] * actg(hv.y, act);
         dh[4 * gq + 2] = gb * wo[8 * gq + 4 * h + 2] * actg(hv.z, act);
@@ -361,10 +415,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
       for (int s = 0; s < 16; ++s)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[(l - 1) * 1024 + (s * 2 + h) * 32 + c], dh[s],
                                                    acc, 0, 0, 0);
-      const float *hprev = l == 1 ? h0 : h1;
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const float4 hv = *reinterpret_cast<const float4 *>(hprev + bb * 32 + 8 * gq + 4 * h);
+        const float4 hv = hc[l - 1][gq];
         dh[4 * gq + 0] = acc[4 * gq + 0] * actg(hv.x, act);
         dh[4 * gq + 1] = acc[4 * gq + 1] * actg(hv.y, act);
         dh[4 * gq + 2] = acc[4 * gq + 2] * actg(hv.z, act);
@@ -384,14 +437,20 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
     // ---- this wave's k-tiles: dX tile (-> d_rows) and dW0 tile ----
 #pragma unroll
     for (int j = 0; j < kWT; ++j) {
-      const int kt = wave + 4 * j;
+      const int kt = wave + 8 * j;
       if (kt >= nkt) break;
       const int kb = kt * 32;
       float *xb = xs;  // single buffer: LDS ops of one wave execute in order
-      store_ktile(xb, pf, lane);
-      if (kt + 4 < nkt) load_ktile(pf, xe, xd, FD, Dn, B, ex0, (kt + 4) * 32, lane);
-      if (kb < FD) {  // dX only for the embedding part of x
-        f32x16 acc;
+      store_ktile(xb, pf[j], lane);
+      load_ktile(pf[j], xe, xd, FD, Dn, B, ex_next, kb, lane);
+      // dW0[kb + c'][unit] += sum_ex x[ex][kb + c'] * dh0[ex][unit]   (first: needs the x tile intact)
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[(2 * s + h) * kLDT + c],
+                                                      dT[(2 * s + h) * 33 + c], accw[j], 0, 0, 0);
+      const bool has_dx = kb < FD;  // dX only for the embedding part of x (wave-uniform)
+      f32x16 acc;
+      if (has_dx) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
@@ -403,26 +462,53 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, dh[4 * gq + 3], acc, 0, 0, 0);
         }
         // acc[r] = dX[example c][k = kb + u(r,h)]
+      }
+      if (has_dx) {
+        // dX (- g*E for the FM term) goes back INTO the x tile, in place, and leaves it row-major:
+        // every lane then writes whole 16-byte pieces of 128-byte row segments (8 lanes per row,
+        // 8 rows per store instruction) and reads S the same way.  Storing straight from the
+        // MFMA layout touched 32 rows x 32 bytes per instruction: the epilogue was 42 of the
+        // kernel's 109 us (ablation, profiles/r01_p9).
+        const bool fm = fm_sum != nullptr;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const int k = kb + 8 * gq + 4 * h;
-          if (k < FD && valid) {
-            float4 o = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
-            if (fm_sum != nullptr) {
-              const float4 e = *reinterpret_cast<const float4 *>(xb + c * kLDT + 8 * gq + 4 * h);
-              const float4 s4 = *reinterpret_cast<const float4 *>(fm_sum + b * D + (k % D));
-              o.x += gb * (s4.x - e.x); o.y += gb * (s4.y - e.y);
-              o.z += gb * (s4.z - e.z); o.w += gb * (s4.w - e.w);
+          float4 *p4 = reinterpret_cast<float4 *>(xb + c * kLDT + 8 * gq + 4 * h);
+          float4 o = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+          if (fm) {
+            const float4 e = *p4;
+            o.x -= gb * e.x; o.y -= gb * e.y; o.z -= gb * e.z; o.w -= gb * e.w;
+          }
+          *p4 = o;
+        }
+        const int piece = lane & 7;
+        const int k = kb + 4 * piece;
+        if (fm && s_lds) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = (lane >> 3) + 8 * q;
+            const int64_t br = ex0 + row;
+            float4 o = *reinterpret_cast<const float4 *>(xb + row * kLDT + 4 * piece);
+            const float4 s4 = *reinterpret_cast<const float4 *>(gS + row * D + (k % D));
+            o.x += s4.x; o.y += s4.y; o.z += s4.z; o.w += s4.w;
+            if (br < B && k < FD) *reinterpret_cast<float4 *>(d_rows + br * FD + k) = o;
+          }
+        } else {
+#pragma unroll 1  // (register-bound kernel: the unrolled form with its global loads spilled 56 VGPRs)
+          for (int q = 0; q < 4; ++q) {
+            const int row = (lane >> 3) + 8 * q;
+            const int64_t br = ex0 + row;
+            if (br < B && k < FD) {
+              float4 o = *reinterpret_cast<const float4 *>(xb + row * kLDT + 4 * piece);
+              if (fm) {
+                const float gr = g[br];
+                const float4 s4 = *reinterpret_cast<const float4 *>(fm_sum + br * D + (k % D));
+                o.x += gr * s4.x; o.y += gr * s4.y; o.z += gr * s4.z; o.w += gr * s4.w;
+              }
+              *reinterpret_cast<float4 *>(d_rows + br * FD + k) = o;
             }
-            *reinterpret_cast<float4 *>(d_rows + b * FD + k) = o;
           }
         }
       }
-      // dW0[kb + c'][unit] += sum_ex x[ex][kb + c'] * dh0[ex][unit]
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[(2 * s + h) * kLDT + c],
-                                                      dT[(2 * s + h) * 33 + c], accw[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);  // keep the unrolled k-tiles from being interleaved
     }
   }
@@ -430,11 +516,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
   // ---- the block's dW0 partial: every wave owns the rows of its k-tiles ----
 #pragma unroll
   for (int j = 0; j < kWT; ++j) {
-    const int kt = wave + 4 * j;
+    const int kt = wave + 8 * j;
     if (kt < nkt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        dW0_part[(((int64_t)blockIdx.x * 2 + grp) * Kp + kt * 32 + unit_of(r, h)) * 32 + c] = accw[j][r];
+        dW0_part[((int64_t)blockIdx.x * Kp + kt * 32 + unit_of(r, h)) * 32 + c] = accw[j][r];
     }
   }
 }
@@ -565,9 +651,9 @@ size_t mlp_fwd_smem(int K, int NL) {
   const int Kp = ((K + 63) / 64) * 64;
   return (size_t)(32 * (Kp + 4) + (NL - 1) * 1024 + (NL + 1) * 32 + RM_MLP_FWD_WAVES * 32 * kLDX) * sizeof(float);
 }
-size_t mlp_bwd_smem(int K, int NL) {
+size_t mlp_bwd_smem(int K, int NL, int Ds) {  // Ds: columns of the per-wave g*S tiles (0 = none)
   const int Kp = ((K + 63) / 64) * 64;
-  return (size_t)(Kp * 36 + (NL - 1) * 1024 + 32 + 8 * 32 * kLDT + 8 * 32 * 33) * sizeof(float);
+  return (size_t)(Kp * 36 + (NL - 1) * 1024 + 32 + 8 * 32 * kLDT + 8 * 32 * 33 + 8 * 32 * Ds) * sizeof(float);
 }
 
 int mlp_check(const char *fn, int FD, int Dn, int NL, const int *H) {
@@ -645,9 +731,11 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     w.H[l] = l < NL ? H[l] : 0;
   }
   const int K = FD + Dn, Kp = ((K + 63) / 64) * 64;
-  const size_t smem = mlp_bwd_smem(K, NL);
+  // the per-wave g*S tiles go to LDS when they fit next to everything else (D = 16: 16 KB more)
+  const int s_lds = (fm_sum != nullptr && mlp_bwd_smem(K, NL, D) <= 160 * 1024) ? 1 : 0;
+  const size_t smem = mlp_bwd_smem(K, NL, s_lds ? D : 0);
   const int64_t ntiles = (B + 31) / 32;
-  const int nblk = rm_grid_cap((ntiles + 1) / 2, 256);  // one 8-wave block per CU, 2 tiles at a time
+  const int nblk = rm_grid_cap(ntiles, 256);  // one 8-wave block per CU, one 32-example tile at a time
   hipStream_t st = (hipStream_t)stream;
   float *part = workspace;
   float *part2 = workspace + (int64_t)512 * Kp * 32;
@@ -658,11 +746,11 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     hipLaunchKernelGGL((mlp_bwd_kernel<NL_>), dim3(nblk), dim3(512), smem, st, xe, xd, FD, Dn, w, \
                        w_out, act, B, g, h[0], NL > 1 ? h[1] : nullptr, NL > 2 ? h[2] : nullptr, \
                        fm_sum, D, d_rows, dh[0], NL > 1 ? dh[1] : nullptr,                       \
-                       NL > 2 ? dh[2] : nullptr, part);                                          \
+                       NL > 2 ? dh[2] : nullptr, part, s_lds);                                   \
   }
   if (NL == 1) RM_MLP_BWD(1) else if (NL == 2) RM_MLP_BWD(2) else RM_MLP_BWD(3)
 #undef RM_MLP_BWD
-  hipLaunchKernelGGL(mlp_dw0_reduce_kernel, dim3(Kp * 32 / 64), dim3(256), 0, st, part, 2 * nblk, K,
+  hipLaunchKernelGGL(mlp_dw0_reduce_kernel, dim3(Kp * 32 / 64), dim3(256), 0, st, part, nblk, K,
                      Kp, H[0], dW[0]);
   {
     SgOut o;
