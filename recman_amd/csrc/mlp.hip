@@ -551,65 +551,75 @@ __global__ __launch_bounds__(256) void mlp_dw0_reduce_kernel(const float *__rest
 //   dW_l = h_{l-1}^T dh_l (l >= 1), db_l = colsum(dh_l), d w_out = h_last^T g, d w0 = sum g.
 // Per-block partial layout: [(NL-1) x 1024 | NL x 32 | 32 | 1], padded to kSgStride.
 constexpr int kSgStride = 2 * 1024 + 3 * 32 + 32 + 32;
+// Stage 1 on the matrix pipe (the first version was a VALU kernel behind LDS staging, 20 us): a wave walks
+// 32-example chunks, loads h_l / dh_l straight in MFMA operand layout (lane = unit, the two lane
+// halves = the two examples of a k-step: coalesced 128-byte rows, no LDS staging),
+//   dW_l += h_{l-1}^T dh_l on the matrix pipe, db_l / d w_out / sum g as per-lane column sums.
+// The 4 waves of a block meet in LDS and write ONE partial per block.  20 -> ~8 us at B = 65536.
 template <int NL>
-__global__ __launch_bounds__(256) void mlp_small_grads_stage1(
+__global__ __launch_bounds__(256) void mlp_small_grads_mfma(
     const float *__restrict__ h0, const float *__restrict__ h1, const float *__restrict__ h2,
     const float *__restrict__ d0, const float *__restrict__ d1, const float *__restrict__ d2,
     const float *__restrict__ g, int64_t B, float *__restrict__ part) {
-  __shared__ float hs[NL][64][33], ds[NL][64][33], gs[64];
-  const int tid = threadIdx.x;
-  const int p = tid >> 3, q0 = (tid & 7) * 4;  // dW_l[p][q0..q0+3]
-  float aw[NL > 1 ? NL - 1 : 1][4];
+  __shared__ float red[4][kSgStride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
+  for (int t = lane; t < kSgStride; t += 64) red[wave][t] = 0.f;
+  constexpr int NW = NL > 1 ? NL - 1 : 1;
+  f32x16 acc[NW];
 #pragma unroll
-  for (int l = 0; l < (NL > 1 ? NL - 1 : 1); ++l) aw[l][0] = aw[l][1] = aw[l][2] = aw[l][3] = 0.f;
-  float av = 0.f;  // threads 0..32*NL-1: db_l[q]; next 32: d w_out[q]; next 1: sum g
-  const int64_t rows_per_block = (B + gridDim.x - 1) / gridDim.x;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
+  for (int l = 0; l < NW; ++l)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[l][r] = 0.f;
+  float db[NL], dwo = 0.f, sg = 0.f;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) db[l] = 0.f;
   const float *hp[3] = {h0, h1, h2};
   const float *dp[3] = {d0, d1, d2};
-  for (int64_t rb = r0; rb < r1; rb += 64) {
-    __syncthreads();
-    for (int t = tid; t < 64 * 32; t += 256) {
-      const int rr = t >> 5, cc = t & 31;
-      const int64_t row = rb + rr;
+  const int64_t nchunks = (B + 31) / 32;
+  for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
+    const int64_t r0 = chunk * 32;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int64_t row = r0 + 2 * s + h;
+      const bool ok = row < B;
+      const int64_t rc = ok ? row : B - 1;
+      float hv[NL], dv[NL];
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
-        hs[l][rr][cc] = row < r1 ? hp[l][row * 32 + cc] : 0.f;
-        ds[l][rr][cc] = row < r1 ? dp[l][row * 32 + cc] : 0.f;
+        hv[l] = hp[l][rc * 32 + c];
+        const float d = dp[l][rc * 32 + c];
+        dv[l] = ok ? d : 0.f;  // rows past the batch contribute nothing
       }
-    }
-    if (tid < 64) gs[tid] = rb + tid < r1 ? g[rb + tid] : 0.f;
-    __syncthreads();
+      const float gv = ok ? g[rc] : 0.f;
 #pragma unroll
-    for (int l = 1; l < NL; ++l) {
-#pragma unroll 8
-      for (int rr = 0; rr < 64; ++rr) {
-        const float xv = hs[l - 1][rr][p];
-        aw[l - 1][0] += xv * ds[l][rr][q0]; aw[l - 1][1] += xv * ds[l][rr][q0 + 1];
-        aw[l - 1][2] += xv * ds[l][rr][q0 + 2]; aw[l - 1][3] += xv * ds[l][rr][q0 + 3];
-      }
-    }
-    if (tid < 32 * NL) {
-      const int l = tid >> 5, q = tid & 31;
-      for (int rr = 0; rr < 64; ++rr) av += ds[l][rr][q];
-    } else if (tid < 32 * NL + 32) {
-      const int q = tid - 32 * NL;
-      for (int rr = 0; rr < 64; ++rr) av += gs[rr] * hs[NL - 1][rr][q];
-    } else if (tid == 32 * NL + 32) {
-      for (int rr = 0; rr < 64; ++rr) av += gs[rr];
+      for (int l = 1; l < NL; ++l)
+        acc[l - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[l - 1], dv[l], acc[l - 1], 0, 0, 0);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) db[l] += dv[l];
+      dwo += gv * hv[NL - 1];
+      sg += gv;
     }
   }
+  // the two lane halves hold disjoint examples of the same column
+#pragma unroll
+  for (int l = 0; l < NL; ++l) db[l] += __shfl_xor(db[l], 32, 64);
+  dwo += __shfl_xor(dwo, 32, 64);
+  sg += __shfl_xor(sg, 32, 64);
+#pragma unroll
+  for (int l = 1; l < NL; ++l)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(l - 1) * 1024 + unit_of(r, h) * 32 + c] = acc[l - 1][r];
+  if (h == 0) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) red[wave][2 * 1024 + l * 32 + c] = db[l];
+    red[wave][2 * 1024 + 32 * NL + c] = dwo;
+    if (c == 0) red[wave][2 * 1024 + 32 * NL + 32] = sg;
+  }
+  __syncthreads();
   float *o = part + (int64_t)blockIdx.x * kSgStride;
-#pragma unroll
-  for (int l = 1; l < NL; ++l) {
-    float *ow = o + (l - 1) * 1024 + p * 32 + q0;
-    ow[0] = aw[l - 1][0]; ow[1] = aw[l - 1][1]; ow[2] = aw[l - 1][2]; ow[3] = aw[l - 1][3];
-  }
-  if (tid <= 32 * NL + 32) o[2 * 1024 + tid] = av;
+  for (int t = tid; t < kSgStride; t += 256) o[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
-// one wave per output: out index space = [(NL-1)*1024 dW | NL*32 db | 32 dw_out | 1 dw0]
 struct SgOut {
   float *dW[kMaxNL];  // dW[l] for l >= 1 ([H_{l-1}, H_l])
   float *db[kMaxNL];
@@ -763,15 +773,15 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     o.dw0 = d_w0_out;
     const float *h1p = NL > 1 ? h[1] : nullptr, *h2p = NL > 2 ? h[2] : nullptr;
     const float *d1p = NL > 1 ? dh[1] : nullptr, *d2p = NL > 2 ? dh[2] : nullptr;
-    const int sblk = 512;
+    const int sblk = 256;  // one 4-wave block per CU, one partial per block
     if (NL == 1)
-      hipLaunchKernelGGL((mlp_small_grads_stage1<1>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
+      hipLaunchKernelGGL((mlp_small_grads_mfma<1>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
                          dh[0], d1p, d2p, g, B, part2);
     else if (NL == 2)
-      hipLaunchKernelGGL((mlp_small_grads_stage1<2>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
+      hipLaunchKernelGGL((mlp_small_grads_mfma<2>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
                          dh[0], d1p, d2p, g, B, part2);
     else
-      hipLaunchKernelGGL((mlp_small_grads_stage1<3>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
+      hipLaunchKernelGGL((mlp_small_grads_mfma<3>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
                          dh[0], d1p, d2p, g, B, part2);
     hipLaunchKernelGGL(mlp_small_grads_stage2, dim3((kSgStride + 63) / 64), dim3(256), 0, st, part2, sblk,
                        NL, o);
