@@ -144,7 +144,10 @@ int rm_logit_loss(const float *logit_a, float coef_a, const float *logit_b, floa
  *   (xe is E: the whole DeepFM row gradient in one pass, no rm_embed_bwd launch);
  *   dh[l] [B,32] = dLoss/d(pre-activation of layer l); dW[l] / db[l] = weight / bias
  *   gradients, d_w_out [H_last], d_w0_out [1] = gradients of the output projection
- *   (db, d_w_out, d_w0_out may be NULL).  Deterministic (no float atomics).
+ *   (db, d_w_out, d_w0_out may be NULL); d_xd_wsum [Dn] (NULL or Dn <= 32) = sum_b g[b] * xd[b,:],
+ *   and d_g_sum [1] (NULL ok) = sum_b g[b]: the gradients of the linear term's dense weights and
+ *   bias when the same g drives it (layers.py:330-347; saves the rm_linear_dense_bwd pass).
+ *   Deterministic (no float atomics).
  *   workspace: rm_mlp_bwd_workspace(FD, Dn) floats. */
 int rm_mlp_supported(int FD, int Dn, int NL, const int *H);
 int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
@@ -156,7 +159,8 @@ int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const i
                const float *const *W, const float *w_out, int act, int64_t B, const float *g,
                const float *const *h, const float *fm_sum, int D, float *d_rows,
                float *const *dh, float *const *dW, float *const *db, float *d_w_out,
-               float *d_w0_out, float *workspace, rm_stream_t stream);
+               float *d_w0_out, float *d_xd_wsum, float *d_g_sum, float *workspace,
+               rm_stream_t stream);
 
 /* Epilogues of the library-GEMM DNN path (wide hidden layers, layers.py:593-601):
  * rm_bias_act: x[b,j] = act(x[b,j] + bias[j]) in place (bias may be NULL);

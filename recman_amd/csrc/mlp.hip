@@ -549,8 +549,9 @@ __global__ __launch_bounds__(256) void mlp_dw0_reduce_kernel(const float *__rest
 
 // Every remaining (tiny) gradient of the MLP in ONE pass over h_l / dh_l / g:
 //   dW_l = h_{l-1}^T dh_l (l >= 1), db_l = colsum(dh_l), d w_out = h_last^T g, d w0 = sum g.
-// Per-block partial layout: [(NL-1) x 1024 | NL x 32 | 32 | 1], padded to kSgStride.
-constexpr int kSgStride = 2 * 1024 + 3 * 32 + 32 + 32;
+// Per-block partial layout: [2 x 1024 dW_l | 3 x 32 db_l | 32 d w_out | 1 sum g (+31 pad) | 32 g^T xd].
+constexpr int kSgDense = 2 * 1024 + 3 * 32 + 32 + 32;  // offset of the g^T xd slots
+constexpr int kSgStride = kSgDense + 32;
 // Stage 1 on the matrix pipe (the first version was a VALU kernel behind LDS staging, 20 us): a wave walks
 // 32-example chunks, loads h_l / dh_l straight in MFMA operand layout (lane = unit, the two lane
 // halves = the two examples of a k-step: coalesced 128-byte rows, no LDS staging),
@@ -560,7 +561,8 @@ template <int NL>
 __global__ __launch_bounds__(256) void mlp_small_grads_mfma(
     const float *__restrict__ h0, const float *__restrict__ h1, const float *__restrict__ h2,
     const float *__restrict__ d0, const float *__restrict__ d1, const float *__restrict__ d2,
-    const float *__restrict__ g, int64_t B, float *__restrict__ part) {
+    const float *__restrict__ g, const float *__restrict__ xd, int Dn, int64_t B,
+    float *__restrict__ part) {
   __shared__ float red[4][kSgStride];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
   for (int t = lane; t < kSgStride; t += 64) red[wave][t] = 0.f;
@@ -570,9 +572,15 @@ __global__ __launch_bounds__(256) void mlp_small_grads_mfma(
   for (int l = 0; l < NW; ++l)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[l][r] = 0.f;
-  float db[NL], dwo = 0.f, sg = 0.f;
+  float db[NL], dwo = 0.f, sg = 0.f, dxd = 0.f;
 #pragma unroll
   for (int l = 0; l < NL; ++l) db[l] = 0.f;
+  // xd != NULL: also g^T xd (the gradient of the linear term's dense weights, layers.py:330-347:
+  // the same g and the same dense columns are already streaming through this kernel)
+  // (unconditional load from an always-valid address: a branch around it would serialise the
+  // unrolled loads of a chunk)
+  const float *xq = xd != nullptr ? xd + (c < Dn ? c : 0) : g;
+  const int64_t xstride = xd != nullptr ? Dn : 1;
   const float *hp[3] = {h0, h1, h2};
   const float *dp[3] = {d0, d1, d2};
   const int64_t nchunks = (B + 31) / 32;
@@ -598,6 +606,7 @@ __global__ __launch_bounds__(256) void mlp_small_grads_mfma(
       for (int l = 0; l < NL; ++l) db[l] += dv[l];
       dwo += gv * hv[NL - 1];
       sg += gv;
+      dxd += gv * xq[rc * xstride];
     }
   }
   // the two lane halves hold disjoint examples of the same column
@@ -605,6 +614,7 @@ __global__ __launch_bounds__(256) void mlp_small_grads_mfma(
   for (int l = 0; l < NL; ++l) db[l] += __shfl_xor(db[l], 32, 64);
   dwo += __shfl_xor(dwo, 32, 64);
   sg += __shfl_xor(sg, 32, 64);
+  dxd += __shfl_xor(dxd, 32, 64);
 #pragma unroll
   for (int l = 1; l < NL; ++l)
 #pragma unroll
@@ -614,6 +624,7 @@ __global__ __launch_bounds__(256) void mlp_small_grads_mfma(
     for (int l = 0; l < NL; ++l) red[wave][2 * 1024 + l * 32 + c] = db[l];
     red[wave][2 * 1024 + 32 * NL + c] = dwo;
     if (c == 0) red[wave][2 * 1024 + 32 * NL + 32] = sg;
+    if (c < Dn) red[wave][kSgDense + c] = dxd;
   }
   __syncthreads();
   float *o = part + (int64_t)blockIdx.x * kSgStride;
@@ -624,6 +635,9 @@ struct SgOut {
   float *dW[kMaxNL];  // dW[l] for l >= 1 ([H_{l-1}, H_l])
   float *db[kMaxNL];
   float *dw_out, *dw0;
+  float *dxd;         // g^T xd [Dn] or NULL
+  float *gsum;        // a second destination for sum g (the linear term's w0 gradient) or NULL
+  int Dn;
   int H[kMaxNL];
 };
 __global__ __launch_bounds__(256) void mlp_small_grads_stage2(const float *__restrict__ part, int nblk,
@@ -640,7 +654,9 @@ __global__ __launch_bounds__(256) void mlp_small_grads_stage2(const float *__res
   __syncthreads();
   if (grp != 0 || src >= kSgStride) return;
   acc = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
-  if (src < 2 * 1024) {
+  if (src >= kSgDense) {
+    if (o.dxd && src - kSgDense < o.Dn) o.dxd[src - kSgDense] = acc;
+  } else if (src < 2 * 1024) {
     const int l = 1 + src / 1024, pq = src % 1024, p = pq >> 5, q = pq & 31;
     if (l < NL && p < o.H[l - 1] && q < o.H[l]) o.dW[l][p * o.H[l] + q] = acc;
   } else {
@@ -651,8 +667,9 @@ __global__ __launch_bounds__(256) void mlp_small_grads_stage2(const float *__res
     } else if (v < 32 * NL + 32) {
       const int q = v - 32 * NL;
       if (q < o.H[NL - 1] && o.dw_out) o.dw_out[q] = acc;
-    } else if (v == 32 * NL + 32 && o.dw0) {
-      o.dw0[0] = acc;
+    } else if (v == 32 * NL + 32) {
+      if (o.dw0) o.dw0[0] = acc;
+      if (o.gsum) o.gsum[0] = acc;
     }
   }
 }
@@ -726,7 +743,8 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
                           const float *const *W, const float *w_out, int act, int64_t B,
                           const float *g, const float *const *h, const float *fm_sum, int D,
                           float *d_rows, float *const *dh, float *const *dW, float *const *db,
-                          float *d_w_out, float *d_w0_out, float *workspace, rm_stream_t stream) {
+                          float *d_w_out, float *d_w0_out, float *d_xd_wsum, float *d_g_sum,
+                          float *workspace, rm_stream_t stream) {
   int rc = mlp_check("rm_mlp_bwd", FD, Dn, NL, H);
   if (rc != RM_OK) return rc;
   if (B == 0) return RM_OK;
@@ -734,6 +752,7 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
                  dW && workspace && (FD == 0 || (d_rows && rm_aligned16(d_rows))),
              "rm_mlp_bwd: NULL or unaligned argument");
   RM_REQUIRE(!fm_sum || (D > 0 && D % 4 == 0 && rm_aligned16(fm_sum)), "rm_mlp_bwd: bad fm_sum / D");
+  RM_REQUIRE(!d_xd_wsum || (Dn >= 1 && Dn <= 32), "rm_mlp_bwd: d_xd_wsum needs 1 <= Dn <= 32");
   MlpW w;
   for (int l = 0; l < kMaxNL; ++l) {
     w.W[l] = l < NL ? W[l] : nullptr;
@@ -771,18 +790,22 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     }
     o.dw_out = d_w_out;
     o.dw0 = d_w0_out;
+    o.dxd = d_xd_wsum;
+    o.gsum = d_g_sum;
+    o.Dn = Dn;
+    const float *xdp = d_xd_wsum ? xd : nullptr;
     const float *h1p = NL > 1 ? h[1] : nullptr, *h2p = NL > 2 ? h[2] : nullptr;
     const float *d1p = NL > 1 ? dh[1] : nullptr, *d2p = NL > 2 ? dh[2] : nullptr;
     const int sblk = 256;  // one 4-wave block per CU, one partial per block
     if (NL == 1)
       hipLaunchKernelGGL((mlp_small_grads_mfma<1>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
-                         dh[0], d1p, d2p, g, B, part2);
+                         dh[0], d1p, d2p, g, xdp, Dn, B, part2);
     else if (NL == 2)
       hipLaunchKernelGGL((mlp_small_grads_mfma<2>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
-                         dh[0], d1p, d2p, g, B, part2);
+                         dh[0], d1p, d2p, g, xdp, Dn, B, part2);
     else
       hipLaunchKernelGGL((mlp_small_grads_mfma<3>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
-                         dh[0], d1p, d2p, g, B, part2);
+                         dh[0], d1p, d2p, g, xdp, Dn, B, part2);
     hipLaunchKernelGGL(mlp_small_grads_stage2, dim3((kSgStride + 63) / 64), dim3(256), 0, st, part2, sblk,
                        NL, o);
   }

@@ -189,20 +189,26 @@ class MLP:
         self._ws = torch.empty(256 * 1024, dtype=F32, device=device)
         self._ones = torch.ones(self._B, dtype=F32, device=device)
 
-    def backward(self, g, dxe, fm_sum=None):
+    def backward(self, g, dxe, fm_sum=None, lin_grads=None):
         """g [B] = dLoss/dlogit; writes dLoss/dxe into dxe [B,FD] and the parameter
         gradients into self.g.  (No gradient is needed for the dense inputs.)
         fm_sum [B,D]: also add the FM second-order gradient g*(S - E) (fused path only;
-        returns True when it was added)."""
+        returns True when it was added).  lin_grads = (d_w_dense [Dn], d_w0 [1]): the linear
+        term's dense-weight gradients g^T xd and sum g ride along too (fused path, Dn <= 32):
+        self.lin_done tells the caller whether they were written."""
         p, gr, pre = self.p, self.g, self.prefix
         n = len(self.hidden)
+        self.lin_done = False
         if self.fused:
             Ws = [p[f"{pre}dnn_layer_{i}_weights"] for i in range(n)]
             ops.mlp_bwd(self.xe, self.xd if self.Dn else None, Ws, p[f"{pre}dnn_w"].view(-1), self.act,
                         g, self.hb, dxe, self.dhb, [gr[f"{pre}dnn_layer_{i}_weights"] for i in range(n)],
                         self.fws, fm_sum=fm_sum,
                         db=[gr[f"{pre}dnn_layer_{i}_bias"] for i in range(n)],
-                        d_w_out=gr[f"{pre}dnn_w"].view(-1), d_w0_out=gr[f"{pre}dnn_w0"])
+                        d_w_out=gr[f"{pre}dnn_w"].view(-1), d_w0_out=gr[f"{pre}dnn_w0"],
+                        d_xd_wsum=lin_grads[0] if (lin_grads and 1 <= self.Dn <= 32) else None,
+                        d_g_sum=lin_grads[1] if (lin_grads and 1 <= self.Dn <= 32) else None)
+            self.lin_done = bool(lin_grads and 1 <= self.Dn <= 32)
             return fm_sum is not None
         ops.linear_dense_bwd(g, self.a[-1], gr[f"{pre}dnn_w"].view(-1), gr[f"{pre}dnn_w0"], self._ws)
         # d(pre-activation of the last layer) = (g w_out^T) o mask o act'(a): a K = 1 GEMM whose
@@ -517,12 +523,19 @@ class Engine:
             # this batch is one of several micro-batches of a step: its gradients are its share
             # of the full-batch mean (recman_amd/dist.py)
             self.dlogit.mul_(self.grad_scale)
+        self._lin_done = False
         self._branches_bwd(idx, dense, self.dlogit, masks)
-        if self.use_linear:
+        if self.use_linear and not self._lin_done:
             ops.linear_dense_bwd(self.dlogit, dense if self.Dn else None,
                                  self.grads["linear_w_dense"] if self.Dn else None,
                                  self.grads["linear_w0"], self.ws)
         return self._add_l2(self.loss)
+
+    def _lin_grads(self):
+        """(d linear_w_dense, d linear_w0) for MLP.backward to fill when the linear term is on."""
+        if not (self.use_linear and self.Dn):
+            return None
+        return (self.grads["linear_w_dense"], self.grads["linear_w0"])
 
     def _add_l2(self, loss):
         hp = self.hp
@@ -696,7 +709,9 @@ class DeepFMEngine(Engine):
             # fused path: the FM gradient g*(S - E) rides along in the MLP backward
             fuse_fm = self.use_fm and fm_masks[0] is None and fm_masks[1] is None
             fm_done = self.mlp.backward(g, self.d_rows.view(-1, self.FD),
-                                        fm_sum=self.fm_sum if fuse_fm else None)
+                                        fm_sum=self.fm_sum if fuse_fm else None,
+                                        lin_grads=self._lin_grads())
+            self._lin_done = self.mlp.lin_done
             dE_up = self.d_rows
         if self.use_fm and fm_masks[0] is not None:
             self.d_bias = torch.empty(idx.shape[0], self.F, dtype=F32, device=self.device)
@@ -966,7 +981,8 @@ class XDeepFMEngine(Engine):
     def _branches_bwd(self, idx, dense, g, masks):
         p, gr = self.params, self.grads
         # DNN first: it STORES dLoss/dE into d_rows; every CIN layer then accumulates
-        self.mlp.backward(g, self.d_rows.view(-1, self.FD))
+        self.mlp.backward(g, self.d_rows.view(-1, self.FD), lin_grads=self._lin_grads())
+        self._lin_done = self.mlp.lin_done
         ops.linear_dense_bwd(g, self.pooled, gr["cin_w"].view(-1), gr["cin_w0"], self.ws)
         cw = p["cin_w"].view(-1)
         L = len(self.units)

@@ -270,7 +270,7 @@ def mlp_fwd(xe, xd, Ws, bs, w_out, w0_out, act, h_out, logit):
 
 
 def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None, db=None,
-            d_w_out=None, d_w0_out=None):
+            d_w_out=None, d_w0_out=None, d_xd_wsum=None, d_g_sum=None):
     B, FD = xe.shape
     Dn = 0 if xd is None else xd.shape[1]
     H = [W.shape[1] for W in Ws]
@@ -289,6 +289,8 @@ def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None
               _ptr_array(dh), _ptr_array(dW), None if db is None else _ptr_array(db),
               _chk(d_w_out, "d_w_out", F32, (H[-1],), allow_none=True),
               _chk(d_w0_out, "d_w0_out", F32, (1,), allow_none=True),
+              _chk(d_xd_wsum, "d_xd_wsum", F32, (Dn,), allow_none=True),
+              _chk(d_g_sum, "d_g_sum", F32, (1,), allow_none=True),
               _chk(workspace, "workspace", F32), _stream())
 
 
