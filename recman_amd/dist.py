@@ -46,6 +46,37 @@ PAD = 4  # bias, linear weight, 2 floats of padding: fused row width D + 4 (16-b
 FORCE = os.environ.get("RECMAN_FORCE_COLLECTIVES", "0") == "1"
 
 
+class _Done:
+    """A finished collective (what the host-staged rehearsal path returns for async_op=True)."""
+
+    def wait(self):
+        return True
+
+
+def _host_staged(t, group):
+    """GPU tensors over the gloo backend (2+ ranks on ONE GPU: a rehearsal of the multi-rank logic
+    on the real kernels, tests/test_gpu_dist.py): staged through host memory, synchronously."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_to_all(out, inp, out_splits=None, in_splits=None, group=None, async_op=False):
+    if _host_staged(inp, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+        return _Done() if async_op else None
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
+
+
+def _all_reduce(t, group=None):
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+        return
+    dist.all_reduce(t, group=group)
+
+
 def shard_rows(R, rank, world):
     """Number of global rows r in [0, R) with r % world == rank."""
     return (R - rank + world - 1) // world
@@ -91,7 +122,7 @@ class RowExchange:
             self.send_counts = self.recv_counts = None
             if self.coll:
                 self.recv_ids = torch.empty_like(self.send_ids)
-                dist.all_to_all_single(self.recv_ids, self.send_ids, group=group)
+                _all_to_all(self.recv_ids, self.send_ids, group=group)
             else:
                 self.recv_ids = self.send_ids
             return
@@ -100,13 +131,12 @@ class RowExchange:
         if self.coll:
             both = torch.empty(2, world, dtype=counts.dtype, device=counts.device)
             both[0].copy_(counts)
-            dist.all_to_all_single(both[1], both[0], group=group)
+            _all_to_all(both[1], both[0], group=group)
             # ONE host sync per batch: the split sizes of the row exchanges must be host-side
             self.send_counts, self.recv_counts = both.tolist()
             self.recv_ids = torch.empty(sum(self.recv_counts), dtype=self.send_ids.dtype,
                                         device=self.send_ids.device)
-            dist.all_to_all_single(self.recv_ids, self.send_ids, self.recv_counts, self.send_counts,
-                                   group=group)
+            _all_to_all(self.recv_ids, self.send_ids, self.recv_counts, self.send_counts, group=group)
         else:
             self.send_counts = self.recv_counts = [self.n]
             self.recv_ids = self.send_ids
@@ -119,8 +149,8 @@ class RowExchange:
         if not self.coll:
             return (owner_rows, None) if async_op else owner_rows
         out = torch.empty(self.slots, owner_rows.shape[1], dtype=owner_rows.dtype, device=owner_rows.device)
-        work = dist.all_to_all_single(out, owner_rows, self.send_counts, self.recv_counts, group=self.group,
-                                      async_op=async_op)
+        work = _all_to_all(out, owner_rows, self.send_counts, self.recv_counts, group=self.group,
+                           async_op=async_op)
         return (out, work) if async_op else out
 
     def push(self, bucketed_rows, async_op=False):
@@ -130,8 +160,8 @@ class RowExchange:
             return (bucketed_rows, None) if async_op else bucketed_rows
         out = torch.empty(len(self.recv_ids), bucketed_rows.shape[1], dtype=bucketed_rows.dtype,
                           device=bucketed_rows.device)
-        work = dist.all_to_all_single(out, bucketed_rows, self.recv_counts, self.send_counts,
-                                      group=self.group, async_op=async_op)
+        work = _all_to_all(out, bucketed_rows, self.recv_counts, self.send_counts, group=self.group,
+                           async_op=async_op)
         return (out, work) if async_op else out
 
 
@@ -239,20 +269,22 @@ def flatten_grads(grads):
     return flat
 
 
-def allreduce_dense(grads, world, group=None, flat=None):
-    """One flat all_reduce (sum / world) over every dense-parameter gradient; in place when
-    the gradients already live in `flat` (flatten_grads)."""
+def allreduce_dense(grads, world, group=None, flat=None, average=True):
+    """One flat all_reduce over every dense-parameter gradient (sum / world, or the plain sum
+    when the per-rank gradients already carry the 1/world factor); in place when the gradients
+    already live in `flat` (flatten_grads)."""
     if world == 1 and not (FORCE and dist.is_initialized()):
         return
     if flat is not None:
-        dist.all_reduce(flat, group=group)
-        if world > 1:
+        _all_reduce(flat, group)
+        if world > 1 and average:
             flat.div_(world)
         return
     keys = sorted(grads)
     flat = torch.cat([grads[k].reshape(-1) for k in keys])
-    dist.all_reduce(flat, group=group)
-    flat.div_(world)
+    _all_reduce(flat, group)
+    if average:
+        flat.div_(world)
     off = 0
     for k in keys:
         n = grads[k].numel()
@@ -392,21 +424,25 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             M = self.micro_batches
             B = idx.shape[0]
             self._alloc(B if M <= 1 else B // M)
+            l2 = any(self.hp.get(k, 0.0) for k in ("deep_l2_reg", "cin_l2_reg", "cross_layer_l2_reg",
+                                                   "embedding_l2_reg", "linear_l2_reg"))
+            if l2 and (world > 1 or M > 1):
+                raise NotImplementedError("l2 terms with a row-sharded table over several ranks / "
+                                          "micro-batches (they would be added once per rank and micro-batch)")
+            # every gradient is the gradient of the GLOBAL batch mean: each rank's (micro-)batch
+            # carries 1/(world*M), the owners sum the rows they receive, the dense all_reduce sums
+            self.grad_scale = 1.0 / (world * M)
             if M <= 1:
                 loss, ids, rows, work = self._one(idx, dense, y, masks, self.grad_rows)
                 if work is not None:
                     work.wait()
                 self.shard_grad_ids, self.shard_grad_rows = ids, rows
-                allreduce_dense(self.grads, world, group, self._flat_grads)
+                allreduce_dense(self.grads, world, group, self._flat_grads, average=False)
                 return loss
             if B % M or masks is not None:
                 raise ValueError("micro-batching needs a batch divisible by micro_batches and no dropout masks")
-            if any(self.hp.get(k, 0.0) for k in ("deep_l2_reg", "cin_l2_reg", "cross_layer_l2_reg",
-                                                  "embedding_l2_reg", "linear_l2_reg")):
-                raise NotImplementedError("micro-batching with l2 terms (they would be added once per micro-batch)")
             b = B // M
             parts = [(idx[c * b: (c + 1) * b], dense[c * b: (c + 1) * b], y[c * b: (c + 1) * b]) for c in range(M)]
-            self.grad_scale = 1.0 / M
             started = self.st.lookup_start(parts[0][0], self.field_off)
             outs, total = [], None
             for c in range(M):
@@ -421,14 +457,13 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 else:
                     self._acc.add_(self._flat_grads)
                     total.add_(loss)
-            self.grad_scale = 1.0
-            self._flat_grads.copy_(self._acc)  # every chunk already carries the 1/M factor
+            self._flat_grads.copy_(self._acc)  # every chunk already carries the 1/(world*M) factor
             for _, _, work in outs:
                 if work is not None:
                     work.wait()
             self.shard_grad_ids = [o[0] for o in outs]
             self.shard_grad_rows = [o[1] for o in outs]
-            allreduce_dense(self.grads, world, group, self._flat_grads)
+            allreduce_dense(self.grads, world, group, self._flat_grads, average=False)
             return total.div_(M)
 
         def overflowed(self):

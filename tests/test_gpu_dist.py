@@ -1,0 +1,106 @@
+"""GPU: the row-sharded ENGINE with two ranks - two processes sharing the one GPU of the test box,
+collectives over gloo staged through host memory (recman_amd.dist._host_staged).  Everything else is
+the product path: HIP routing / gather / pack kernels, fixed-capacity and dynamic exchange layouts,
+micro-batch pipelining.  Rank r owns table rows r::2 and its own half of the global batch; the
+result must equal the single-GPU engine on the whole batch (gradients of the global-batch mean)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, model, kw, fixed, micro, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("RECMAN_FORCE_COLLECTIVES", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from recman_amd import dist as rd
+        from recman_amd import engine as eng
+        from tests.cases import make_case
+
+        Bl = 24  # per-rank batch
+        spec, p, idx, dense, y, hp = make_case(model, B=world * Bl, D=16, **kw)
+        hp = dict(hp, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=0.0, cross_layer_l2_reg=0.0,
+                  cin_l2_reg=0.0)
+        espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names)
+        dev = torch.device("cuda", 0)
+        s = rd.make_sharded_engine(model, espec, 16, hp, dev, rank, world,
+                                   capacity_factor=1.5 if fixed else None, micro_batches=micro)
+        s.load_params({k: v for k, v in p.items() if k in s.params})
+        full = torch.cat([p[f"{n}_feat_embed"] for n in spec.sparse_names])
+        bias = (torch.cat([p[f"{n}_feat_bias"].reshape(-1) for n in spec.sparse_names])
+                if model == "deepfm" else None)
+        R, D = full.shape[0], 16
+        s.st.load_global(full, bias=bias, lin=p["linear_w"].reshape(-1)[:R])
+        s.linear_w_dense.copy_(p["linear_w"].reshape(-1)[R:])
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        loss = s.fwd_bwd(idx[sl].cuda(), dense[sl].cuda(), y[sl].cuda())
+        assert not s.overflowed()
+        ids, rows = s.shard_grad_ids, s.shard_grad_rows
+        if not isinstance(ids, list):
+            ids, rows = [ids], [rows]
+        dt = torch.zeros(s.st.shard.shape[0], D + rd.PAD, device=dev)
+        for i, r in zip(ids, rows):
+            live = i >= 0
+            dt.index_add_(0, i[live], r[live])
+        torch.save({"loss": loss.cpu(), "dt": dt.cpu(), "grads": {k: v.cpu() for k, v in s.grads.items()},
+                    "logit": s.logit.cpu()}, f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,kw,fixed,micro", [
+    ("deepfm", {}, True, 1),
+    ("deepfm", {}, False, 2),
+    ("dcn", dict(cross_layers=2, scale=0.15), True, 2),
+    ("xdeepfm", dict(cin_units=(16, 8), scale=0.2), False, 1),
+])
+def test_two_rank_sharded_engine_equals_single_gpu(hip_lib, tmp_path, model, kw, fixed, micro):
+    from recman_amd import dist as rd
+    from recman_amd import engine as eng
+    from tests.cases import make_case
+
+    world, Bl = 2, 24
+    out = str(tmp_path / "r")
+    port = 29700 + (hash((model, fixed, micro)) % 200)
+    mp.spawn(_worker, args=(world, port, model, kw, fixed, micro, out), nprocs=world, join=True)
+    res = [torch.load(f"{out}.{r}", weights_only=True) for r in range(world)]
+
+    spec, p, idx, dense, y, hp = make_case(model, B=world * Bl, D=16, **kw)
+    hp = dict(hp, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=0.0, cross_layer_l2_reg=0.0,
+              cin_l2_reg=0.0)
+    e = eng.ENGINES[model](eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names), 16, hp)
+    e.load_params({k: v for k, v in p.items() if k in e.params or k == "linear_w"})
+    loss = e.fwd_bwd(idx.cuda(), dense.cuda(), y.cuda()).cpu()
+    gd = e.dense_grads(idx.cuda(), reference_names=True)
+    gi = e.dense_grads(idx.cuda())
+    R, D = sum(spec.feat_sizes), 16
+
+    def close(got, want, what, atol=2e-6):
+        want = want.detach().cpu().double()
+        err = float((got.double() - want).abs().max())
+        scale = max(1.0, float(want.abs().max()))
+        assert err <= atol * scale + 1e-7, f"{what}: {err:.3e}"
+
+    close(torch.stack([r["loss"] for r in res]).mean(0), loss, "loss (mean of the ranks' means)")
+    if micro == 1:  # (with micro-batches the engine's logit buffer holds the last micro-batch only)
+        close(torch.cat([r["logit"] for r in res]), e.logit, "logit")
+    want_t = torch.cat([gd[f"{n}_feat_embed"] for n in spec.sparse_names]).cpu()
+    want_l = gd["linear_w"].reshape(-1)[:R].cpu()
+    for r in range(world):
+        close(res[r]["dt"][:, :D], want_t[r::world], f"table grad of rank {r}'s shard")
+        close(res[r]["dt"][:, D + 1], want_l[r::world], f"linear grad of rank {r}'s shard")
+        if model == "deepfm":
+            want_b = torch.cat([gd[f"{n}_feat_bias"].reshape(-1) for n in spec.sparse_names]).cpu()
+            close(res[r]["dt"][:, D], want_b[r::world], f"bias grad of rank {r}'s shard")
+        for k, v in res[r]["grads"].items():
+            if k in gi:
+                close(v, gi[k], f"rank {r} dense grad {k}")
