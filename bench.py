@@ -168,13 +168,21 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # RECMAN_REHEARSE_ONE_GPU=1: every rank on GPU 0 with gloo (host-staged) collectives - a
+    # rehearsal of the multi-rank control flow on a one-GPU box, not a measurement
+    rehearse = os.environ.get("RECMAN_REHEARSE_ONE_GPU", "0") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from recman_amd import engine as eng
 
@@ -212,6 +220,7 @@ def main():
             return False
         hit = torch.tensor([1.0 if engine.overflowed() else 0.0], device=dev)
         if dist is not None and world > 1:
+            hit = hit.cpu() if rehearse else hit
             dist.all_reduce(hit, op=dist.ReduceOp.MAX)
         return bool(hit.item() > 0)
 
@@ -253,7 +262,7 @@ def main():
     if any_overflow():
         raise SystemExit("[bench] a timed batch overflowed the fixed-capacity exchange: rerun with --exchange dynamic")
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     ms = elapsed / a.steps * 1e3
