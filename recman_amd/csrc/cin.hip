@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
 __global__ __launch_bounds__(256) void cin_dm_kernel(
     const float *__restrict__ out, const float *__restrict__ d_hidden, int64_t dh_bstride,
     const float *__restrict__ g, const float *__restrict__ cw, int pool_from, int act, int64_t B,
-    int N, int Np, int D, float *__restrict__ dM, float *__restrict__ dbias) {
+    int N, int Np, int D, float *__restrict__ dM, float *__restrict__ dbias_part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *tile = smem;             // [D][Np + 1]
   float *colsum = tile + D * (Np + 1);  // [Np]
@@ -250,7 +250,19 @@ __global__ __launch_bounds__(256) void cin_dm_kernel(
     }
   }
   __syncthreads();
-  if (tid < N && dbias != nullptr) atomicAdd(dbias + tid, colsum[tid]);
+  // per-block partial column sums; cin_dbias_reduce_kernel adds them in block order
+  // (deterministic - a float atomicAdd here made cin_bias gradients differ in the last bits
+  // between two identical steps)
+  if (tid < Np) dbias_part[(int64_t)blockIdx.x * Np + tid] = colsum[tid];
+}
+
+__global__ void cin_dbias_reduce_kernel(const float *__restrict__ part, int nblk, int N, int Np,
+                                        float *__restrict__ dbias) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int i = 0; i < nblk; ++i) s += part[(int64_t)i * Np + n];
+  dbias[n] = s;
 }
 
 // dX-kernel k' ordering: k' = i*Hp + j with Hp = H rounded up to 32, so that every
@@ -444,6 +456,7 @@ size_t cin_dx_smem(int m, int H, int NT, int rows) {
 // dW partial: part[s][k'][n] = sum over the split's rows p of Z[p][k'] * dM[p][n].
 // MFMA with the rows as the reduction dimension: A = Z^T (formed in registers from the
 // [row][field] LDS images), B = dM rows.  A wave owns 4 k'-tiles x NT n-tiles.
+constexpr int kDmBlocks = 256 * 8;  // grid cap of the dM pass (= rows of its dbias partials)
 constexpr int kRC = 64;   // rows per staged chunk
 constexpr int kKT = 2;    // k'-tiles per wave
 constexpr int kDWW = 8;   // waves per dW block (2 per SIMD)
@@ -747,7 +760,7 @@ extern "C" int64_t rm_cin_bwd_workspace(int64_t B, int m, int H, int N, int D) {
   const int Np = 32 * NT, Kp = cin_Kp(m, H);
   const int64_t chunks_total = (B * D + kRC - 1) / kRC;
   const DwPlan plan = cin_dw_plan(Kp, chunks_total > 0 ? chunks_total : 1, 256);
-  return (int64_t)m * cin_Hp(H) * Np + B * D * Np + (int64_t)plan.Smax * Kp * Np;
+  return (int64_t)m * cin_Hp(H) * Np + B * D * Np + (int64_t)plan.Smax * Kp * Np + (int64_t)kDmBlocks * Np;
 }
 
 extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int xk_is_x0,
@@ -779,13 +792,21 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
   float *dM = Wq + (int64_t)m * cin_Hp(H) * Np;
   float *part = dM + B * D * Np;
   hipStream_t st = (hipStream_t)stream;
+  float *dbias_part;
+  {
+    const int64_t chunks_total = (B * D + kRC - 1) / kRC;
+    const DwPlan plan0 = cin_dw_plan(Kp, chunks_total > 0 ? chunks_total : 1, 256);
+    dbias_part = part + (int64_t)plan0.Smax * Kp * Np;  // [kDmBlocks][Np]
+  }
 
-  hipMemsetAsync(dbias, 0, sizeof(float) * N, st);
   hipLaunchKernelGGL(cin_prep_bwd_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, Np, Wq);
   {
     const size_t smem = (size_t)(D * (Np + 1) + Np) * sizeof(float);
-    hipLaunchKernelGGL(cin_dm_kernel, dim3(rm_grid_cap(B, 256 * 8)), dim3(256), smem, st, out,
-                       d_hidden, dh_bstride, g, cin_w_direct, pool_from, act, B, N, Np, D, dM, dbias);
+    const int nblk = rm_grid_cap(B, kDmBlocks);
+    hipLaunchKernelGGL(cin_dm_kernel, dim3(nblk), dim3(256), smem, st, out, d_hidden, dh_bstride, g,
+                       cin_w_direct, pool_from, act, B, N, Np, D, dM, dbias_part);
+    hipLaunchKernelGGL(cin_dbias_reduce_kernel, dim3((N + 63) / 64), dim3(64), 0, st, dbias_part, nblk, N,
+                       Np, dbias);
   }
   {
     const int rows = (kRC * 2 % D == 0 && 256 % D == 0 && cin_dx_smem(m, H, NT, 256) <= 160 * 1024) ? 256 : 128;

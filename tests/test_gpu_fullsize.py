@@ -1,0 +1,102 @@
+"""GPU: the three BASELINE.json single-GPU configurations at their FULL sizes (26 x 1,000,001-row
+tables, batch 65536 / 131072), checked through size-independent properties plus the oracle on a
+slice the CPU finishes in seconds:
+  * batch independence - the logits of a slice of the full batch equal (bit for bit) the logits
+    of that slice run alone, and equal the CPU oracle within 1e-5;
+  * linearity of the mean - loss and dense gradients of the full batch equal the average over its
+    two halves; the row gradients of a slice scale with 1/batch;
+  * determinism - two runs of the same step give bit-identical results (no float atomics on the path).
+"""
+import pytest
+import torch
+
+from oracle import th_layers as T
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "deepfm": dict(B=65536, hp=dict(deep_hidden_units=(32, 32), deep_activation="relu"), oracle_rows=4096),
+    "xdeepfm": dict(B=65536, hp=dict(deep_hidden_units=(32, 32), deep_activation="leaky_relu",
+                                      cin_cross_layer_units=(128, 128), cin_activation="leaky_relu"),
+                    oracle_rows=1024),
+    "dcn": dict(B=131072, hp=dict(deep_hidden_units=(400, 400), deep_activation="relu", cross_layer_num=6),
+                oracle_rows=2048),
+}
+F, V, Dn, D = 26, 1_000_001, 13, 16
+
+
+@pytest.mark.parametrize("model", ["deepfm", "xdeepfm", "dcn"])
+def test_full_size_properties(hip_lib, model):
+    from recman_amd import engine as eng
+
+    cfg = CONFIGS[model]
+    B = cfg["B"]
+    hp = dict(cfg["hp"], embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=0.0, cin_l2_reg=0.0,
+              cross_layer_l2_reg=0.0)
+    spec = eng.FeatureSpec([f"C{i + 1}" for i in range(F)], [V] * F, [f"I{j + 1}" for j in range(Dn)])
+    e = eng.ENGINES[model](spec, D, hp)
+    g = torch.Generator(device="cuda").manual_seed(2019)
+    for base in e.storage():
+        flat = base.view(-1)
+        for s in range(0, flat.numel(), 1 << 26):
+            t = min(flat.numel(), s + (1 << 26))
+            flat[s:t] = torch.randn(t - s, generator=g, device="cuda") * 0.01
+    idx = torch.randint(0, V, (B, F), generator=g, device="cuda")
+    dense = torch.randn(B, Dn, generator=g, device="cuda")
+    y = (torch.rand(B, generator=g, device="cuda") < 0.25).long()
+
+    loss = e.fwd_bwd(idx, dense, y).clone()
+    logit = e.logit.clone()
+    grads = {k: v.clone() for k, v in e.grads.items()}
+    d_rows = e.d_rows.clone()
+    # determinism
+    loss2 = e.fwd_bwd(idx, dense, y)
+    assert torch.equal(loss2, loss) and torch.equal(e.logit, logit) and torch.equal(e.d_rows, d_rows)
+    for k in grads:
+        assert torch.equal(e.grads[k], grads[k]), f"grad {k} differs between two identical steps"
+
+    # linearity of the mean over the two halves
+    h = B // 2
+    acc, lsum = {k: torch.zeros_like(v) for k, v in grads.items()}, 0.0
+    for sl in (slice(0, h), slice(h, B)):
+        lsum = lsum + e.fwd_bwd(idx[sl].contiguous(), dense[sl].contiguous(), y[sl].contiguous())
+        for k in acc:
+            acc[k] += e.grads[k]
+    assert abs(float(lsum) / 2 - float(loss)) < 1e-6
+    for k in grads:
+        want = grads[k]
+        err = float((acc[k] / 2 - want).abs().max())
+        assert err <= 2e-5 * max(1e-3, float(want.abs().max())), f"grad {k}: {err:.3e}"
+
+    # batch independence of a slice, and the oracle on it
+    n = cfg["oracle_rows"]
+    sl = slice(B - n, B)
+    e.fwd_bwd(idx[sl].contiguous(), dense[sl].contiguous(), y[sl].contiguous())
+    assert torch.equal(e.logit, logit[sl]), "logits depend on the rest of the batch"
+    scale = float(d_rows[sl].abs().max())
+    assert float((e.d_rows * (n / B) - d_rows[sl]).abs().max()) <= 2e-5 * scale
+    tspec = T.Spec(spec.sparse_names, spec.feat_sizes, spec.dense_names)
+    # the oracle only needs the table rows this slice touches: compact them (1M-row tables would
+    # make the CPU autograd pass allocate gigabytes)
+    p = {k: v.cpu() for k, v in e.state_dict().items() if not k.endswith("_feat_embed")
+         and not k.endswith("_feat_bias") and k != "linear_w"}
+    sd = e.state_dict()
+    idx_c = idx[sl].cpu()
+    small_sizes, idx_small = [], torch.empty_like(idx_c)
+    lin_parts = []
+    off = 0
+    for f, name in enumerate(spec.sparse_names):
+        uniq, inv = torch.unique(idx_c[:, f], return_inverse=True)
+        small_sizes.append(len(uniq))
+        idx_small[:, f] = inv
+        p[f"{name}_feat_embed"] = sd[f"{name}_feat_embed"][uniq.cuda()].cpu()
+        if f"{name}_feat_bias" in sd:
+            p[f"{name}_feat_bias"] = sd[f"{name}_feat_bias"][uniq.cuda()].cpu()
+        lin_parts.append(sd["linear_w"][off + uniq.cuda()].cpu())
+        off += V
+    lin_parts.append(sd["linear_w"][off:].cpu())
+    p["linear_w"] = torch.cat(lin_parts)
+    small = T.Spec(spec.sparse_names, small_sizes, spec.dense_names)
+    logit_o = T.MODELS[model][0](p, small, idx_small, dense[sl].cpu(), hp, training=True).reshape(-1)
+    err = float((logit[sl].cpu() - logit_o).abs().max())
+    assert err < 1e-5, f"max |logit - oracle| = {err:.3e}"
