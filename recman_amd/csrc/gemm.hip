@@ -102,35 +102,7 @@ struct NNArgs {
   int64_t ldc, ldc2;
 };
 
-// the lane's KC/8 float4 of A for chunk k0: k = k0 + 8q + 4h + e
-// fast: the whole chunk lies inside A1 (caller guarantees k0 + 16 <= K1)
-constexpr int AQ = KC / 8;  // float4 of A per lane per chunk
-__device__ __forceinline__ void load_a_fast(float4 (&v)[AQ], const NNArgs &a, int64_t row, int k0, int h) {
-#pragma unroll
-  for (int q = 0; q < AQ; ++q)
-    v[q] = *reinterpret_cast<const float4 *>(a.A1 + row * a.lda1 + k0 + 8 * q + 4 * h);
-}
-// tail: any chunk; per element A1 / A2 / zero by selects on clamped addresses - no branches, so
-// the 16 loads issue back to back (a second piece that does not exist aliases A1)
-__device__ __forceinline__ void load_a_tail(float4 (&v)[AQ], const NNArgs &a, int64_t row, int k0, int h) {
-  const float *A2 = a.K2 > 0 ? a.A2 : a.A1;
-  const int64_t lda2 = a.K2 > 0 ? a.lda2 : a.lda1;
-#pragma unroll
-  for (int q = 0; q < AQ; ++q) {
-    float t[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k = k0 + 8 * q + 4 * h + e;
-      const bool in1 = k < a.K1;
-      const int k2 = k - a.K1;
-      const bool in2 = !in1 && k2 < a.K2;
-      const float x1 = a.A1[row * a.lda1 + (in1 ? k : 0)];
-      const float x2 = A2[row * lda2 + (in2 ? k2 : 0)];
-      t[e] = in1 ? x1 : (in2 ? x2 : 0.f);
-    }
-    v[q] = make_float4(t[0], t[1], t[2], t[3]);
-  }
-}
+constexpr int AQ = KC / 8;  // float4 of A fragments per lane per weight chunk
 
 // One wave of the NN kernel with EXACTLY NT accumulators (no conditional MFMAs: a per-MFMA
 // `if (nt < ntw)` cost 16 branches per chunk and fenced the scheduler).  ntw <= NT is the number
@@ -139,8 +111,6 @@ template <int NT>
 __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int c, int h, int rg,
                                         int cg, int ct, const ColTile tl, int ntw) {
   const int64_t row0 = (int64_t)blockIdx.x * kNNRows + 32 * rg;
-  int64_t row = row0 + c;
-  row = row < a.M ? row : a.M - 1;
   const float *Wp = a.Wp + (int64_t)ct * a.nch * WCH;
 
   f32x16 acc[NT];
@@ -149,16 +119,49 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-  // prologue: chunk 0 of the weights to LDS, chunk 0 of A to registers
-  constexpr int WQ = WCH / 4 / kNNThreads;  // float4 of a weight chunk per thread (8)
+  // A goes through LDS in FULL 128-byte lines: per group of 32 k the block stages its 128 rows once
+  // (8 lanes per row) and both column-group waves read their fragments from there.  The first
+  // version loaded fragments straight to registers - 32 rows x 32 bytes per instruction, issued
+  // twice (once per column group): +85 us of 525 in the ablation (profiles/r01_p8).
+  constexpr int AG = 32;                      // k per A group = 2 weight chunks
+  constexpr int ALD = AG + 4;                 // LDS row stride of the A tile (floats)
+  float *As = Ws + 2 * WCH;                   // [2][kNNRows][ALD]
+  const int64_t brow0 = (int64_t)blockIdx.x * kNNRows;
+  const int ngroups = (a.nch + 1) / 2;
+  const int gfast = a.a_vec ? a.K1 / AG : 0;  // groups inside A1 that float4 loads can take
+  const float *A2 = a.K2 > 0 ? a.A2 : a.A1;
+  const int64_t lda2 = a.K2 > 0 ? a.lda2 : a.lda1;
+  // this thread's two float4 of a group: f = tid + 512*i -> row f >> 3, piece f & 7
+  auto load_group = [&](int g, int i) -> float4 {
+    const int f = tid + i * kNNThreads, r = f >> 3, piece = f & 7;
+    int64_t gr = brow0 + r;
+    gr = gr < a.M ? gr : a.M - 1;
+    const int k = g * AG + 4 * piece;
+    if (g < gfast) return *reinterpret_cast<const float4 *>(a.A1 + gr * a.lda1 + k);
+    float t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // ragged group: A1 / second piece / zero, by selects
+      const int kk = k + e;
+      const bool in1 = kk < a.K1;
+      const int k2 = kk - a.K1;
+      const bool in2 = !in1 && k2 < a.K2;
+      const float x1 = a.A1[gr * a.lda1 + (in1 ? kk : 0)];
+      const float x2 = A2[gr * lda2 + (in2 ? k2 : 0)];
+      t[e] = in1 ? x1 : (in2 ? x2 : 0.f);
+    }
+    return make_float4(t[0], t[1], t[2], t[3]);
+  };
+  const int a_lds0 = (tid >> 3) * ALD + 4 * (tid & 7);                   // float4 slot i = 0
+  const int a_lds1 = ((tid + kNNThreads) >> 3) * ALD + 4 * (tid & 7);    // float4 slot i = 1
+
+  // prologue: weight chunk 0 and A group 0 to LDS
+  constexpr int WQ = WCH / 4 / kNNThreads;  // float4 of a weight chunk per thread
 #pragma unroll
   for (int q = 0; q < WQ; ++q)
     *reinterpret_cast<float4 *>(Ws + (tid + q * kNNThreads) * 4) =
         *reinterpret_cast<const float4 *>(Wp + (tid + q * kNNThreads) * 4);
-  float4 acur[AQ];
-  const int nfull = a.a_vec ? a.K1 / KC : 0;  // chunks inside A1 that float4 loads can take
-  if (nfull > 0) load_a_fast(acur, a, row, 0, h);
-  else load_a_tail(acur, a, row, 0, h);
+  *reinterpret_cast<float4 *>(As + a_lds0) = load_group(0, 0);
+  *reinterpret_cast<float4 *>(As + a_lds1) = load_group(0, 1);
   __syncthreads();
 
   // B operands of one k-step: the lane's NT weights = two ds_read_b128
@@ -168,11 +171,13 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
     t0 = *reinterpret_cast<const float4 *>(wp);
     if constexpr (NT > 4) t1 = *reinterpret_cast<const float4 *>(wp + 128);
   };
-  // one chunk: prefetch the next chunk (always - the last iteration re-loads its own chunk into
-  // the idle buffer: a conditional prefetch made hipcc park the registers in scratch behind an
-  // s_waitcnt vmcnt(0)), KC/2 k-steps of MFMAs with the B operands read one step ahead,
-  // commit the prefetch, barrier
-  auto chunk = [&](int ch, auto fast_next) {
+  float4 an0, an1;  // the next A group, in flight over the two chunks of the current one
+  // one weight chunk: prefetch the next chunk (always - the last iteration re-loads its own chunk
+  // into the idle buffer: a conditional prefetch made hipcc park the registers in scratch behind
+  // an s_waitcnt vmcnt(0)), KC/2 k-steps of MFMAs, commit the prefetch, barrier.
+  // first_of_group: also issue the next A group's loads; otherwise commit them before the barrier.
+  auto chunk = [&](int ch, auto first_of_group) {
+    constexpr bool kFirst = decltype(first_of_group)::value;
     const int nx = ch + 1 < a.nch ? ch + 1 : ch;
     const float *wsrc = Wp + (int64_t)nx * WCH + tid * 4;
     static_assert(WQ <= 8, "the prefetch below is written out for up to 8 float4 per thread");
@@ -181,13 +186,21 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
   const float4 w##q = q < WQ ? *reinterpret_cast<const float4 *>(wsrc + (q < WQ ? q : 0) * kNNThreads * 4) : float4{}
     RM_W(0); RM_W(1); RM_W(2); RM_W(3); RM_W(4); RM_W(5); RM_W(6); RM_W(7);
 #undef RM_W
-    float4 anext[AQ];
-    if constexpr (decltype(fast_next)::value) load_a_fast(anext, a, row, nx * KC, h);
-    else load_a_tail(anext, a, row, nx * KC, h);
+    const int g = ch >> 1;
+    if constexpr (kFirst) {
+      const int gn = g + 1 < ngroups ? g + 1 : g;
+      an0 = load_group(gn, 0);
+      an1 = load_group(gn, 1);
+    }
     // keep the prefetch HERE: without the fence the scheduler sinks the global loads to their
     // first use (the ds_write at the end of the chunk) and the whole L2 latency is exposed
     __builtin_amdgcn_sched_barrier(0);
     const float *Wb = Ws + (ch & 1) * WCH;
+    // this lane's A fragments of the chunk: row 32*rg + c, k = 16*(ch & 1) + 8q + 4h + e
+    const float *ap = As + (g & 1) * (kNNRows * ALD) + (32 * rg + c) * ALD + 16 * (ch & 1) + 4 * h;
+    float4 acur[AQ];
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) acur[q] = *reinterpret_cast<const float4 *>(ap + 8 * q);
     float4 b0[2], b1[2];
     read_b(Wb, 0, b0[0], b1[0]);
 #pragma unroll
@@ -200,8 +213,6 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt], acc[nt], 0, 0, 0);
-      // emit "next step's LDS reads, then this step's MFMAs": left alone the scheduler reads
-      // just in time and every step starts with an exposed ds_read latency
 #if RM_GEMM_SGB
       __builtin_amdgcn_sched_group_barrier(0x100, NT > 4 ? 2 : 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
@@ -212,13 +223,20 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
   if constexpr (q < WQ) *reinterpret_cast<float4 *>(wdst + q * kNNThreads * 4) = w##q
     RM_W(0); RM_W(1); RM_W(2); RM_W(3); RM_W(4); RM_W(5); RM_W(6); RM_W(7);
 #undef RM_W
-#pragma unroll
-    for (int q = 0; q < AQ; ++q) acur[q] = anext[q];
+    if constexpr (!kFirst) {  // the group is done after this chunk: publish the next one
+      float *adst = As + ((g + 1) & 1) * (kNNRows * ALD);
+      *reinterpret_cast<float4 *>(adst + a_lds0) = an0;
+      *reinterpret_cast<float4 *>(adst + a_lds1) = an1;
+    }
     __syncthreads();
   };
+  static_assert(KC == 16, "two weight chunks per A group");
   int ch = 0;
-  for (; ch + 1 < nfull; ++ch) chunk(ch, std::true_type{});   // next chunk also inside A1
-  for (; ch < a.nch; ++ch) chunk(ch, std::false_type{});      // next chunk is (or is past) the K tail
+  for (; ch + 1 < a.nch; ch += 2) {
+    chunk(ch, std::true_type{});
+    chunk(ch + 1, std::false_type{});
+  }
+  if (ch < a.nch) chunk(ch, std::true_type{});  // odd chunk count: the last group has one chunk
 
   // ---- epilogue: one straight-line pass per column block - all aux loads of a block are
   // issued before the first use and the epilogue kind is switched ONCE per wave.  (The first
@@ -580,7 +598,7 @@ extern "C" int rm_dense_fwd(const float *A1, int64_t lda1, int K1, const float *
   NNArgs a{A1, A2, lda1, lda2, K1, K2, (rm_aligned16(A1) && lda1 % 4 == 0) ? 1 : 0, filter_ws, N, nch, bias, epilogue, act, aux1, aux2,
            ld_aux1, ld_aux2, M, C, C2, ldc, ldc2};
   const dim3 grid((unsigned)((M + kNNRows - 1) / kNNRows), (unsigned)nct);
-  const size_t smem = 2 * WCH * sizeof(float);  // 128 KB: one block per CU
+  const size_t smem = (2 * WCH + 2 * kNNRows * 36) * sizeof(float);  // 100 KB: one block per CU
   const int nb0 = nbt < kMaxNB ? nbt : kMaxNB;  // blocks of the widest (first) column tile
 #define RM_NN(P0, P1)                                                                         \
   {                                                                                         \
