@@ -920,8 +920,8 @@ class XDeepFMEngine(Engine):
         assert len(self.units) > 0  # layers.py:656
         self.cin_act = act_name(hp.get("cin_activation", "leaky_relu"))
         keep = hp.get("cin_dropout")
-        if keep is not None and any(k < 1 for k in keep):
-            raise NotImplementedError("CIN dropout (keep < 1) is not supported by the HIP path yet")
+        if keep is not None:
+            assert len(keep) == len(self.units) + 1  # layers.py:657
         self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
                        hp.get("deep_activation", "leaky_relu"), dev)
         m = self.F
@@ -956,14 +956,30 @@ class XDeepFMEngine(Engine):
         self.cin_fws = torch.empty(fw, dtype=F32, device=dev)
         self.cin_bws = torch.empty(bw, dtype=F32, device=dev)
 
-    def _cin_fwd(self):
+    def _cin_fwd(self, keep=None, masks=None):
+        """CIN.__call__ (layers.py:697-760).  keep / masks: the L+1 keep probabilities and 0/1
+        masks of cin_dropout (input E, then every layer's maps, layers.py:708,740); a dropped
+        layer is scaled in place after its kernel and its pooled columns are re-summed."""
         p = self.params
+        L = len(self.units)
+        on = [bool(keep is not None and masks is not None and keep[i] < 1 and masks[i] is not None)
+              for i in range(L + 1)]
+        self._cin_drop = (keep, masks, on) if any(on) else None
         X0 = self.E
+        if on[0]:
+            self.E_cin = self.E * (masks[0] / keep[0])
+            X0 = self.E_cin
+        self._cin_x0 = X0
         xk = X0
         for i, n in enumerate(self.units):
             ops.cin_layer_fwd(X0, xk, self.Hs[i], p[f"cin_filter_{i}"][0], p[f"cin_bias_{i}"],
-                              self.cin_act, self.maps[i], self.cin_fws, pooled=self.pooled,
+                              self.cin_act, self.maps[i], self.cin_fws,
+                              pooled=None if on[i + 1] else self.pooled,
                               pool_col0=self.pool_col0[i], pool_from=self.pool_from[i])
+            if on[i + 1]:
+                pf, c0 = self.pool_from[i], self.pool_col0[i]
+                self.maps[i].mul_(masks[i + 1] / keep[i + 1])
+                torch.sum(self.maps[i][:, pf:, :], dim=2, out=self.pooled[:, c0: c0 + n - pf])
             xk = self.maps[i]
         ops.rowdot(self.pooled, p["cin_w"].view(-1), p["cin_w0"], self.cin_logit)
 
@@ -971,7 +987,8 @@ class XDeepFMEngine(Engine):
         hp = self.hp
         m = (masks or {}) if training else {}
         self._embed(idx, dense, False, m, lin_w)
-        self._cin_fwd()
+        ck = list(hp.get("cin_dropout") or []) if training else []
+        self._cin_fwd(ck if ck and any(k < 1 for k in ck) else None, m.get("cin"))
         n = len(hp["deep_hidden_units"])
         keep = list(hp.get("deep_dropout", [1] * (n + 1))) if training else [1] * (n + 1)
         self.dnn_logit = self.mlp.forward(self.E.view(-1, self.FD), dense if self.Dn else None, keep,
@@ -986,16 +1003,35 @@ class XDeepFMEngine(Engine):
         ops.linear_dense_bwd(g, self.pooled, gr["cin_w"].view(-1), gr["cin_w0"], self.ws)
         cw = p["cin_w"].view(-1)
         L = len(self.units)
+        drop = getattr(self, "_cin_drop", None)
+        keep, cmasks, on = drop if drop else (None, None, [False] * (L + 1))
+        X0 = self._cin_x0
+        dX0 = self.d_rows
+        if on[0]:  # dropped input: collect dLoss/d(dropped E) apart, then scale and add
+            self._dx0_cin = torch.zeros_like(self.E)
+            dX0 = self._dx0_cin
         for i in range(L - 1, -1, -1):
             n = self.units[i]
             pf, c0 = self.pool_from[i], self.pool_col0[i]
+            d_hidden = self.dxk[i + 1] if i + 1 < L else None
+            cwd, pfa = cw[c0: c0 + n - pf], pf
+            if on[i + 1]:
+                # dropped layer: the whole upstream gradient of its maps, built explicitly
+                # ([next layer's dXk | g x cin_w]) and scaled by mask / keep, goes in as "hidden"
+                up = torch.empty_like(self.maps[i])
+                if pf:
+                    up[:, :pf] = d_hidden
+                up[:, pf:] = g.view(-1, 1, 1) * cw[c0: c0 + n - pf].view(1, -1, 1)  # broadcast over D
+                up.mul_(cmasks[i + 1] / keep[i + 1])
+                d_hidden, cwd, pfa = up, None, n
             ops.cin_layer_bwd(
-                self.E, self.E if i == 0 else self.maps[i - 1], self.Hs[i], p[f"cin_filter_{i}"][0],
-                self.cin_act, self.maps[i], g, self.d_rows, gr[f"cin_filter_{i}"][0],
+                X0, X0 if i == 0 else self.maps[i - 1], self.Hs[i], p[f"cin_filter_{i}"][0],
+                self.cin_act, self.maps[i], g, dX0, gr[f"cin_filter_{i}"][0],
                 gr[f"cin_bias_{i}"], self.cin_bws, xk_is_x0=(i == 0),
-                d_hidden=self.dxk[i + 1] if i + 1 < L else None,
-                cin_w_direct=cw[c0: c0 + n - pf], pool_from=pf, accumulate_dx0=True,
+                d_hidden=d_hidden, cin_w_direct=cwd, pool_from=pfa, accumulate_dx0=True,
                 dXk=self.dxk[i] if i > 0 else None)
+        if on[0]:
+            self.d_rows.addcmul_(self._dx0_cin, cmasks[0] / keep[0])
         reg = self.hp.get("deep_l2_reg", 0.0)
         if reg:
             self.mlp.add_l2_grads(reg)

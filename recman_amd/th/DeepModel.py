@@ -162,6 +162,11 @@ class DeepModel(BaseEstimator, TransformerMixin):
             mb = (torch.rand(B, e.F, device=dev) < fk[0]).float() / fk[0] if fk[0] < 1 else None
             me = (torch.rand(B, e.F, e.D, device=dev) < fk[1]).float() / fk[1] if fk[1] < 1 else None
             masks["fm"] = (mb, me)
+        ck = hp.get("cin_dropout")
+        if ck is not None and any(k < 1 for k in ck) and e.model == "xdeepfm":
+            shapes = [(B, e.F, e.D)] + [(B, n, e.D) for n in e.units]
+            masks["cin"] = [(torch.rand(*sh, device=dev) < k).float() if k < 1 else None
+                            for sh, k in zip(shapes, ck)]
         return masks or None
 
     def fit_on_batch(self, X, y):

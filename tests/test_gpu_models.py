@@ -289,3 +289,18 @@ def test_dcn_matrix_cross_trains_through_model_surface(hip_lib):
     assert after < before
     with pytest.raises(ValueError):
         th.DCN(fd, cross_type="tensor")._build()
+
+
+def test_xdeepfm_trains_with_cin_dropout(hip_lib):
+    import recman_amd.th as th
+
+    df = ml_frame()
+    fd = ml_features(df)
+    hp = {"embedding_size": 8, "cin_cross_layer_units": (8, 8), "cin_dropout": (0.9, 0.8, 0.9),
+          "deep_hidden_units": (16, 16), "deep_dropout": (1, 1, 1), "learning_rate": 0.01}
+    m = th.xDeepFM(fd, hp, metrics=(log_loss,), epoch=3, batch_size=128)
+    before = log_loss(df["label"].values, m.predict(df).astype(np.float64))
+    m.fit(df, df["label"].values)
+    after = log_loss(df["label"].values, m.predict(df).astype(np.float64))
+    assert after < before
+    assert np.array_equal(m.predict(df), m.predict(df))  # inference draws no masks

@@ -420,3 +420,27 @@ def test_sharded_engine_micro_batches_match_single_pass(hip_lib, model, kw, fixe
     with pytest.raises(ValueError):
         rd.make_sharded_engine(model, espec, 16, hp, torch.device("cuda"), 0, 1, micro_batches=5).fwd_bwd(
             idx_d, dense_d, y_d)  # 48 is not divisible by 5
+
+
+@pytest.mark.parametrize("keep", [(0.8, 0.7, 0.9), (1, 0.6, 1), (0.75, 1, 1)])
+def test_cin_dropout_masks_injected(hip_lib, keep):
+    """cin_dropout (layers.py:708,740): keep probabilities on the CIN input and on every layer's
+    maps (both halves, before the split and the pooling); same 0/1 masks into the oracle."""
+    spec, p, idx, dense, y, hp = make_case("xdeepfm", B=37, D=8, cin_units=(8, 6), scale=0.2)
+    hp = dict(hp, cin_dropout=keep)
+    g = torch.Generator().manual_seed(13)
+    shapes = [(37, spec.F, 8), (37, 8, 8), (37, 6, 8)]
+    masks = [(torch.rand(*sh, generator=g) < k).float() if k < 1 else None for sh, k in zip(shapes, keep)]
+    loss_o, logit_o, pred_o, grads_o = T.fwd_bwd("xdeepfm", p, spec, idx, dense, y, hp, masks={"cin": masks})
+    e = _engine("xdeepfm", spec, 8, hp, p)
+    loss = e.fwd_bwd(idx.cuda(), dense.cuda(), y.cuda(),
+                     masks={"cin": [None if m is None else m.cuda() for m in masks]})
+    _close(e.logit, logit_o, rtol=0, atol=1e-5, what="logit")
+    _close(loss, loss_o.reshape(1), what="loss")
+    grads = e.dense_grads(idx.cuda(), reference_names=True)
+    for k in grads_o:
+        _close(grads[k], grads_o[k], what=f"grad {k}")
+    # inference ignores the dropout
+    logit_i, _ = e.forward(idx.cuda(), dense.cuda(), training=False)
+    want = T.xdeepfm_logit(p, spec, idx, dense, hp, training=False).reshape(-1)
+    _close(logit_i, want, rtol=0, atol=1e-5, what="inference logit")
