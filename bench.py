@@ -14,6 +14,7 @@ embedding_l2_reg 0, weights N(0, 0.01), indices uniform over each field's vocabu
   deepfm  (default) configs[1]: 26 sparse x 1,000,001 rows + 13 dense, D=16, MLP (32,32) relu, B=65536
   xdeepfm           configs[2]: same inputs, CIN [128,128] leaky_relu, MLP (32,32) leaky_relu
   dcn               configs[3]: 6 vector cross layers + MLP [400,400] relu, B=131072
+  xdeepfm_100m      configs[4]: xDeepFM on a 100 M-row x 64-dim table (row-sharded with --gpus 8)
   dcn_matrix        (extra)    : the same with matrix cross layers x0 o (W x_l + b) + x_l
 """
 import argparse
@@ -38,6 +39,11 @@ WORKLOADS = {
                             cin_cross_layer_units=(128, 128), cin_activation="leaky_relu")),
     "dcn": dict(model="dcn", B=131072, D=16, F=26, V=1_000_001, Dn=13,
                 hp=dict(deep_hidden_units=(400, 400), deep_activation="relu", cross_layer_num=6)),
+    # BASELINE configs[4]: 100 M rows x 64 floats, meant for --gpus 8 (row-sharded; 3.4 GB per shard);
+    # also runs on one GPU (51 GB of fused rows)
+    "xdeepfm_100m": dict(model="xdeepfm", B=65536, D=64, F=26, V=3_846_154, Dn=13,
+                         hp=dict(deep_hidden_units=(32, 32), deep_activation="leaky_relu",
+                                 cin_cross_layer_units=(128, 128), cin_activation="leaky_relu")),
     # not a BASELINE config: the matrix form of the cross layers (x0 o (W x_l + b) + x_l), same shapes
     "dcn_matrix": dict(model="dcn", B=131072, D=16, F=26, V=1_000_001, Dn=13,
                        hp=dict(deep_hidden_units=(400, 400), deep_activation="relu", cross_layer_num=6,
@@ -284,6 +290,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"{a.workload} (BASELINE configs[{1 + ['deepfm', 'xdeepfm', 'dcn'].index(a.workload)}])"
                                 if a.workload in ("deepfm", "xdeepfm", "dcn") else
+                                "xdeepfm_100m (BASELINE configs[4])" if a.workload == "xdeepfm_100m" else
                                 f"{a.workload} (extra workload, not a BASELINE config)"),
                    "batch_per_gpu": B, "batch_all_gpus": B * world, "sparse_fields": w["F"],
                    "rows_per_field": V,
