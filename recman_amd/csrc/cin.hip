@@ -27,6 +27,46 @@ constexpr int kRows = 256;  // (b,d) rows per forward block
 __host__ __device__ inline int cin_He(int H) { return H + (H & 1); }
 __host__ __device__ inline int cin_Kp(int m, int H) { return ((m * cin_He(H) + 31) / 32) * 32; }
 
+// First layer (Xk IS X0, H = m): Z[i][j] = X0[i]*X0[j] is symmetric, so only the pairs j >= i are
+// enumerated, against the folded filter W'[i][j] = W[i][j] + W[j][i] (j > i), W[i][i] (j = i):
+// K' drops from m*He to about half (m = 26: 704 -> 384 padded) in the forward and the dW pass.
+// Row i runs j from (i & ~1) to He-1 so that the two k' of an MFMA step still share i; the one
+// extra element (j = i-1 for odd i) carries a zero filter row.
+__host__ __device__ inline int cin_sym_len(int He, int i) { return He - (i & ~1); }
+__host__ __device__ inline int cin_sym_start(int He, int i) {
+  const int r = i >> 1;
+  const int s = 2 * (r * He - r * (r - 1));
+  return (i & 1) ? s + (He - 2 * r) : s;
+}
+__host__ __device__ inline int cin_Kp_sym(int m, int H) {
+  const int He = cin_He(H);
+  return ((cin_sym_start(He, m - 1) + cin_sym_len(He, m - 1) + 31) / 32) * 32;
+}
+// k' -> (i, j); i = m when k' lies past the last pair
+__host__ __device__ inline void cin_sym_ij(int kp, int m, int He, int &i, int &j) {
+  for (i = 0; i < m; ++i) {
+    const int s0 = cin_sym_start(He, i);
+    if (kp < s0 + cin_sym_len(He, i)) {
+      j = (i & ~1) + (kp - s0);
+      return;
+    }
+  }
+  i = m;
+  j = 0;
+}
+// the generic k' map of both orderings; ok = a real (i, j) pair of this ordering
+__host__ __device__ inline void cin_kp_ij(int kp, int m, int H, int sym, int &i, int &j, bool &ok) {
+  const int He = cin_He(H);
+  if (sym) {
+    cin_sym_ij(kp, m, He, i, j);
+    ok = i < m && j >= i && j < H;
+  } else {
+    i = kp / He;
+    j = kp - i * He;
+    ok = i < m && j < H;
+  }
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == RM_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == RM_ACT_LEAKY_RELU) return v > 0.f ? v : 0.2f * v;
@@ -41,16 +81,23 @@ __device__ __forceinline__ float act_grad_from_out(float o, int act) {
 
 // Wp[k'][c*NT + nt] = W[(i*H+j)*N + nt*32 + c]  (zero where padded): the B-operand
 // layout - a lane reads its NT filter columns with one ds_read_b(32*NT).
-__global__ void cin_prep_fwd_kernel(const float *__restrict__ W, int m, int H, int N, int NT,
+__global__ void cin_prep_fwd_kernel(const float *__restrict__ W, int m, int H, int N, int NT, int sym,
                                     float *__restrict__ Wp) {
-  const int He = cin_He(H), Kp = cin_Kp(m, H), Np = 32 * NT;
+  const int Kp = sym ? cin_Kp_sym(m, H) : cin_Kp(m, H), Np = 32 * NT;
   const int total = Kp * Np;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
     const int kp = t / Np, r = t - kp * Np;
     const int c = r / NT, nt = r - c * NT;
     const int n = nt * 32 + c;
-    const int i = kp / He, j = kp - i * He;
-    Wp[t] = (i < m && j < H && n < N) ? W[(int64_t)(i * H + j) * N + n] : 0.f;
+    int i, j;
+    bool ok;
+    cin_kp_ij(kp, m, H, sym, i, j, ok);
+    float v = 0.f;
+    if (ok && n < N) {
+      v = W[(int64_t)(i * H + j) * N + n];
+      if (sym && j > i) v += W[(int64_t)(j * H + i) * N + n];  // folded filter of the symmetric layer
+    }
+    Wp[t] = v;
   }
 }
 
@@ -62,12 +109,12 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
     const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride,
     const float *__restrict__ Wp, const float *__restrict__ bias, int act, int64_t B, int m, int H,
     int N, int D, float *__restrict__ out, float *__restrict__ pooled, int pool_stride,
-    int pool_col0, int pool_from) {
+    int pool_col0, int pool_from, int sym) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int Np = 32 * NT;
   constexpr int WCH = 32 * Np;  // floats per filter chunk
   const int He = cin_He(H);
-  const int Kp = cin_Kp(m, H);
+  const int Kp = sym ? cin_Kp_sym(m, H) : cin_Kp(m, H);
   float *X0s = smem;                      // [(m+1)][256], row m is zero
   float *Xks = X0s + (m + 1) * kRows;     // [He][256], row H (if padded) is zero
   float *Ws = Xks + He * kRows;           // [2][32][Np]
@@ -151,7 +198,7 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
         for (int mt = 0; mt < MT; ++mt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
       j_cur += 2;
-      if (j_cur >= He) { j_cur = 0; ++i_cur; }
+      if (j_cur >= He) { ++i_cur; j_cur = sym ? (i_cur & ~1) : 0; }
     }
     {
       // stores are unconditional wherever the chunk divides evenly over the threads: a store
@@ -256,13 +303,22 @@ __global__ __launch_bounds__(256) void cin_dm_kernel(
   if (tid < Np) dbias_part[(int64_t)blockIdx.x * Np + tid] = colsum[tid];
 }
 
-__global__ void cin_dbias_reduce_kernel(const float *__restrict__ part, int nblk, int N, int Np,
-                                        float *__restrict__ dbias) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// one block per column n: 256 threads take every 256th partial, then a fixed-order tree in LDS
+// (a single thread walking all 2048 partials took 596 us)
+__global__ __launch_bounds__(256) void cin_dbias_reduce_kernel(const float *__restrict__ part, int nblk,
+                                                               int N, int Np, float *__restrict__ dbias) {
+  __shared__ float sm[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
   float s = 0.f;
-  for (int i = 0; i < nblk; ++i) s += part[(int64_t)i * Np + n];
-  dbias[n] = s;
+  for (int i = tid; i < nblk; i += 256) s += part[(int64_t)i * Np + n];
+  sm[tid] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) sm[tid] += sm[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) dbias[n] = sm[0];
 }
 
 // dX-kernel k' ordering: k' = i*Hp + j with Hp = H rounded up to 32, so that every
@@ -506,12 +562,12 @@ template <int NT>
 __global__ __launch_bounds__(512) void cin_dw_kernel(
     const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride,
     const float *__restrict__ dM, int64_t B, int m, int H, int D, DwPlan plan,
-    float *__restrict__ part) {
+    float *__restrict__ part, int sym) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int Np = 32 * NT;
   constexpr int NTHR = 64 * kDWW;
   const int He = cin_He(H);
-  const int Kp = cin_Kp(m, H);
+  const int Kp = sym ? cin_Kp_sym(m, H) : cin_Kp(m, H);
   const int ld0 = (m + 1) | 1, ldk = He | 1;
   float *X0T = smem;                 // [64][ld0]  (column m is zero)
   float *XkT = X0T + kRC * ld0;      // [64][ldk]
@@ -549,8 +605,10 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(
     const int tile = group * kDWW * kKT + q * kDWW + wave;
     tile_ok[q] = tile * 32 < Kp;
     const int kp = tile * 32 + c;
-    const int i = kp / He, j = kp - i * He;
-    const bool ok = kp < Kp && i < m && j < H;
+    int i, j;
+    bool ok;
+    cin_kp_ij(kp, m, H, sym, i, j, ok);
+    ok = ok && kp < Kp;
     iq[q] = ok ? i : m;
     jq[q] = ok ? j : 0;
   }
@@ -684,15 +742,22 @@ size_t cin_dw_smem(int m, int H, int NT) {
   return (size_t)(kRC * (((m + 1) | 1) + (cin_He(H) | 1) + 32 * NT)) * sizeof(float);
 }
 
-// dW[(i*H+j)][n] = sum_s part[s][i*He+j][n]
+// dW[(i*H+j)][n] = sum_s part[s][k'(i,j)][n]; in the symmetric ordering (i,j) and (j,i) read the
+// same k' (dLoss/dW[i][j] = dLoss/dW[j][i] = dLoss/dW'[min][max])
 __global__ void cin_dw_reduce_kernel(const float *__restrict__ part, DwPlan plan, int m, int H, int N,
-                                     int Np, float *__restrict__ dW) {
-  const int He = cin_He(H), Kp = cin_Kp(m, H);
+                                     int Np, int sym, float *__restrict__ dW) {
+  const int He = cin_He(H), Kp = sym ? cin_Kp_sym(m, H) : cin_Kp(m, H);
   const int total = m * H * N;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
     const int k = t / N, n = t - k * N;
     const int i = k / H, j = k - i * H;
-    const int kp = i * He + j;
+    int kp;
+    if (sym) {
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      kp = cin_sym_start(He, lo) + (hi - (lo & ~1));
+    } else {
+      kp = i * He + j;
+    }
     const int S = plan.S[(kp / 32) / (kDWW * kKT)];
     float acc = 0.f;
     for (int s = 0; s < S; ++s) acc += part[((int64_t)s * Kp + kp) * Np + n];
@@ -738,7 +803,9 @@ extern "C" int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bst
   const size_t smem = cin_fwd_smem(m, H, NT);
   RM_REQUIRE(smem <= 160 * 1024, "rm_cin_layer_fwd: m=%d H=%d needs %zu B of LDS (> 160 KiB)", m, H, smem);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(cin_prep_fwd_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, NT, filter_ws);
+  // first layer (Xk is X0 itself): symmetric k' ordering with a folded filter, about half the K'
+  const int sym = (Xk == X0 && H == m && xk_bstride == (int64_t)m * D) ? 1 : 0;
+  hipLaunchKernelGGL(cin_prep_fwd_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, NT, sym, filter_ws);
   const int epb = kRows / D;
   dim3 grid((unsigned)((B + epb - 1) / epb));
 #define RM_CIN_FWD(NT_)                                                                          \
@@ -747,7 +814,7 @@ extern "C" int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bst
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
     hipLaunchKernelGGL((cin_fwd_kernel<NT_, 1>), grid, dim3(512), smem, st, X0, Xk, xk_bstride,  \
                        filter_ws, bias, act, B, m, H, N, D, out, pooled, pool_stride, pool_col0, \
-                       pool_from);                                                               \
+                       pool_from, sym);                                                          \
   }
   if (NT == 1) RM_CIN_FWD(1) else if (NT == 2) RM_CIN_FWD(2) else RM_CIN_FWD(4)
 #undef RM_CIN_FWD
@@ -755,14 +822,26 @@ extern "C" int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bst
   return RM_OK;
 }
 
-extern "C" int64_t rm_cin_bwd_workspace(int64_t B, int m, int H, int N, int D) {
-  const int NT = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
-  const int Np = 32 * NT, Kp = cin_Kp(m, H);
+// floats of the dW partial slabs: the larger of the two k' orderings (the symmetric one has fewer
+// tiles but may be split into more slabs)
+static int64_t cin_part_floats(int64_t B, int m, int H, int Np, int D) {
   const int64_t chunks_total = (B * D + kRC - 1) / kRC;
-  const DwPlan plan = cin_dw_plan(Kp, chunks_total > 0 ? chunks_total : 1, 256);
-  return (int64_t)m * cin_Hp(H) * Np + B * D * Np + (int64_t)plan.Smax * Kp * Np + (int64_t)kDmBlocks * Np;
+  const int64_t ct = chunks_total > 0 ? chunks_total : 1;
+  const int Kp = cin_Kp(m, H);
+  int64_t need = (int64_t)cin_dw_plan(Kp, ct, 256).Smax * Kp * Np;
+  if (H == m) {
+    const int Ks = cin_Kp_sym(m, H);
+    const int64_t ns = (int64_t)cin_dw_plan(Ks, ct, 256).Smax * Ks * Np;
+    need = ns > need ? ns : need;
+  }
+  return need;
 }
 
+extern "C" int64_t rm_cin_bwd_workspace(int64_t B, int m, int H, int N, int D) {
+  const int NT = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
+  const int Np = 32 * NT;
+  return (int64_t)m * cin_Hp(H) * Np + B * D * Np + cin_part_floats(B, m, H, Np, D) + (int64_t)kDmBlocks * Np;
+}
 extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int xk_is_x0,
                                 const float *W, int act, const float *out, const float *d_hidden,
                                 int64_t dh_bstride, const float *g, const float *cin_w_direct,
@@ -792,12 +871,7 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
   float *dM = Wq + (int64_t)m * cin_Hp(H) * Np;
   float *part = dM + B * D * Np;
   hipStream_t st = (hipStream_t)stream;
-  float *dbias_part;
-  {
-    const int64_t chunks_total = (B * D + kRC - 1) / kRC;
-    const DwPlan plan0 = cin_dw_plan(Kp, chunks_total > 0 ? chunks_total : 1, 256);
-    dbias_part = part + (int64_t)plan0.Smax * Kp * Np;  // [kDmBlocks][Np]
-  }
+  float *dbias_part = part + cin_part_floats(B, m, H, Np, D);  // [kDmBlocks][Np]
 
   hipLaunchKernelGGL(cin_prep_bwd_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, Np, Wq);
   {
@@ -805,8 +879,7 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
     const int nblk = rm_grid_cap(B, kDmBlocks);
     hipLaunchKernelGGL(cin_dm_kernel, dim3(nblk), dim3(256), smem, st, out, d_hidden, dh_bstride, g,
                        cin_w_direct, pool_from, act, B, N, Np, D, dM, dbias_part);
-    hipLaunchKernelGGL(cin_dbias_reduce_kernel, dim3((N + 63) / 64), dim3(64), 0, st, dbias_part, nblk, N,
-                       Np, dbias);
+    hipLaunchKernelGGL(cin_dbias_reduce_kernel, dim3(N), dim3(256), 0, st, dbias_part, nblk, N, Np, dbias);
   }
   {
     const int rows = (kRC * 2 % D == 0 && 256 % D == 0 && cin_dx_smem(m, H, NT, 256) <= 160 * 1024) ? 256 : 128;
@@ -836,18 +909,19 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
   {
     const size_t smem = cin_dw_smem(m, H, NT);
     const int64_t chunks_total = (B * D + kRC - 1) / kRC;
-    const DwPlan plan = cin_dw_plan(Kp, chunks_total, 256);
+    const int sym = xk_is_x0 ? 1 : 0;  // first layer: symmetric k' ordering (half the tiles)
+    const DwPlan plan = cin_dw_plan(sym ? cin_Kp_sym(m, H) : Kp, chunks_total, 256);
     dim3 grid(plan.blk0[plan.ngroups]);
 #define RM_CIN_DW(NT_)                                                                        \
   {                                                                                           \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dw_kernel<NT_>),             \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);         \
     hipLaunchKernelGGL((cin_dw_kernel<NT_>), grid, dim3(512), smem, st, X0, Xk, xk_bstride,   \
-                       dM, B, m, H, D, plan, part);                                           \
+                       dM, B, m, H, D, plan, part, sym);                                      \
   }
     if (NT == 1) RM_CIN_DW(1) else if (NT == 2) RM_CIN_DW(2) else RM_CIN_DW(4)
 #undef RM_CIN_DW
-    hipLaunchKernelGGL(cin_dw_reduce_kernel, dim3(256), dim3(256), 0, st, part, plan, m, H, N, Np, dW);
+    hipLaunchKernelGGL(cin_dw_reduce_kernel, dim3(256), dim3(256), 0, st, part, plan, m, H, N, Np, sym, dW);
   }
   RM_CHECK_LAUNCH("rm_cin_layer_bwd");
   return RM_OK;
