@@ -282,6 +282,10 @@ def main():
         # profiles/r01_p5_deepfm_fused.md
         roof["traffic"] = 375.0e6
         roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, profiles/r01_p5_deepfm_fused.md"
+    if roof is not None and B == w["B"] and V == 1_000_001 and a.zipf == 0 and a.workload in ("xdeepfm", "dcn"):
+        # HBM bytes per launch of the dominant MFMA kernel (same PMC recipe): profiles/r01_p10_traffic.md
+        roof["traffic"] = {"xdeepfm": 475.0e6 + 591.0e6, "dcn": 249.0e6 + 217.0e6}[a.workload]
+        roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2) / --pmc WRITE_SIZE, profiles/r01_p10_traffic.md"
 
     out = {
         "metric": "examples/sec fwd+bwd, Criteo-shape batch 65536; % HBM and MFMA roofline",
