@@ -310,7 +310,7 @@ int rm_pool_rows_bwd(const float *d_rows, int64_t dr_stride, const float *g_bias
  *   stamp [R] int32 (any values != step), step >= 1 and different from the previous call,
  *   g_bias / g_lin [B]: per-example gradient of the bias (column D) / linear (column D+1)
  *   entries or NULL; reset != 0 ignores the stored moments (the reference builds a new
- *   optimizer for every batch). */
+ *   optimizer for every batch).  * Occurrences with idx < 0 are skipped. */
 int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field_off, const float *d_rows,
                              const float *g_bias, const float *g_lin, int64_t B, int F, int D,
                              int LD, float *rows, float *m_state, float *v_state, float *gbuf,

@@ -10,6 +10,8 @@
 //   apply:      one occurrence per distinct row wins an atomicCAS on stamp[row] (== step),
 //               reads the row's summed gradient, updates param / moments, and zeroes the
 //               gbuf row again - gbuf is all-zero between steps by construction.
+// Occurrences with idx < 0 are skipped (the caller hands them in by another call: the tag rows of
+// a multi-valued feature arrive as an expanded one-field occurrence list, recman_amd/optim.py).
 #include "rm_common.h"
 
 namespace {
@@ -26,7 +28,9 @@ __global__ __launch_bounds__(kBlock) void sparse_accumulate_kernel(
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const int64_t o = t / W;
     const int k = (int)(t - o * W);
-    const int64_t row = field_off[o % F] + idx[o];
+    const int64_t id = idx[o];
+    if (id < 0) continue;  // occurrence handled elsewhere (multi-valued / value features)
+    const int64_t row = field_off[o % F] + id;
     float v;
     if (k < D) v = d_rows[o * D + k];
     else if (k == D) v = g_bias ? g_bias[o / F] : 0.f;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_kernel(
     const int64_t o = o0 + lane;
     int64_t row = -1;
     bool win = false;
-    if (o < n) {
+    if (o < n && idx[o] >= 0) {
       row = field_off[o % F] + idx[o];
       win = atomicExch(stamp + row, step) != step;  // first occurrence of this row in this step
     }

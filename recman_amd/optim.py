@@ -58,15 +58,16 @@ class SparseTableOptimizer:
     backward produces (rm_sparse_optimizer_step): only rows occurring in the batch are
     touched, no dense gradient is ever formed.  Needs embedding_l2_reg == linear_l2_reg == 0
     (a dense l2 term touches every row, layers.py:188-193) - DeepModel falls back to the
-    dense path otherwise."""
+    dense path otherwise.  Multi-valued (MultiValCsvFeat) and value (SparseValueFeat) features:
+    their column of idx is masked out (-1) in the main call and every such feature is handed to
+    the same kernel as an expanded one-field occurrence list - one occurrence per tag, its row
+    gradient scaled by the pooling / value factor (rm_pool_rows_bwd's factors)."""
 
     def __init__(self, engine, name="adam", lr=1e-3):
         import torch as _t
 
         from . import ops
 
-        if engine.spec.scratch_names:
-            raise NotImplementedError("the row-wise sparse step does not cover multi-valued / value features yet")
         self.ops, self.e, self.name, self.lr = ops, engine, name, float(lr)
         R, LD = engine.rows.shape
         dev = engine.device
@@ -78,9 +79,32 @@ class SparseTableOptimizer:
         self.t = 0
 
     def step(self, idx, reset=False):
+        import torch as _t
+
         e = self.e
         self.t += 1
+        g_bias = e.dlogit if (e.use_bias_tables and e._has_fm()) else None
+        g_lin = e.dlogit if e.use_linear else None
+        if e.mv_fields:
+            idx = idx.clone()
+            idx[:, e.mv_fields] = -1  # handled below
         self.ops.sparse_optimizer_step(
             idx, e.field_off, e.d_rows, e.rows, self.m, self.v, self.gbuf, self.stamp, self.t,
-            self.name, self.lr, g_bias=e.dlogit if (e.use_bias_tables and e._has_fm()) else None,
-            g_lin=e.dlogit if e.use_linear else None, reset=reset)
+            self.name, self.lr, g_bias=g_bias, g_lin=g_lin, reset=reset)
+        B = idx.shape[0]
+        for f in e.mv_fields:
+            offsets, ids, vals = e._mv_entry(f)
+            n = offsets[1:] - offsets[:-1]
+            seg = _t.repeat_interleave(_t.arange(B, device=ids.device), n)
+            if vals is not None:  # value feature: emb and linear scaled by the value, bias not
+                we, wb, wl = vals, _t.ones_like(vals), vals
+            else:                 # sqrtn combiner; the linear term is a multi-hot count without slot 0
+                inv = n.clamp(min=1).to(_t.float32).rsqrt()[seg]
+                we, wb, wl = inv, inv, (ids >= 1).to(_t.float32)
+            rows_g = (e.d_rows[seg, f, :] * we.unsqueeze(1)).contiguous().view(-1, 1, e.D)
+            zoff = e.field_off[f: f + 1]
+            self.ops.sparse_optimizer_step(
+                ids.view(-1, 1).contiguous(), zoff, rows_g, e.rows, self.m, self.v, self.gbuf, self.stamp,
+                self.t, self.name, self.lr,
+                g_bias=(g_bias[seg] * wb).contiguous() if g_bias is not None else None,
+                g_lin=(g_lin[seg] * wl).contiguous() if g_lin is not None else None, reset=reset)

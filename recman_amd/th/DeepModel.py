@@ -66,7 +66,7 @@ class DeepModel(BaseEstimator, TransformerMixin):
         self._opt = Optimizer(hp.get("optimizer", "adam"), hp.get("learning_rate", 1e-3))
         # row-wise sparse step for the table when nothing forces a dense gradient
         no_l2 = not hp.get("embedding_l2_reg", 0.0) and not hp.get("linear_l2_reg", 0.0)
-        want = hp.get("sparse_optimizer", e.rows.numel() > (1 << 24)) and not spec.scratch_names
+        want = hp.get("sparse_optimizer", e.rows.numel() > (1 << 24))
         self._sparse_opt = None
         if want and no_l2 and hp.get("optimizer", "adam") in ("adam", "adagrad", "gd", "sgd"):
             self._sparse_opt = SparseTableOptimizer(e, hp.get("optimizer", "adam"),

@@ -95,3 +95,50 @@ def test_model_fit_with_sparse_optimizer_learns(hip_lib):
     assert m._sparse_opt is not None and m._sparse_opt.t > 0
     after = log_loss(df["label"].values, m.predict(df).astype(np.float64))
     assert after < before - 0.01
+
+
+def test_sparse_step_with_multi_valued_and_value_features(hip_lib):
+    """Scratch-row features in the row-wise step: a MultiValCsvFeat and a SparseValueFeat field are
+    masked out of the main call and arrive as expanded one-field occurrence lists.  With the
+    optimizer rebuilt per batch (reset) the result equals the dense Adam step on dense_grads()."""
+    from oracle import th_layers as T
+    from recman_amd import engine as eng
+    from recman_amd.optim import Optimizer, SparseTableOptimizer
+
+    spec, p, idx, dense, y, hp = make_case("deepfm", B=90, D=8, sizes=[7, 11, 5, 13, 3])
+    hp = dict(hp, embedding_l2_reg=0.0, linear_l2_reg=0.0)
+    mname, vname = spec.sparse_names[1], spec.sparse_names[3]
+    tspec = T.Spec(spec.sparse_names, spec.feat_sizes, spec.dense_names, multi_names=[mname],
+                   value_names=[vname])
+    espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names, [mname], [vname])
+    g = torch.Generator().manual_seed(17)
+    B = 90
+    n = torch.randint(0, 4, (B,), generator=g)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), n.cumsum(0)])
+    ids = torch.randint(0, spec.feat_sizes[1], (int(n.sum()),), generator=g)
+    vids = torch.randint(0, spec.feat_sizes[3], (B,), generator=g)
+    vals = torch.randn(B, generator=g)
+    mv = {mname: (offsets.cuda(), ids.cuda()), vname: (torch.arange(B + 1).cuda(), vids.cuda(), vals.cuda())}
+
+    def mk():
+        e = eng.ENGINES["deepfm"](espec, 8, hp)
+        e.load_params({k: v for k, v in p.items() if k in e.params or k == "linear_w"})
+        return e
+
+    e1, e2 = mk(), mk()
+    dopt, sdense = Optimizer("adam", 0.01), Optimizer("adam", 0.01)
+    sopt = SparseTableOptimizer(e2, "adam", 0.01)
+    idx_d, dense_d, y_d = idx.cuda(), dense.cuda(), y.cuda()
+    for step in range(2):
+        e1.fwd_bwd(idx_d, dense_d, y_d, mv=mv)
+        dopt.reset()
+        dopt.step(e1.params, e1.dense_grads(idx_d))
+        e2.fwd_bwd(idx_d, dense_d, y_d, mv=mv)
+        sdense.reset()
+        sopt.step(idx_d, reset=True)
+        sdense.step(e2.params, e2.grads)
+        for k in e1.params:
+            a, b = e1.params[k], e2.params[k]
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), (step, k)
+    assert float(sopt.gbuf.abs().max()) == 0.0
+    assert tspec.multi_names == [mname]  # (the oracle spec of the same case, for readers)
