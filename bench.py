@@ -275,14 +275,20 @@ def main():
     value = world * B * a.steps / elapsed
 
     # ---- roofline of the dominant hand-written kernel, HIP events on its stream ----
-    roof = None if sharded else engine.roofline_probe(idx, dense, y, iters=max(10, min(a.steps, 50)))
-    if roof is not None and a.workload == "deepfm" and B == 65536 and V == 1_000_001 and a.zipf == 0:
+    # (sharded: only for the models whose dominant kernel is the gather; rank 0, local kernel only)
+    roof = None
+    if not sharded:
+        roof = engine.roofline_probe(idx, dense, y, iters=max(10, min(a.steps, 50)))
+    elif rank == 0 and w["model"] == "deepfm":
+        roof = engine.roofline_probe(idx, dense, y, iters=max(10, min(a.steps, 50)))
+    if roof is not None and not sharded and a.workload == "deepfm" and B == 65536 and V == 1_000_001 and a.zipf == 0:
         # HBM bytes per launch of the gather kernel from rocprofv3 PMC passes of this same command
         # (FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes on gfx950, + WRITE_SIZE):
         # profiles/r01_p5_deepfm_fused.md
         roof["traffic"] = 375.0e6
         roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, profiles/r01_p5_deepfm_fused.md"
-    if roof is not None and B == w["B"] and V == 1_000_001 and a.zipf == 0 and a.workload in ("xdeepfm", "dcn"):
+    if (roof is not None and not sharded and B == w["B"] and V == 1_000_001 and a.zipf == 0
+            and a.workload in ("xdeepfm", "dcn")):
         # HBM bytes per launch of the dominant MFMA kernel (same PMC recipe): profiles/r01_p10_traffic.md
         roof["traffic"] = {"xdeepfm": 475.0e6 + 591.0e6, "dcn": 249.0e6 + 217.0e6}[a.workload]
         roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2) / --pmc WRITE_SIZE, profiles/r01_p10_traffic.md"

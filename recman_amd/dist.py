@@ -466,6 +466,34 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             allreduce_dense(self.grads, world, group, self._flat_grads, average=False)
             return total.div_(M)
 
+        def _dominant_kernel(self, idx, dense):
+            """roofline_probe on the sharded engine: the LOCAL gather + FM + linear kernel over the
+            rows received in the last exchange (no collective inside, any rank may call it)."""
+            from . import ops
+
+            if getattr(self, "ex", None) is None or getattr(self, "rows", None) is None:
+                raise RuntimeError("run fwd_bwd once before roofline_probe")
+            fm = self._has_fm()
+            b = self.ex.pos.numel() // self.F  # the (micro-)batch of the last exchange
+            W = self.D + PAD
+            flat = self.rows.view(-1)
+            pos = self.ex.pos.view(b, self.F)
+            d = dense[:b].contiguous() if (self.use_linear and self.Dn) else None
+
+            def fn():
+                ops.embed_fwd(
+                    pos, self.rows, self._zoff, table_ld=W, D=self.D,
+                    bias_table=flat[self.D:] if fm else None, bias_ld=W,
+                    lin_w=flat[self.D + 1:] if self.use_linear else None, lin_ld=W, lin_off=self._zoff,
+                    lin_w_dense=self.linear_w_dense if (self.use_linear and self.Dn) else None,
+                    lin_w0=self.params["linear_w0"] if self.use_linear else None, dense=d,
+                    E=self.E[:b], fm_sum=self.fm_sum[:b] if fm else None,
+                    fm_logit=self.fm_logit[:b] if fm else None,
+                    lin_logit=self.lin_logit[:b] if self.use_linear else None)
+
+            return ("embed_fwd_kernel on the exchanged rows (rm_embed_fwd: gather + FM + linear, "
+                    f"{b} examples per launch)", fn, self._embed_fwd_bytes(b, fm), "hbm")
+
         def overflowed(self):
             """True when a fixed-capacity batch did not fit (host sync; clears the flag): every
             result since the last call must be discarded and redone with the dynamic layout."""
