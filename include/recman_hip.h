@@ -167,6 +167,11 @@ int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const i
  * rm_act_bwd:  da[b,j] *= act'(a[b,j]) in place, act' read off the post-activation a. */
 int rm_bias_act(float *x, const float *bias, int64_t B, int N, int act, rm_stream_t stream);
 int rm_act_bwd(float *da, const float *a, int64_t B, int N, int act, rm_stream_t stream);
+/* da[b,j] = g[b] * w[j] * act'(a[b,j]) (a = post-activation of the last hidden layer, or NULL for no
+ * activation factor): the backward of the [H,1] output projection (layers.py:606-609) and of the last
+ * activation in one pass.  N % 4 == 0. */
+int rm_outer_actgrad(const float *g, const float *w, const float *a, int64_t B, int N, int act,
+                     float *da, rm_stream_t stream);
 
 /* out[b] = sum_j X[b,j]*w[j] + w0[0]: the [*,1] output projections (dnn_w/dnn_w0,
  * layers.py:606-609; cin_w/cin_w0, layers.py:757-760).  w0 may be NULL. */

@@ -37,6 +37,7 @@ SIGNATURES = {
                    P, P, P, P],
     "rm_bias_act": [P, P, I64, c_int, c_int, P],
     "rm_act_bwd": [P, P, I64, c_int, c_int, P],
+    "rm_outer_actgrad": [P, P, P, I64, c_int, c_int, P, P],
     "rm_rowdot": [P, P, P, I64, c_int, P, P],
     "rm_cross_fwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P],
     "rm_cross_bwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P, P, P, P, P, P],

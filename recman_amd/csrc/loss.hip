@@ -143,6 +143,41 @@ extern "C" int rm_bias_act(float *x, const float *bias, int64_t B, int N, int ac
   return RM_OK;
 }
 
+// da[b,j] = g[b] * w[j] * act'(a[b,j]): dLoss/d(pre-activation) of the LAST hidden layer of a wide
+// DNN from the logit gradient (the backward of the [H,1] output projection, layers.py:606-609, and of
+// the last activation) - one pass over a instead of a K = 1 GEMM launch
+__global__ __launch_bounds__(kBlock) void outer_actgrad_kernel(const float *__restrict__ g,
+                                                               const float *__restrict__ w,
+                                                               const float4 *__restrict__ a, int64_t B,
+                                                               int N4, int act, float4 *__restrict__ da) {
+  const int64_t n4 = B * N4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += stride) {
+    const int64_t b = t / N4;
+    const int j = (int)(t - b * N4) * 4;
+    const float gb = g[b];
+    float4 d = make_float4(gb * w[j], gb * w[j + 1], gb * w[j + 2], gb * w[j + 3]);
+    if (a != nullptr) {
+      const float4 o = a[t];
+      d.x *= act_g(o.x, act); d.y *= act_g(o.y, act); d.z *= act_g(o.z, act); d.w *= act_g(o.w, act);
+    }
+    da[t] = d;
+  }
+}
+
+extern "C" int rm_outer_actgrad(const float *g, const float *w, const float *a, int64_t B, int N, int act,
+                                float *da, rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && N > 0 && N % 4 == 0, "rm_outer_actgrad: N must be a multiple of 4");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(g && w && da && rm_aligned16(da) && (!a || rm_aligned16(a)), "rm_outer_actgrad: NULL or unaligned");
+  const int64_t n4 = B * (N / 4);
+  hipLaunchKernelGGL(outer_actgrad_kernel, dim3(rm_grid_cap((n4 + kBlock - 1) / kBlock, 256 * 16)),
+                     dim3(kBlock), 0, (hipStream_t)stream, g, w, (const float4 *)a, B, N / 4, act,
+                     (float4 *)da);
+  RM_CHECK_LAUNCH("rm_outer_actgrad");
+  return RM_OK;
+}
+
 extern "C" int rm_act_bwd(float *da, const float *a, int64_t B, int N, int act, rm_stream_t stream) {
   RM_REQUIRE(B >= 0 && N > 0 && (B * N) % 4 == 0, "rm_act_bwd: B*N must be a multiple of 4");
   if (B == 0) return RM_OK;

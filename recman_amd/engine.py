@@ -211,13 +211,17 @@ class MLP:
             self.lin_done = bool(lin_grads and 1 <= self.Dn <= 32)
             return fm_sum is not None
         ops.linear_dense_bwd(g, self.a[-1], gr[f"{pre}dnn_w"].view(-1), gr[f"{pre}dnn_w0"], self._ws)
-        # d(pre-activation of the last layer) = (g w_out^T) o mask o act'(a): a K = 1 GEMM whose
-        # epilogue applies the activation gradient (the mask multiplies in between)
+        # d(pre-activation of the last layer) = (g w_out^T) o mask o act'(a): one elementwise pass
+        # (rm_outer_actgrad; widths that are not a multiple of 4 take the K = 1 GEMM instead)
         da = self.da[-1]
         last_drop = self.keep[n] < 1 and self.masks[n] is not None
-        ops.dense_fwd(g.view(-1, 1), None, p[f"{pre}dnn_w"], da, self._fws, transposed=True,
-                      epilogue=ops.DENSE_ADD if (last_drop or self.act == "identity") else ops.DENSE_MUL_ACTGRAD,
-                      act=self.act, aux1=None if (last_drop or self.act == "identity") else self.a[-1])
+        plain = last_drop or self.act == "identity"
+        if da.shape[1] % 4 == 0:
+            ops.outer_actgrad(g, p[f"{pre}dnn_w"].view(-1), None if plain else self.a[-1], self.act, da)
+        else:
+            ops.dense_fwd(g.view(-1, 1), None, p[f"{pre}dnn_w"], da, self._fws, transposed=True,
+                          epilogue=ops.DENSE_ADD if plain else ops.DENSE_MUL_ACTGRAD,
+                          act=self.act, aux1=None if plain else self.a[-1])
         if last_drop:
             da.mul_(self.masks[n] / self.keep[n])
             if self.act != "identity":

@@ -391,6 +391,13 @@ def bias_act_(x, bias, act):
               ACT_IDS[act], _stream())
 
 
+def outer_actgrad(g, w, a, act, da):
+    """da[b,j] = g[b] * w[j] * act'(a[b,j]) (a may be None: no activation factor)."""
+    B, N = da.shape
+    _lib.call("rm_outer_actgrad", _chk(g, "g", F32, (B,)), _chk(w, "w", F32, (N,)),
+              _chk(a, "a", F32, (B, N), allow_none=True), B, N, ACT_IDS[act], _chk(da, "da", F32), _stream())
+
+
 def act_bwd_(da, a, act):
     B, N = da.shape
     _lib.call("rm_act_bwd", _chk(da, "da", F32), _chk(a, "a", F32, (B, N)), B, N, ACT_IDS[act], _stream())
