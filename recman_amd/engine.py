@@ -924,8 +924,8 @@ class XDeepFMEngine(Engine):
         assert len(self.units) > 0  # layers.py:656
         self.cin_act = act_name(hp.get("cin_activation", "leaky_relu"))
         keep = hp.get("cin_dropout")
-        if keep is not None:
-            assert len(keep) == len(self.units) + 1  # layers.py:657
+        if keep is not None and any(k < 1 for k in keep):
+            assert len(keep) == len(self.units) + 1  # layers.py:657 (checked only when it matters)
         self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
                        hp.get("deep_activation", "leaky_relu"), dev)
         m = self.F

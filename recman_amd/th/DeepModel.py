@@ -78,9 +78,9 @@ class DeepModel(BaseEstimator, TransformerMixin):
         """name -> tensor with the reference's variable names (DeepModel.py:43)."""
         return self._build().state_dict()
 
-    def _encode(self, X, y=None):
+    def _encode(self, X, y=None, on_host=False):
         inp = DataInputs().load(self.feat_dict, X, y)
-        dev = self._build().device
+        dev = "cpu" if on_host else self._build().device
         idx = torch.from_numpy(np.ascontiguousarray(inp.idx)).to(dev)
         dense = torch.from_numpy(np.ascontiguousarray(inp.dense)).to(dev)
         yt = None
@@ -131,7 +131,10 @@ class DeepModel(BaseEstimator, TransformerMixin):
             if t <= s:
                 continue
             masks = self._dropout_masks(t - s) if training else None
-            _, pred = e.forward(idx[s:t].contiguous(), dense[s:t].contiguous(), training=training,
+            ib, db = idx[s:t].contiguous(), dense[s:t].contiguous()
+            if not ib.is_cuda:  # dataset kept on the host (feeder="pinned")
+                ib, db = ib.to(e.device, non_blocking=True), db.to(e.device, non_blocking=True)
+            _, pred = e.forward(ib, db, training=training,
                                 masks=masks, manual_weights=mw, mv=self._mv_batch(mv_host, s, t))
             out[s:t] = pred.cpu().numpy()
         return out
@@ -210,10 +213,15 @@ class DeepModel(BaseEstimator, TransformerMixin):
         if X_valid is not None and y_valid is not None:
             vi, vd, _ = self._encode(X_valid)
             enc_valid = (vi, vd, self._mv_host)
-        idx, dense, yt = self._encode(X_train, y_train)
+        pinned = self._use_feeder(len(y_train))
+        idx, dense, yt = self._encode(X_train, y_train, on_host=pinned)
         mv_host = self._mv_host
-        eval_results = self._eval_at_epoch((idx, dense, mv_host), y_train, enc_valid, y_valid, time())
         n = len(y_train)
+        if pinned:
+            return self._fit_pinned(idx, dense, yt, mv_host, y_train, enc_valid, y_valid,
+                                    random_seed_for_mini_batch, epoch_callback, X_train,
+                                    batch_number_to_show_progress)
+        eval_results = self._eval_at_epoch((idx, dense, mv_host), y_train, enc_valid, y_valid, time())
         for epoch in range(1, self.epoch + 1):
             start = time()
             seed = np.random.randint(1, 2019) if random_seed_for_mini_batch else self.random_seed
@@ -238,6 +246,50 @@ class DeepModel(BaseEstimator, TransformerMixin):
             if epoch_callback:
                 epoch_callback(model=self, eval_results=eval_results, df_all=X_train[:1])
         return None  # the reference's fit returns None
+
+    def _use_feeder(self, n):
+        """hparams["feeder"]: "gpu" (whole encoded dataset resident in HBM, the default while it is
+        small), "pinned" (host-resident, batches through the pinned-memory feeder), or "auto":
+        pinned once the encoded arrays exceed a quarter of the free HBM."""
+        mode = self.hparams.get("feeder", "auto")
+        if mode == "gpu":
+            return False
+        if mode == "pinned":
+            return True
+        from .feeder import encoded_nbytes
+
+        e = self._build()
+        free, _ = torch.cuda.mem_get_info(e.device)
+        return encoded_nbytes(n, e.F, e.Dn) > free // 4
+
+    def _fit_pinned(self, idx, dense, yt, mv_host, y_train, enc_valid, y_valid, random_seed_for_mini_batch,
+                    epoch_callback, X_train, every):
+        """fit() with the encoded dataset in pinned host memory (th/feeder.py): same batches, same
+        shuffles, the H2D copy of batch i+1 overlaps the step on batch i."""
+        from .feeder import BatchFeeder
+
+        e = self._build()
+        n = len(y_train)
+        feeder = BatchFeeder(idx, dense, yt, self.batch_size, e.device)
+        perm_all = np.arange(n)  # position -> original row: the shuffles compose across epochs
+        eval_results = self._eval_at_epoch((idx, dense, mv_host), y_train, enc_valid, y_valid, time())
+        for epoch in range(1, self.epoch + 1):
+            start = time()
+            seed = np.random.randint(1, 2019) if random_seed_for_mini_batch else self.random_seed
+            p = np.arange(n)
+            check_random_state(seed).shuffle(p)
+            perm_all = perm_all[p]
+            mv_perm = {k: c.take(perm_all) for k, c in mv_host.items()} if mv_host else mv_host
+            total_batch = n // self.batch_size + 1
+            for i, (s, t, ib, db, yb) in enumerate(feeder.batches(perm_all)):
+                self._fit_encoded(ib, db, yb, self._mv_batch(mv_perm, s, t))
+                if i % every == 0:
+                    log.info(f"Fit: {(i + 1)}/{total_batch} has been completed")
+            # evaluation order does not matter for the metrics: the unshuffled host arrays
+            eval_results = self._eval_at_epoch((idx, dense, mv_host), y_train, enc_valid, y_valid, start, epoch)
+            if epoch_callback:
+                epoch_callback(model=self, eval_results=eval_results, df_all=X_train[:1])
+        return None
 
     # --------------------------------------------------------------- checkpoint
     @classmethod

@@ -304,3 +304,43 @@ def test_xdeepfm_trains_with_cin_dropout(hip_lib):
     after = log_loss(df["label"].values, m.predict(df).astype(np.float64))
     assert after < before
     assert np.array_equal(m.predict(df), m.predict(df))  # inference draws no masks
+
+
+@pytest.mark.parametrize("with_genres", [False, True])
+def test_pinned_feeder_fit_equals_gpu_resident_fit(hip_lib, with_genres):
+    """hparams feeder="pinned": the encoded dataset stays in pinned host memory and batches travel
+    on a copy stream one step ahead (th/feeder.py) - same shuffles, same batches, the same model up to
+    the summation order of the float atomics that densify the small-table gradients."""
+    import recman_amd.th as th
+
+    df = ml_frame()
+    preds = {}
+    for mode in ("gpu", "pinned"):
+        fd = ml_features(df)
+        if with_genres:
+            df["genres"] = GOLD["raw_genres"].astype(object)
+            fd["genres"] = th.MultiValCsvFeat(name="genres", tags=tuple(GOLD["genre_tags"].tolist()))
+        hp = {"embedding_size": 8, "cin_cross_layer_units": (8, 8), "deep_hidden_units": (16, 16),
+              "deep_dropout": (1, 1, 1), "learning_rate": 0.01, "feeder": mode}
+        m = th.xDeepFM(fd, hp, metrics=(log_loss,), epoch=2, batch_size=100)  # 1024 rows: ragged last batch
+        m.fit(df, df["label"].values, random_seed_for_mini_batch=False)
+        preds[mode] = m.predict(df)
+    assert np.abs(preds["gpu"] - preds["pinned"]).max() < 2e-5
+
+
+def test_batch_feeder_yields_the_permuted_batches(hip_lib):
+    from recman_amd.th.feeder import BatchFeeder
+
+    g = torch.Generator().manual_seed(0)
+    idx = torch.randint(0, 100, (1000, 5), generator=g)
+    dense = torch.randn(1000, 3, generator=g)
+    y = torch.randint(0, 2, (1000,), generator=g)
+    f = BatchFeeder(idx, dense, y, 96, "cuda")
+    perm = torch.randperm(1000, generator=g).numpy()
+    seen = 0
+    for s, t, ib, db, yb in f.batches(perm):
+        assert torch.equal(ib.cpu(), idx[perm[s:t]]) and torch.equal(db.cpu(), dense[perm[s:t]])
+        assert torch.equal(yb.cpu(), y[perm[s:t]])
+        seen += t - s
+    assert seen == 1000
+    assert sum(t - s for s, t, *_ in f.batches()) == 1000  # no permutation: the natural order
