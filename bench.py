@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent for indices (0 = uniform)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded engine even at world size 1 (rehearsal)")
+    ap.add_argument("--no-graph-segments", action="store_true",
+                    help="sharded + fixed-capacity: do not capture the compute between the collectives "
+                         "as hipGraph segments (eager kernel launches instead)")
     ap.add_argument("--graph-sharded", action="store_true",
                     help="EXPERIMENTAL: capture the row-sharded step (fixed-capacity exchange, RCCL calls "
                          "included) in one hipGraph; off by default - a replayed RCCL all_to_all of "
@@ -250,6 +253,16 @@ def main():
             print(f"[bench] hipGraph capture failed, running eager: {e}", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+    segments = False
+    if sharded and fixed and graph is None and not a.no_graph and not a.no_graph_segments:
+        # the compute between the collectives as hipGraphs, the RCCL calls eager in between
+        try:
+            engine.capture_segments(idx, dense, y)
+            segments = True
+        except Exception as e:
+            print(f"[bench] segment capture failed, running eager: {e}", file=sys.stderr)
+            engine._segs = None
+            torch.cuda.synchronize()
     run = graph.replay if graph is not None else step
 
     def barrier():
@@ -263,6 +276,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         run()
+    enqueue = time.perf_counter() - t0  # host time to enqueue the steps (launch-bound when ~= elapsed)
     barrier()
     elapsed = time.perf_counter() - t0
     if any_overflow():
@@ -307,7 +321,8 @@ def main():
                    "dense_fields": w["Dn"], "emb_dim": w["D"], "hp": {k: v for k, v in w["hp"].items()},
                    "indices": "uniform" if a.zipf == 0 else f"zipf({a.zipf})",
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
-                   "hipgraph": graph is not None,
+                   "host_enqueue_ms_per_step": round(enqueue / a.steps * 1e3, 4),
+                   "hipgraph": ("segments between the collectives" if segments else graph is not None),
                    "table": (f"row-sharded mod {world}, fused [D+4] rows, all_to_all over xGMI, "
                              + ("fixed-capacity exchange (equal splits, no host sync)" if fixed
                                 else "dynamic split sizes (one host sync per batch)")
@@ -348,6 +363,15 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
+        # graphs first: a hipGraph that holds RCCL kernels (--graph-sharded) keeps the communicator
+        # busy and destroy_process_group() waited on it forever
+        run = graph = None
+        if sharded:
+            engine._segs = None
+        import gc
+
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

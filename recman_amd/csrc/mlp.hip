@@ -528,12 +528,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
 // dW0[k][u] = sum_slabs part[slab][k][u]   (k < K, u < H0).  A block owns 64 consecutive
 // slab elements; its 4 waves take every 4th slab (coalesced 256-byte reads), partial sums
 // meet in LDS in a fixed order -> deterministic.
-__global__ __launch_bounds__(256) void mlp_dw0_reduce_kernel(const float *__restrict__ part, int nslab,
-                                                             int K, int Kp, int H0,
-                                                             float *__restrict__ dW0) {
-  __shared__ float sm[4][64];
+__device__ __forceinline__ void mlp_dw0_reduce_body(float (*sm)[64], int blk,
+                                                    const float *__restrict__ part, int nslab, int K,
+                                                    int Kp, int H0, float *__restrict__ dW0) {
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + o;  // element of the [Kp][32] slab
+  const int e = blk * 64 + o;  // element of the [Kp][32] slab
   const int64_t slab = (int64_t)Kp * 32;
   float acc = 0.f;
 #pragma unroll 8
@@ -640,11 +639,11 @@ struct SgOut {
   int Dn;
   int H[kMaxNL];
 };
-__global__ __launch_bounds__(256) void mlp_small_grads_stage2(const float *__restrict__ part, int nblk,
-                                                              int NL, SgOut o) {
-  __shared__ float sm[4][64];
+__device__ __forceinline__ void mlp_small_grads_stage2_body(float (*sm)[64], int blk,
+                                                            const float *__restrict__ part, int nblk,
+                                                            int NL, const SgOut &o) {
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int src = blockIdx.x * 64 + lane;  // element of the per-block partial
+  const int src = blk * 64 + lane;  // element of the per-block partial
   float acc = 0.f;
   if (src < kSgStride) {
 #pragma unroll 8
@@ -672,6 +671,18 @@ __global__ __launch_bounds__(256) void mlp_small_grads_stage2(const float *__res
       if (o.gsum) o.gsum[0] = acc;
     }
   }
+}
+
+// The two finishing reductions of the backward in ONE launch (each was a ~5 us launch of its own on
+// a 250 us step): blocks [0, n_dw0) finish dW0 from mlp_bwd's slabs, the rest finish the small
+// gradients from mlp_small_grads_mfma's per-block partials.
+__global__ __launch_bounds__(256) void mlp_finish_kernel(const float *__restrict__ part, int nslab, int K,
+                                                         int Kp, int H0, float *__restrict__ dW0, int n_dw0,
+                                                         const float *__restrict__ part2, int nblk2, int NL,
+                                                         SgOut o) {
+  __shared__ float sm[4][64];
+  if ((int)blockIdx.x < n_dw0) mlp_dw0_reduce_body(sm, blockIdx.x, part, nslab, K, Kp, H0, dW0);
+  else mlp_small_grads_stage2_body(sm, blockIdx.x - n_dw0, part2, nblk2, NL, o);
 }
 
 size_t mlp_fwd_smem(int K, int NL) {
@@ -779,8 +790,6 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
   }
   if (NL == 1) RM_MLP_BWD(1) else if (NL == 2) RM_MLP_BWD(2) else RM_MLP_BWD(3)
 #undef RM_MLP_BWD
-  hipLaunchKernelGGL(mlp_dw0_reduce_kernel, dim3(Kp * 32 / 64), dim3(256), 0, st, part, nblk, K,
-                     Kp, H[0], dW[0]);
   {
     SgOut o;
     for (int l = 0; l < kMaxNL; ++l) {
@@ -806,8 +815,9 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     else
       hipLaunchKernelGGL((mlp_small_grads_mfma<3>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
                          dh[0], d1p, d2p, g, xdp, Dn, B, part2);
-    hipLaunchKernelGGL(mlp_small_grads_stage2, dim3((kSgStride + 63) / 64), dim3(256), 0, st, part2, sblk,
-                       NL, o);
+    const int n_dw0 = Kp * 32 / 64;
+    hipLaunchKernelGGL(mlp_finish_kernel, dim3(n_dw0 + (kSgStride + 63) / 64), dim3(256), 0, st, part, nblk,
+                       K, Kp, H[0], dW[0], n_dw0, part2, sblk, NL, o);
   }
   RM_CHECK_LAUNCH("rm_mlp_bwd");
   return RM_OK;

@@ -16,7 +16,13 @@ constexpr int kMaxW = 16;
 
 __global__ __launch_bounds__(kBlock) void route_count_kernel(
     const int64_t *__restrict__ idx, const int64_t *__restrict__ field_off, int64_t n, int F, int W,
-    int64_t per_block, int *__restrict__ cnt /* [W][nblk] */) {
+    int64_t per_block, int *__restrict__ cnt /* [W][nblk] */, int64_t *__restrict__ fill,
+    int64_t nfill) {
+  // fixed-capacity layout: every slot starts as the empty id -1 (the place kernel, next on the
+  // stream, overwrites the occupied ones).  A kernel, not hipMemsetAsync: the step is captured in
+  // hipGraphs and a kernel node is the one node type every kernel of this library already is.
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nfill; i += (int64_t)gridDim.x * kBlock)
+    fill[i] = -1;
   __shared__ int sc[kMaxW];
   if (threadIdx.x < kMaxW) sc[threadIdx.x] = 0;
   __syncthreads();
@@ -169,15 +175,10 @@ static int shard_route_impl(const int64_t *idx, const int64_t *field_off, int64_
   const int64_t n = B * F;
   RM_REQUIRE(n < (1ll << 31) && cap * world < (1ll << 31), "rm_shard_route: too many occurrences");
   hipStream_t st = (hipStream_t)stream;
-  if (cap > 0) hipMemsetAsync(send_ids, 0xFF, sizeof(int64_t) * world * cap, st);  // empty slots: id -1
-  if (n == 0) {
-    hipMemsetAsync(counts, 0, sizeof(int64_t) * world, st);
-    return RM_OK;
-  }
-  const int nblk = (int)(n < 1024 * 256 ? (n + 255) / 256 : 1024);
+  const int nblk = (int)(n == 0 ? 1 : n < 1024 * 256 ? (n + 255) / 256 : 1024);
   const int64_t per_block = ((n + nblk - 1) / nblk + kBlock - 1) / kBlock * kBlock;
   hipLaunchKernelGGL(route_count_kernel, dim3(nblk), dim3(kBlock), 0, st, idx, field_off, n, F, world,
-                     per_block, workspace);
+                     per_block, workspace, cap > 0 ? send_ids : nullptr, cap > 0 ? world * cap : 0);
   hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, st, workspace, world * nblk, nblk, world,
                      counts);
   hipLaunchKernelGGL(route_last_count_kernel, dim3(1), dim3(64), 0, st, workspace, nblk, world, n, counts);

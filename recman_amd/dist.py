@@ -309,10 +309,10 @@ class HipRouter:
         self._n = None
         self._turn = 0
 
-    def __call__(self, idx, field_off, world, cap=0):
+    def ensure(self, n, world, cap=0):
+        """Allocates the output ring, the sticky overflow flag and the workspace for n occurrences."""
         from . import ops
 
-        n = idx.numel()
         if self._n != (n, world, cap):
             self._n = (n, world, cap)
             dev = self.device
@@ -322,6 +322,11 @@ class HipRouter:
             self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)  # sticky
             self.ws = torch.empty(ops._lib.lib().rm_shard_route_workspace(world), dtype=torch.int32,
                                   device=dev)
+
+    def __call__(self, idx, field_off, world, cap=0):
+        from . import ops
+
+        self.ensure(idx.numel(), world, cap)
         self._turn = (self._turn + 1) % self.ring
         self.pos, self.ids, self.counts = self._sets[self._turn]
         if cap:
@@ -348,6 +353,8 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
         def __init__(self):
             self._shard_args = (rank, world, group)
             self._pending = None
+            self._slot = None
+            self._segs = None
             self.micro_batches = int(micro_batches)
             super().__init__(spec, D, hp, device=device)
             self._flat_grads = flatten_grads(self.grads)
@@ -384,7 +391,9 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             fm_masks = m.get("fm", (None, None))
             B = idx.shape[0]
             # rows arrive owner-bucketed; the gather kernel reads occurrence (b,f) at row pos[b,f]
-            if self._pending is not None:   # a micro-batch whose exchange was started earlier
+            if self._slot is not None:      # captured segment: static buffers, exchange done by the caller
+                self.ex, self.rows = self._slot, self._slot.rows
+            elif self._pending is not None:   # a micro-batch whose exchange was started earlier
                 self.ex, self._pending = self._pending, None
                 self.rows = self.st.lookup_finish(self.ex)
             else:
@@ -423,6 +432,8 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             pieces when M > 1) and self.grads."""
             M = self.micro_batches
             B = idx.shape[0]
+            if self._segs is not None and masks is None:
+                return self._replay_segments(idx, dense, y)
             self._alloc(B if M <= 1 else B // M)
             l2 = any(self.hp.get(k, 0.0) for k in ("deep_l2_reg", "cin_l2_reg", "cross_layer_l2_reg",
                                                    "embedding_l2_reg", "linear_l2_reg"))
@@ -465,6 +476,144 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             self.shard_grad_rows = [o[1] for o in outs]
             allreduce_dense(self.grads, world, group, self._flat_grads, average=False)
             return total.div_(M)
+
+        # ---- hipGraph segments (fixed-capacity layout): the compute BETWEEN the collectives ----
+        def capture_segments(self, idx, dense, y):
+            """Fixed-capacity layout only.  Captures the three compute stretches of every
+            micro-batch - route | owner-side gather | embed..loss..backward..pack - as hipGraphs
+            over static buffers; fwd_bwd then replays them with the RCCL calls issued eagerly in
+            between (a replayed graph that CONTAINS the all_to_all faulted on this stack, see
+            DESIGN.md).  A step costs 3 graph launches + 3 collectives per micro-batch on the host
+            instead of ~25 kernel launches.  idx / dense / y become the static input buffers:
+            later calls with other tensors of the same shape are copied into them."""
+            from types import SimpleNamespace
+
+            from . import ops
+
+            if not self.st.capacity_factor:
+                raise ValueError("capture_segments needs the fixed-capacity exchange layout")
+            M = max(1, self.micro_batches)
+            B = idx.shape[0]
+            if B % M:
+                raise ValueError("batch must be divisible by micro_batches")
+            b = B // M
+            self._segs = None
+            self._alloc(b)
+            dev, W, F = self.device, self.D + PAD, self.F
+            cap = self.st.capacity(b * F)
+            slots = world * cap
+            router = self.st.route_fn
+            router.ensure(b * F, world, cap)
+            coll = world > 1 or (FORCE and dist.is_initialized())
+            self.grad_scale = 1.0 / (world * M)
+            self._seg_loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            segs = []
+            for c in range(M):
+                s = SimpleNamespace(idx=idx[c * b: (c + 1) * b], dense=dense[c * b: (c + 1) * b],
+                                    y=y[c * b: (c + 1) * b])
+                s.pos = torch.empty(b * F, dtype=torch.int64, device=dev)
+                s.send_ids = torch.empty(slots, dtype=torch.int64, device=dev)
+                s.counts = torch.empty(world, dtype=torch.int64, device=dev)
+                s.recv_ids = torch.empty_like(s.send_ids) if coll else s.send_ids
+                s.served = torch.empty(slots, W, dtype=torch.float32, device=dev)
+                s.rows = torch.empty_like(s.served) if coll else s.served
+                s.grad_rows = torch.zeros(slots, W, dtype=torch.float32, device=dev)
+                s.grad_out = torch.empty_like(s.grad_rows) if coll else s.grad_rows
+                segs.append(s)
+
+            def route(s, c):
+                ops.shard_route_padded(s.idx, self.field_off, world, cap, s.pos, s.send_ids, s.counts,
+                                       router.overflow, router.ws)
+
+            def gather(s, c):
+                ops.gather_rows(self.st.shard, s.recv_ids, s.served)
+
+            def compute(s, c):
+                self._slot = s
+                try:
+                    loss = base.fwd_bwd(self, s.idx, s.dense, s.y, None)
+                finally:
+                    self._slot = None
+                ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
+                                   self.dlogit if self.use_linear else None, s.pos, s.grad_rows)
+                if c == 0:
+                    self._seg_loss.copy_(loss)
+                else:
+                    self._seg_loss.add_(loss)
+                if M > 1:
+                    if c == 0:
+                        self._acc.copy_(self._flat_grads)
+                    elif c < M - 1:
+                        self._acc.add_(self._flat_grads)
+                    else:
+                        self._flat_grads.add_(self._acc)
+                        self._seg_loss.div_(M)
+
+            # eager rehearsal first (lazy workspaces, RCCL buffers), collectives included so the
+            # static buffers hold real rows; then the captures, which only record
+            self._segs, self._seg_coll, self._seg_in = segs, coll, (idx, dense, y)
+            self._seg_bodies = (route, gather, compute)
+            self._run_segments(eager=True)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for c, s in enumerate(segs):
+                    s.graphs = []
+                    for body in (route, gather, compute):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=side):
+                            body(s, c)
+                        s.graphs.append(g)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+
+        def _run_segments(self, eager=False):
+            S, coll = self._segs, self._seg_coll
+            M = len(S)
+
+            def run(s, c, k):
+                if eager:
+                    self._seg_bodies[k](s, c)
+                else:
+                    s.graphs[k].replay()
+
+            def start(c):
+                s = S[c]
+                run(s, c, 0)
+                if coll:
+                    _all_to_all(s.recv_ids, s.send_ids, group=group)
+                run(s, c, 1)
+                return _all_to_all(s.rows, s.served, group=group, async_op=True) if coll else None
+
+            rows_work = start(0)
+            works = []
+            for c, s in enumerate(S):
+                # the NEXT micro-batch's routing and row exchange go out before this one's compute
+                nxt = start(c + 1) if c + 1 < M else None
+                if rows_work is not None:
+                    rows_work.wait()
+                run(s, c, 2)
+                if coll:
+                    works.append(_all_to_all(s.grad_out, s.grad_rows, group=group, async_op=True))
+                rows_work = nxt
+            for w in works:
+                w.wait()
+            if M == 1:
+                self.shard_grad_ids, self.shard_grad_rows = S[0].recv_ids, S[0].grad_out
+            else:
+                self.shard_grad_ids = [s.recv_ids for s in S]
+                self.shard_grad_rows = [s.grad_out for s in S]
+            allreduce_dense(self.grads, world, group, self._flat_grads, average=False)
+            return self._seg_loss
+
+        def _replay_segments(self, idx, dense, y):
+            for src, dst in zip((idx, dense, y), self._seg_in):
+                if src.shape != dst.shape:
+                    raise ValueError("captured segments: batch shape differs from the captured one")
+                if src.data_ptr() != dst.data_ptr():
+                    dst.copy_(src)
+            return self._run_segments()
 
         def _dominant_kernel(self, idx, dense):
             """roofline_probe on the sharded engine: the LOCAL gather + FM + linear kernel over the

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, model, kw, fixed, micro, out_path):
+def _worker(rank, world, port, model, kw, fixed, micro, segments, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.pop("RECMAN_FORCE_COLLECTIVES", None)
@@ -42,7 +42,14 @@ def _worker(rank, world, port, model, kw, fixed, micro, out_path):
         s.st.load_global(full, bias=bias, lin=p["linear_w"].reshape(-1)[:R])
         s.linear_w_dense.copy_(p["linear_w"].reshape(-1)[R:])
         sl = slice(rank * Bl, (rank + 1) * Bl)
-        loss = s.fwd_bwd(idx[sl].cuda(), dense[sl].cuda(), y[sl].cuda())
+        il, dl, yl = idx[sl].cuda(), dense[sl].cuda(), y[sl].cuda()
+        if segments:
+            # the compute between the collectives replayed from hipGraphs; a second batch through
+            # the same graphs (copied into the static inputs), then the batch under test
+            s.capture_segments(il.clone(), dl.clone(), yl.clone())  # these become the static inputs
+            s.fwd_bwd(il.flip(0).contiguous(), dl.flip(0).contiguous(), yl.flip(0).contiguous())
+            assert s._segs is not None
+        loss = s.fwd_bwd(il, dl, yl)
         assert not s.overflowed()
         ids, rows = s.shard_grad_ids, s.shard_grad_rows
         if not isinstance(ids, list):
@@ -57,21 +64,24 @@ def _worker(rank, world, port, model, kw, fixed, micro, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model,kw,fixed,micro", [
-    ("deepfm", {}, True, 1),
-    ("deepfm", {}, False, 2),
-    ("dcn", dict(cross_layers=2, scale=0.15), True, 2),
-    ("xdeepfm", dict(cin_units=(16, 8), scale=0.2), False, 1),
+@pytest.mark.parametrize("model,kw,fixed,micro,segments", [
+    ("deepfm", {}, True, 1, False),
+    ("deepfm", {}, False, 2, False),
+    ("dcn", dict(cross_layers=2, scale=0.15), True, 2, False),
+    ("xdeepfm", dict(cin_units=(16, 8), scale=0.2), False, 1, False),
+    ("deepfm", {}, True, 2, True),
+    ("xdeepfm", dict(cin_units=(16, 8), scale=0.2), True, 1, True),
+    ("dcn", dict(cross_layers=2, scale=0.15), True, 3, True),
 ])
-def test_two_rank_sharded_engine_equals_single_gpu(hip_lib, tmp_path, model, kw, fixed, micro):
+def test_two_rank_sharded_engine_equals_single_gpu(hip_lib, tmp_path, model, kw, fixed, micro, segments):
     from recman_amd import dist as rd
     from recman_amd import engine as eng
     from tests.cases import make_case
 
     world, Bl = 2, 24
     out = str(tmp_path / "r")
-    port = 29700 + (hash((model, fixed, micro)) % 200)
-    mp.spawn(_worker, args=(world, port, model, kw, fixed, micro, out), nprocs=world, join=True)
+    port = 29700 + (hash((model, fixed, micro, segments)) % 200)
+    mp.spawn(_worker, args=(world, port, model, kw, fixed, micro, segments, out), nprocs=world, join=True)
     res = [torch.load(f"{out}.{r}", weights_only=True) for r in range(world)]
 
     spec, p, idx, dense, y, hp = make_case(model, B=world * Bl, D=16, **kw)
@@ -104,3 +114,55 @@ def test_two_rank_sharded_engine_equals_single_gpu(hip_lib, tmp_path, model, kw,
         for k, v in res[r]["grads"].items():
             if k in gi:
                 close(v, gi[k], f"rank {r} dense grad {k}")
+
+
+@pytest.mark.parametrize("model,kw,micro", [
+    ("deepfm", {}, 2),
+    ("dcn", dict(cross_layers=2, scale=0.15), 1),
+    ("xdeepfm", dict(cin_units=(16, 8), scale=0.2), 3),
+])
+def test_segment_graphs_equal_eager_sharded_step(hip_lib, model, kw, micro):
+    """World size 1, no collective: the route | gather | compute segments replayed from hipGraphs
+    give bit-identical gradients to the same engine launching its kernels eagerly."""
+    from recman_amd import dist as rd
+    from recman_amd import engine as eng
+    from tests.cases import make_case
+
+    B = 24
+    spec, p, idx, dense, y, hp = make_case(model, B=B, D=16, **kw)
+    hp = dict(hp, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=0.0, cross_layer_l2_reg=0.0,
+              cin_l2_reg=0.0)
+    espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names)
+    dev = torch.device("cuda", 0)
+    full = torch.cat([p[f"{n}_feat_embed"] for n in spec.sparse_names])
+    R = full.shape[0]
+
+    def make():
+        s = rd.make_sharded_engine(model, espec, 16, hp, dev, 0, 1, capacity_factor=1.5, micro_batches=micro)
+        s.load_params({k: v for k, v in p.items() if k in s.params})
+        s.st.load_global(full, lin=p["linear_w"].reshape(-1)[:R])
+        s.linear_w_dense.copy_(p["linear_w"].reshape(-1)[R:])
+        return s
+
+    def result(s, loss):
+        ids, rows = s.shard_grad_ids, s.shard_grad_rows
+        if not isinstance(ids, list):
+            ids, rows = [ids], [rows]
+        dt = torch.zeros(s.st.shard.shape[0], 16 + rd.PAD, device=dev, dtype=torch.float64)
+        for i, r in zip(ids, rows):
+            live = i >= 0
+            dt.index_add_(0, i[live], r[live].double())
+        return loss.clone(), dt, {k: v.clone() for k, v in s.grads.items()}
+
+    il, dl, yl = idx.cuda(), dense.cuda(), y.cuda()
+    e = make()
+    want = result(e, e.fwd_bwd(il, dl, yl))
+    s = make()
+    s.capture_segments(il.clone(), dl.clone(), yl.clone())
+    s.fwd_bwd(il.flip(0).contiguous(), dl.flip(0).contiguous(), yl.flip(0).contiguous())  # another batch
+    got = result(s, s.fwd_bwd(il, dl, yl))
+    assert not s.overflowed()
+    assert torch.equal(got[0], want[0])
+    assert float((got[1] - want[1]).abs().max()) <= 1e-6 * max(1.0, float(want[1].abs().max()))
+    for k in want[2]:
+        assert float((got[2][k] - want[2][k]).abs().max()) <= 1e-6 * max(1.0, float(want[2][k].abs().max())), k
