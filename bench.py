@@ -68,9 +68,9 @@ def parse():
                     help="sharded + fixed-capacity: do not capture the compute between the collectives "
                          "as hipGraph segments (eager kernel launches instead)")
     ap.add_argument("--graph-sharded", action="store_true",
-                    help="EXPERIMENTAL: capture the row-sharded step (fixed-capacity exchange, RCCL calls "
-                         "included) in one hipGraph; off by default - a replayed RCCL all_to_all of "
-                         "100+ MB faulted on the one-GPU rehearsal box")
+                    help="capture the WHOLE row-sharded step (fixed-capacity exchange, RCCL calls included) "
+                         "in one hipGraph; opt-in - RCCL capture was only exercised at world size 1 "
+                         "(the default captures the compute between the collectives instead)")
     ap.add_argument("--micro-batches", type=int, default=0,
                     help="row-sharded engine: pipeline the step over this many micro-batches so the "
                          "all_to_alls overlap the compute (0 = auto: 2 when N > 1, else 1)")

@@ -23,8 +23,9 @@ uses all 7 links of a GPU at once.
 Two exchange layouts:
   dynamic (default)   exact split sizes: a count all_to_all + ONE host sync per batch
   fixed capacity      every bucket has `cap` slots (cap = capacity_factor * n / W): equal
-                      splits, no count exchange, no host sync - the whole step (routing,
-                      RCCL calls, compute) replays as one hipGraph.  Unused slots carry id -1
+                      splits, no count exchange, no host sync - every shape is static, so the
+                      compute between the collectives replays from hipGraphs
+                      (capture_segments).  Unused slots carry id -1
                       (zero rows).  A batch that needs more than cap slots for some rank sets
                       a sticky device flag (`overflowed()`): its result must be discarded and
                       redone with the dynamic layout.  Cyclic sharding keeps uniform / hashed
