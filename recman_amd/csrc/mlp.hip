@@ -95,6 +95,35 @@ __device__ __forceinline__ void store_chunk(float *xs, const float4 (&v)[8], int
 // global loads are issued before its first LDS write (a load->store loop serialises ~28 L2
 // round trips per thread: 20 us of prologue at the benchmark shape).
 // TRANSPOSED: dst[u*ld + k]; otherwise dst[k*ld + u].
+// Split form: ALL of a thread's W0 values in registers (Kp <= 448: at most 28 with 512 threads), so
+// that the caller can put the first x loads between the W0 loads and their first use - vmcnt
+// retires in order, and x loads issued BEFORE a staging batch would have to land before that batch
+// could be stored (the staging then waits a full HBM round trip instead of an L2 hit).
+constexpr int kW0Regs = 448 * 32 / 512;
+template <int NTHREADS>
+__device__ __forceinline__ void stage_w0_load(float (&v)[kW0Regs], const float *__restrict__ W0, int K,
+                                              int Kp, int H0, int tid) {
+  static_assert(NTHREADS == 512, "kW0Regs assumes 512 threads");
+#pragma unroll
+  for (int q = 0; q < kW0Regs; ++q) {
+    const int t = q * NTHREADS + tid;
+    const int k = t >> 5, u = t & 31;
+    const bool ok = t < Kp * 32 && k < K && u < H0;
+    const float x = W0[ok ? (int64_t)k * H0 + u : 0];
+    v[q] = ok ? x : 0.f;
+  }
+}
+template <bool TRANSPOSED, int NTHREADS>
+__device__ __forceinline__ void stage_w0_store(float *dst, int ld, const float (&v)[kW0Regs], int Kp,
+                                               int tid) {
+#pragma unroll
+  for (int q = 0; q < kW0Regs; ++q) {
+    const int t = q * NTHREADS + tid;
+    const int k = t >> 5, u = t & 31;
+    if (t < Kp * 32) dst[TRANSPOSED ? u * ld + k : k * ld + u] = v[q];
+  }
+}
+
 template <bool TRANSPOSED, int NTHREADS>
 __device__ __forceinline__ void stage_w0(float *dst, int ld, const float *__restrict__ W0, int K,
                                          int Kp, int H0, int tid) {
@@ -139,36 +168,71 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
   constexpr int NW = RM_MLP_FWD_WAVES, NTHR = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
 
-  stage_w0<true, 64 * RM_MLP_FWD_WAVES>(W0t, LDW, w.W[0], K, Kp, w.H[0], tid);
+  static_assert(NTHR == 512, "the staging below is written for 8 waves");
+  // Program order of the prologue's loads: parameters first (L2 hits), then the first two x chunks
+  // of this wave's first tile (HBM), and only then the parameters' LDS stores - the x stream starts
+  // at t = 0 and the staging runs under it.  (With the x loads first, vmcnt's in-order retirement
+  // made the staging wait for them; with the staging first, HBM idled during the prologue: the
+  // kernel ran 15 us over its 22 us of HBM time.)
+  float w0v[kW0Regs];
+  stage_w0_load<NTHR>(w0v, w.W[0], K, Kp, w.H[0], tid);
+  float wav[(NL > 1 ? NL - 1 : 1) * 2];
 #pragma unroll
   for (int l = 1; l < NL; ++l)
-    for (int t = tid; t < 1024; t += NTHR) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = tid + i * NTHR;
       const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
       const int ku = unit_of(s, hh);
-      WA[(l - 1) * 1024 + t] =
-          (ku < w.H[l - 1] && cc < w.H[l]) ? w.W[l][ku * w.H[l] + cc] : 0.f;
+      const bool ok = ku < w.H[l - 1] && cc < w.H[l];
+      const float x = w.W[l][ok ? ku * w.H[l] + cc : 0];
+      wav[(l - 1) * 2 + i] = ok ? x : 0.f;
     }
-  for (int t = tid; t < (NL + 1) * 32; t += NTHR) {
-    const int l = t >> 5, u = t & 31;
-    float v = 0.f;
-    if (l < NL) v = u < w.H[l] ? w.b[l][u] : 0.f;
-    else v = u < w.H[NL - 1] ? w_out[u] : 0.f;
-    bs[t] = v;
+  // biases / w_out: static layer index and unconditional clamped loads (a dynamic `w.b[tid >> 5]`
+  // made hipcc index the kernel-argument struct through memory, three dependent round trips)
+  float bsv = 0.f;
+  {
+    const int u = tid & 31, lsel = tid >> 5;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const bool ok = lsel == l && u < w.H[l];
+      const float x = w.b[l][ok ? u : 0];
+      bsv = ok ? x : bsv;
+    }
+    const bool oko = lsel == NL && u < w.H[NL - 1];
+    const float xo = w_out[oko ? u : 0];
+    bsv = oko ? xo : bsv;
   }
+  const int nch = Kp / 64;
+  const int64_t ntiles = (B + 31) / 32;
+  const int64_t tile0 = (int64_t)blockIdx.x * NW + wave;
+  float4 pfa[8], pfb[8];
+  {
+    const int64_t e0 = (tile0 < ntiles ? tile0 : 0) * 32;  // (a wave without a tile loads tile 0: unused)
+    load_chunk(pfa, xe, xd, FD, Dn, B, e0, 0, lane);
+    load_chunk(pfb, xe, xd, FD, Dn, B, e0, nch > 1 ? 64 : 0, lane);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  stage_w0_store<true, NTHR>(W0t, LDW, w0v, Kp, tid);
+#pragma unroll
+  for (int l = 1; l < NL; ++l)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) WA[(l - 1) * 1024 + tid + i * NTHR] = wav[(l - 1) * 2 + i];
+  if (tid < (NL + 1) * 32) bs[tid] = bsv;
   __syncthreads();
 
   float *xs = xs_all + wave * 32 * kLDX;
-  const int nch = Kp / 64;
-  const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
+  for (int64_t tile = tile0; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
     const int64_t ex0 = tile * 32;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // two chunks in flight per wave (the 7-deep dependent load chain is what bounds this kernel)
-    float4 pfa[8], pfb[8];
-    load_chunk(pfa, xe, xd, FD, Dn, B, ex0, 0, lane);
-    if (nch > 1) load_chunk(pfb, xe, xd, FD, Dn, B, ex0, 64, lane);
+    // two chunks in flight per wave (the 7-deep dependent load chain is what bounds this kernel);
+    // the first tile's were issued in the prologue
+    if (tile != tile0) {
+      load_chunk(pfa, xe, xd, FD, Dn, B, ex0, 0, lane);
+      if (nch > 1) load_chunk(pfb, xe, xd, FD, Dn, B, ex0, 64, lane);
+    }
     for (int ch = 0; ch < nch; ch += 2) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -305,17 +369,24 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wv8 = tid >> 6, wave = wv8;
   const int h = lane >> 5, c = lane & 31;
 
-  stage_w0<false, 512>(W0r, LDR, w.W[0], K, Kp, w.H[0], tid);
+  // prologue loads in the order parameters (L2) -> first tile's x / g / h (HBM) -> parameters' LDS
+  // stores, as in mlp_fwd_kernel: the HBM stream starts at t = 0 and the staging runs under it
+  float w0v[kW0Regs];
+  stage_w0_load<512>(w0v, w.W[0], K, Kp, w.H[0], tid);
+  float wbv[(NL > 1 ? NL - 1 : 1) * 2];
 #pragma unroll
   for (int l = 1; l < NL; ++l)
-    for (int t = tid; t < 1024; t += 512) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = tid + i * 512;
       const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
       const int ku = unit_of(s, hh);  // unit of layer l (the reduction index)
-      WB[(l - 1) * 1024 + t] =
-          (cc < w.H[l - 1] && ku < w.H[l]) ? w.W[l][cc * w.H[l] + ku] : 0.f;
+      const bool ok = cc < w.H[l - 1] && ku < w.H[l];
+      const float x = w.W[l][ok ? cc * w.H[l] + ku : 0];
+      wbv[(l - 1) * 2 + i] = ok ? x : 0.f;
     }
-  if (tid < 32) wo[tid] = tid < w.H[NL - 1] ? w_out[tid] : 0.f;
-  __syncthreads();
+  const bool wo_ok = tid < w.H[NL - 1] && tid < 32;
+  const float wo_x = w_out[wo_ok ? tid : 0];
 
   float *xs = xs_all + wv8 * 32 * kLDT;
   float *dT = dT_all + wv8 * 32 * 33;
@@ -352,6 +423,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
       for (int gq = 0; gq < 4; ++gq)
         hn[l][gq] = *reinterpret_cast<const float4 *>(hptr[l] + bn * 32 + 8 * gq + 4 * h);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  stage_w0_store<false, 512>(W0r, LDR, w0v, Kp, tid);
+#pragma unroll
+  for (int l = 1; l < NL; ++l)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) WB[(l - 1) * 1024 + tid + i * 512] = wbv[(l - 1) * 2 + i];
+  if (tid < 32) wo[tid] = wo_ok ? wo_x : 0.f;
+  __syncthreads();
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t ex0 = tile * 32;
     const int64_t ex_next = (tile + gridDim.x < ntiles ? tile + gridDim.x : tile) * 32;
