@@ -345,22 +345,101 @@ __device__ __forceinline__ void store_ktile(float *xs, const float4 (&v)[4], int
   }
 }
 
+// dh chain of one 32-example tile per wave: dh_last = g w_out * act'(h_last), dh_{l-1} =
+// (dh_l W_l^T) * act'(h_{l-1}); everything transposed as in mlp_fwd_kernel (lane (c, h) holds 16 units
+// of example c), so the layers chain through registers.  Writes dh_l [B,32] for every layer: the
+// inputs of mlp_bwd_kernel (dh0) and mlp_small_grads_mfma (all of them).
 template <int NL>
-__global__ __launch_bounds__(512) void mlp_bwd_kernel(
-    const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn, MlpW w,
-    const float *__restrict__ w_out, int act, int64_t B, const float *__restrict__ g,
+__global__ __launch_bounds__(256) void mlp_dh_chain_kernel(
+    MlpW w, const float *__restrict__ w_out, int act, int64_t B, const float *__restrict__ g,
     const float *__restrict__ h0, const float *__restrict__ h1, const float *__restrict__ h2,
-    const float *__restrict__ fm_sum, int D, float *__restrict__ d_rows, float *__restrict__ dh0,
-    float *__restrict__ dh1, float *__restrict__ dh2, float *__restrict__ dW0_part, int s_lds) {
+    float *__restrict__ dh0, float *__restrict__ dh1, float *__restrict__ dh2) {
+  __shared__ float WB[(NL > 1 ? NL - 1 : 1) * 1024];  // [NL-1][16][2][32]: W_l[c][u(s,h)]
+  __shared__ float wo[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int64_t ntiles = (B + 31) / 32;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  // this wave's inputs first (HBM / L2), the parameters under them
+  const float *hptr[3] = {h0, h1, h2};
+  float4 hc[NL][4];
+  int64_t b = (tile < ntiles ? tile : 0) * 32 + c;
+  const bool valid = tile < ntiles && b < B;
+  b = b < B ? b : B - 1;
+  const float gb = g[b];
+#pragma unroll
+  for (int l = 0; l < NL; ++l)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      hc[l][gq] = *reinterpret_cast<const float4 *>(hptr[l] + b * 32 + 8 * gq + 4 * h);
+#pragma unroll
+  for (int l = 1; l < NL; ++l)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = tid + i * 256;
+      const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
+      const int ku = unit_of(s, hh);  // unit of layer l (the reduction index)
+      const bool ok = cc < w.H[l - 1] && ku < w.H[l];
+      const float x = w.W[l][ok ? cc * w.H[l] + ku : 0];
+      WB[(l - 1) * 1024 + t] = ok ? x : 0.f;
+    }
+  if (tid < 32) wo[tid] = tid < w.H[NL - 1] ? w_out[tid] : 0.f;
+  __syncthreads();
+
+  float dh[16];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const float4 hv = hc[NL - 1][gq];
+    dh[4 * gq + 0] = gb * wo[8 * gq + 4 * h + 0] * actg(hv.x, act);
+    dh[4 * gq + 1] = gb * wo[8 * gq + 4 * h + 1] * actg(hv.y, act);
+    dh[4 * gq + 2] = gb * wo[8 * gq + 4 * h + 2] * actg(hv.z, act);
+    dh[4 * gq + 3] = gb * wo[8 * gq + 4 * h + 3] * actg(hv.w, act);
+  }
+#pragma unroll
+  for (int l = NL - 1; l >= 1; --l) {
+    float *dout = l == 1 ? dh1 : dh2;
+    if (valid) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<float4 *>(dout + b * 32 + 8 * gq + 4 * h) =
+            make_float4(dh[4 * gq], dh[4 * gq + 1], dh[4 * gq + 2], dh[4 * gq + 3]);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[(l - 1) * 1024 + (s * 2 + h) * 32 + c], dh[s], acc,
+                                                 0, 0, 0);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const float4 hv = hc[l - 1][gq];
+      dh[4 * gq + 0] = acc[4 * gq + 0] * actg(hv.x, act);
+      dh[4 * gq + 1] = acc[4 * gq + 1] * actg(hv.y, act);
+      dh[4 * gq + 2] = acc[4 * gq + 2] * actg(hv.z, act);
+      dh[4 * gq + 3] = acc[4 * gq + 3] * actg(hv.w, act);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      *reinterpret_cast<float4 *>(dh0 + b * 32 + 8 * gq + 4 * h) =
+          make_float4(dh[4 * gq], dh[4 * gq + 1], dh[4 * gq + 2], dh[4 * gq + 3]);
+  }
+}
+
+__global__ __launch_bounds__(512) void mlp_bwd_kernel(
+    const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn,
+    const float *__restrict__ W0, int H0, int64_t B, const float *__restrict__ g,
+    const float *__restrict__ dh0, const float *__restrict__ fm_sum, int D,
+    float *__restrict__ d_rows, float *__restrict__ dW0_part, int s_lds) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = FD + Dn;
   const int Kp = ((K + 63) / 64) * 64;
   const int nkt = Kp / 32;
   constexpr int LDR = 36;
   float *W0r = smem;                         // [Kp][36]: W0r[k][u] = W0[k][u]
-  float *WB = W0r + Kp * LDR;                // [NL-1][16][2][32]: W_l[c][u(s,h)]
-  float *wo = WB + (NL - 1) * 1024;          // [32] w_out
-  float *xs_all = wo + 32;                   // [8 waves][32][kLDT]
+  float *xs_all = W0r + Kp * LDR;            // [8 waves][32][kLDT]
   float *dT_all = xs_all + 8 * 32 * kLDT;    // [8 waves][32][33]: dh0 as [example][unit]
   float *gS_all = dT_all + 8 * 32 * 33;      // [8 waves][32][D]: g[b] * S[b][:] of the wave's tile (s_lds)
   // The 8 waves share one 32-example tile; wave w owns k-tiles w and w+8: 2 dW0 accumulators
@@ -369,24 +448,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wv8 = tid >> 6, wave = wv8;
   const int h = lane >> 5, c = lane & 31;
 
-  // prologue loads in the order parameters (L2) -> first tile's x / g / h (HBM) -> parameters' LDS
+  // prologue loads in the order parameters (L2) -> first tile's x / g / dh0 (HBM) -> parameters' LDS
   // stores, as in mlp_fwd_kernel: the HBM stream starts at t = 0 and the staging runs under it
   float w0v[kW0Regs];
-  stage_w0_load<512>(w0v, w.W[0], K, Kp, w.H[0], tid);
-  float wbv[(NL > 1 ? NL - 1 : 1) * 2];
-#pragma unroll
-  for (int l = 1; l < NL; ++l)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int t = tid + i * 512;
-      const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
-      const int ku = unit_of(s, hh);  // unit of layer l (the reduction index)
-      const bool ok = cc < w.H[l - 1] && ku < w.H[l];
-      const float x = w.W[l][ok ? cc * w.H[l] + ku : 0];
-      wbv[(l - 1) * 2 + i] = ok ? x : 0.f;
-    }
-  const bool wo_ok = tid < w.H[NL - 1] && tid < 32;
-  const float wo_x = w_out[wo_ok ? tid : 0];
+  stage_w0_load<512>(w0v, W0, K, Kp, H0, tid);
 
   float *xs = xs_all + wv8 * 32 * kLDT;
   float *dT = dT_all + wv8 * 32 * 33;
@@ -408,28 +473,23 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
     for (int j = 0; j < kWT; ++j)
       if (wave + 8 * j < nkt) load_ktile(pf[j], xe, xd, FD, Dn, B, e0, (wave + 8 * j) * 32, lane);
   }
-  // ... and so are the tile's g and post-activation h values (the dh chain's inputs): without
-  // this every tile started with two exposed global-load latencies (ablation: 40 us floor)
-  const float *hptr[3] = {h0, h1, h2};
-  float4 hn[NL][4];
+  // ... and so are the tile's g and dh0 values (written by mlp_dh_chain_kernel, the launch before):
+  // lane (c = example, h) holds dh0[example][8 gq + 4 h + e] - the B operand of the dX product as it
+  // stands.  (The chain used to be recomputed here by every wave; with every load and MFMA compiled
+  // out the kernel still took 40 of its 102 us - g, h -> dh -> 16 DEPENDENT MFMAs -> dh0 -> LDS sat
+  // on every tile's critical path: profiles/r01_p9_mlp_bwd.md.)
+  float4 dn[4];
   float gn;
   {
     int64_t bn = (int64_t)(blockIdx.x < ntiles ? blockIdx.x : 0) * 32 + c;
     bn = bn < B ? bn : B - 1;
     gn = g[bn];
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq)
-        hn[l][gq] = *reinterpret_cast<const float4 *>(hptr[l] + bn * 32 + 8 * gq + 4 * h);
+    for (int gq = 0; gq < 4; ++gq)
+      dn[gq] = *reinterpret_cast<const float4 *>(dh0 + bn * 32 + 8 * gq + 4 * h);
   }
   __builtin_amdgcn_sched_barrier(0);
   stage_w0_store<false, 512>(W0r, LDR, w0v, Kp, tid);
-#pragma unroll
-  for (int l = 1; l < NL; ++l)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) WB[(l - 1) * 1024 + tid + i * 512] = wbv[(l - 1) * 2 + i];
-  if (tid < 32) wo[tid] = wo_ok ? wo_x : 0.f;
   __syncthreads();
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t ex0 = tile * 32;
@@ -437,20 +497,19 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
     const int64_t b = ex0 + c;
     const bool valid = b < B;
     const float gb = valid ? gn : 0.f;
-    float4 hc[NL][4];
+    float dh[16];
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) hc[l][gq] = hn[l][gq];
+    for (int gq = 0; gq < 4; ++gq) {
+      dh[4 * gq + 0] = dn[gq].x; dh[4 * gq + 1] = dn[gq].y;
+      dh[4 * gq + 2] = dn[gq].z; dh[4 * gq + 3] = dn[gq].w;
+    }
     {  // next tile's values (the last tile re-loads its own)
       int64_t bn = ex_next + c;
       bn = bn < B ? bn : B - 1;
       gn = g[bn];
 #pragma unroll
-      for (int l = 0; l < NL; ++l)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-          hn[l][gq] = *reinterpret_cast<const float4 *>(hptr[l] + bn * 32 + 8 * gq + 4 * h);
+      for (int gq = 0; gq < 4; ++gq)
+        dn[gq] = *reinterpret_cast<const float4 *>(dh0 + bn * 32 + 8 * gq + 4 * h);
     }
     if (s_lds) {
       // g[b] * S[b][:] of this tile, once per tile: every k-tile's epilogue adds the same 16-byte
@@ -465,49 +524,6 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
         *reinterpret_cast<float4 *>(gS + row * D + 4 * p4) =
             make_float4(gr * s4.x, gr * s4.y, gr * s4.z, gr * s4.w);
       }
-    }
-    // ---- dh chain (recomputed by every wave; wave 0 stores dh_l) ----
-    float dh[16];
-    {
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const float4 hv = hc[NL - 1][gq];
-        dh[4 * gq + 0] = gb * wo[8 * gq + 4 * h + 0] * actg(hv.x, act);
-        dh[4 * gq + 1] = gb * wo[8 * gq + 4 * h + 1] * actg(hv.y, act);
-        dh[4 * gq + 2] = gb * wo[8 * gq + 4 * h + 2] * actg(hv.z, act);
-        dh[4 * gq + 3] = gb * wo[8 * gq + 4 * h + 3] * actg(hv.w, act);
-      }
-    }
-#pragma unroll
-    for (int l = NL - 1; l >= 1; --l) {
-      float *dout = l == 1 ? dh1 : dh2;
-      if (valid && wave == 0) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-          *reinterpret_cast<float4 *>(dout + b * 32 + 8 * gq + 4 * h) =
-              make_float4(dh[4 * gq], dh[4 * gq + 1], dh[4 * gq + 2], dh[4 * gq + 3]);
-      }
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[(l - 1) * 1024 + (s * 2 + h) * 32 + c], dh[s],
-                                                   acc, 0, 0, 0);
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const float4 hv = hc[l - 1][gq];
-        dh[4 * gq + 0] = acc[4 * gq + 0] * actg(hv.x, act);
-        dh[4 * gq + 1] = acc[4 * gq + 1] * actg(hv.y, act);
-        dh[4 * gq + 2] = acc[4 * gq + 2] * actg(hv.z, act);
-        dh[4 * gq + 3] = acc[4 * gq + 3] * actg(hv.w, act);
-      }
-    }
-    if (valid && wave == 0) {
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq)
-        *reinterpret_cast<float4 *>(dh0 + b * 32 + 8 * gq + 4 * h) =
-            make_float4(dh[4 * gq], dh[4 * gq + 1], dh[4 * gq + 2], dh[4 * gq + 3]);
     }
     // dh0 as [example][unit] for the dW0 product (B operand: lane = unit)
 #pragma unroll
@@ -768,9 +784,9 @@ size_t mlp_fwd_smem(int K, int NL) {
   const int Kp = ((K + 63) / 64) * 64;
   return (size_t)(32 * (Kp + 4) + (NL - 1) * 1024 + (NL + 1) * 32 + RM_MLP_FWD_WAVES * 32 * kLDX) * sizeof(float);
 }
-size_t mlp_bwd_smem(int K, int NL, int Ds) {  // Ds: columns of the per-wave g*S tiles (0 = none)
+size_t mlp_bwd_smem(int K, int Ds) {  // Ds: columns of the per-wave g*S tiles (0 = none)
   const int Kp = ((K + 63) / 64) * 64;
-  return (size_t)(Kp * 36 + (NL - 1) * 1024 + 32 + 8 * 32 * kLDT + 8 * 32 * 33 + 8 * 32 * Ds) * sizeof(float);
+  return (size_t)(Kp * 36 + 8 * 32 * kLDT + 8 * 32 * 33 + 8 * 32 * Ds) * sizeof(float);
 }
 
 int mlp_check(const char *fn, int FD, int Dn, int NL, const int *H) {
@@ -851,24 +867,33 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
   }
   const int K = FD + Dn, Kp = ((K + 63) / 64) * 64;
   // the per-wave g*S tiles go to LDS when they fit next to everything else (D = 16: 16 KB more)
-  const int s_lds = (fm_sum != nullptr && mlp_bwd_smem(K, NL, D) <= 160 * 1024) ? 1 : 0;
-  const size_t smem = mlp_bwd_smem(K, NL, s_lds ? D : 0);
+  const int s_lds = (fm_sum != nullptr && mlp_bwd_smem(K, D) <= 160 * 1024) ? 1 : 0;
+  const size_t smem = mlp_bwd_smem(K, s_lds ? D : 0);
   const int64_t ntiles = (B + 31) / 32;
   const int nblk = rm_grid_cap(ntiles, 256);  // one 8-wave block per CU, one 32-example tile at a time
   hipStream_t st = (hipStream_t)stream;
   float *part = workspace;
   float *part2 = workspace + (int64_t)512 * Kp * 32;
-#define RM_MLP_BWD(NL_)                                                                          \
-  {                                                                                              \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_kernel<NL_>),               \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
-    hipLaunchKernelGGL((mlp_bwd_kernel<NL_>), dim3(nblk), dim3(512), smem, st, xe, xd, FD, Dn, w, \
-                       w_out, act, B, g, h[0], NL > 1 ? h[1] : nullptr, NL > 2 ? h[2] : nullptr, \
-                       fm_sum, D, d_rows, dh[0], NL > 1 ? dh[1] : nullptr,                       \
-                       NL > 2 ? dh[2] : nullptr, part, s_lds);                                   \
+  // 1. the dh chain, one wave per tile: dh_l for every layer
+  {
+    const dim3 cgrid((unsigned)((ntiles + 3) / 4));
+    const float *h1p = NL > 1 ? h[1] : nullptr, *h2p = NL > 2 ? h[2] : nullptr;
+    float *d1p = NL > 1 ? dh[1] : nullptr, *d2p = NL > 2 ? dh[2] : nullptr;
+    if (NL == 1)
+      hipLaunchKernelGGL((mlp_dh_chain_kernel<1>), cgrid, dim3(256), 0, st, w, w_out, act, B, g, h[0], h1p,
+                         h2p, dh[0], d1p, d2p);
+    else if (NL == 2)
+      hipLaunchKernelGGL((mlp_dh_chain_kernel<2>), cgrid, dim3(256), 0, st, w, w_out, act, B, g, h[0], h1p,
+                         h2p, dh[0], d1p, d2p);
+    else
+      hipLaunchKernelGGL((mlp_dh_chain_kernel<3>), cgrid, dim3(256), 0, st, w, w_out, act, B, g, h[0], h1p,
+                         h2p, dh[0], d1p, d2p);
   }
-  if (NL == 1) RM_MLP_BWD(1) else if (NL == 2) RM_MLP_BWD(2) else RM_MLP_BWD(3)
-#undef RM_MLP_BWD
+  // 2. dX (+ FM term) -> d_rows and the dW0 slabs, from x and dh0
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(nblk), dim3(512), smem, st, xe, xd, FD, Dn, W[0], H[0], B, g,
+                     (const float *)dh[0], fm_sum, D, d_rows, part, s_lds);
   {
     SgOut o;
     for (int l = 0; l < kMaxNL; ++l) {
