@@ -148,19 +148,47 @@ int rm_logit_loss(const float *logit_a, float coef_a, const float *logit_b, floa
  *   and d_g_sum [1] (NULL ok) = sum_b g[b]: the gradients of the linear term's dense weights and
  *   bias when the same g drives it (layers.py:330-347; saves the rm_linear_dense_bwd pass).
  *   Deterministic (no float atomics).
- *   workspace: rm_mlp_bwd_workspace(FD, Dn) floats. */
+ *   workspace: rm_mlp_bwd_workspace(FD, Dn) floats.
+ *
+ * Fused training head (rm_mlp_tail, optional - NULL gives the plain calls above).  When the DNN is
+ *   the LAST branch of the model's forward (DeepFM, xDeepFM), everything between its output and its
+ *   backward is elementwise per example: final logit = coef_mlp * dnn + coef_a * logit_a + coef_b *
+ *   logit_b (xDeepFM.py:99-102), PredictionLayer + loss (layers.py:796-808, utils.py:192-198, the
+ *   arithmetic of rm_logit_loss) and the dh chain of the hidden layers.  rm_mlp_fwd with a tail does
+ *   all of it in the forward kernel's epilogue, where h_l are still in registers: it writes logit /
+ *   pred / dlogit (= dLoss/dlogit * grad_scale, the `g` of the backward), the per-tile loss sums
+ *   loss_partial [ceil(B/32)] and dh[l] [B,32].  rm_mlp_bwd with the SAME tail skips its own dh-chain
+ *   launch (g = tail->dlogit) and its finishing kernel also reduces loss_partial into loss [1]
+ *   (mean over B; no l2 terms).  Saves three launches per step (rm_logit_loss's two kernels and the
+ *   chain kernel) - 20 of 237 us on the DeepFM benchmark step. */
+typedef struct rm_mlp_tail {
+  const float *logit_a; /* other branch logits [B], NULL = absent */
+  float coef_a;
+  const float *logit_b;
+  float coef_b;
+  float coef_mlp;       /* coefficient of this MLP's logit in the sum */
+  const int64_t *y;     /* labels: int64 (classification) ... */
+  const float *y_f;     /* ... or float (regression); exactly one of them */
+  int task;             /* 0 = classification (sigmoid + binary cross-entropy), 1 = regression (MSE) */
+  float grad_scale;     /* dlogit is multiplied by this (micro-batches / ranks); 1 = plain mean over B */
+  float *logit, *pred, *dlogit; /* [B] outputs (logit / pred may be NULL) */
+  float *loss_partial;  /* [ceil(B/32)] workspace: per-tile loss sums */
+  float *loss;          /* [1], written by rm_mlp_bwd's finishing kernel; NULL = not wanted */
+  float *dh[3];         /* dh[l] [B,32] for l < NL (the same buffers rm_mlp_bwd gets as dh) */
+} rm_mlp_tail;
+
 int rm_mlp_supported(int FD, int Dn, int NL, const int *H);
 int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
                const float *const *W, const float *const *bias, const float *w_out,
                const float *w0_out, int act, int64_t B, float *const *h_out, float *logit,
-               rm_stream_t stream);
+               const rm_mlp_tail *tail, rm_stream_t stream);
 int64_t rm_mlp_bwd_workspace(int FD, int Dn);
 int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
                const float *const *W, const float *w_out, int act, int64_t B, const float *g,
                const float *const *h, const float *fm_sum, int D, float *d_rows,
                float *const *dh, float *const *dW, float *const *db, float *d_w_out,
                float *d_w0_out, float *d_xd_wsum, float *d_g_sum, float *workspace,
-               rm_stream_t stream);
+               const rm_mlp_tail *tail, rm_stream_t stream);
 
 /* Epilogues of the library-GEMM DNN path (wide hidden layers, layers.py:593-601):
  * rm_bias_act: x[b,j] = act(x[b,j] + bias[j]) in place (bias may be NULL);

@@ -20,6 +20,14 @@ class RecmanHipError(RuntimeError):
 P = c_void_p  # every device pointer and the stream travel as void*
 I64 = c_int64
 
+class MlpTail(ctypes.Structure):
+    """rm_mlp_tail of include/recman_hip.h (the fused training head of the skinny MLP)."""
+    _fields_ = [("logit_a", P), ("coef_a", c_float), ("logit_b", P), ("coef_b", c_float),
+                ("coef_mlp", c_float), ("y", P), ("y_f", P), ("task", c_int), ("grad_scale", c_float),
+                ("logit", P), ("pred", P), ("dlogit", P), ("loss_partial", P), ("loss", P),
+                ("dh", P * 3)]
+
+
 # name -> argtypes, in the order of include/recman_hip.h
 SIGNATURES = {
     "rm_version": [],
@@ -32,9 +40,9 @@ SIGNATURES = {
     "rm_logit_loss": [P, c_float, P, c_float, P, c_float, P, c_float, P, P, c_int, I64, P, P, P,
                       P, P, P],
     "rm_mlp_supported": [c_int, c_int, c_int, P],
-    "rm_mlp_fwd": [P, P, c_int, c_int, c_int, P, P, P, P, P, c_int, I64, P, P, P],
+    "rm_mlp_fwd": [P, P, c_int, c_int, c_int, P, P, P, P, P, c_int, I64, P, P, P, P],
     "rm_mlp_bwd": [P, P, c_int, c_int, c_int, P, P, P, c_int, I64, P, P, P, c_int, P, P, P, P, P, P,
-                   P, P, P, P],
+                   P, P, P, P, P],
     "rm_bias_act": [P, P, I64, c_int, c_int, P],
     "rm_act_bwd": [P, P, I64, c_int, c_int, P],
     "rm_outer_actgrad": [P, P, P, I64, c_int, c_int, P, P],

@@ -6,7 +6,6 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxBlocks = 1024;
-constexpr float kEps = 1e-7f;  // Keras backend epsilon()
 
 __global__ __launch_bounds__(kBlock) void logit_loss_kernel(
     const float *__restrict__ la, float ca, const float *__restrict__ lb, float cb,
@@ -26,24 +25,10 @@ __global__ __launch_bounds__(kBlock) void logit_loss_kernel(
     if (ld) z += cd * ld[i];
     if (logit) logit[i] = z;
     const float t = y ? (float)y[i] : (y_f ? y_f[i] : 0.f);
-    if (task == 0) {
-      const float p = 1.0f / (1.0f + expf(-z));
-      if (pred) pred[i] = p;
-      const float lo = kEps, hi = 1.0f - kEps;
-      const float pc = fminf(fmaxf(p, lo), hi);
-      const float a = pc + kEps, c = 1.0f - pc + kEps;
-      acc += -(t * logf(a) + (1.0f - t) * logf(c));
-      if (dlogit) {
-        const bool inside = p >= lo && p <= hi;  // clip passes the gradient only inside
-        const float dp = inside ? -(t / a - (1.0f - t) / c) : 0.f;
-        dlogit[i] = dp * p * (1.0f - p) * invB;
-      }
-    } else {
-      if (pred) pred[i] = z;
-      const float e = z - t;
-      acc += e * e;
-      if (dlogit) dlogit[i] = 2.0f * e * invB;
-    }
+    float p, dz;
+    acc += rm_loss_point(z, t, task, &p, &dz);
+    if (pred) pred[i] = p;
+    if (dlogit) dlogit[i] = dz * invB;
   }
   acc = rm_wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;

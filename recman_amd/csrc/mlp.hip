@@ -151,12 +151,14 @@ __device__ __forceinline__ void stage_w0(float *dst, int ld, const float *__rest
 #ifndef RM_MLP_FWD_WAVES
 #define RM_MLP_FWD_WAVES 8
 #endif
-template <int NL>
+// TAIL: the fused training head (rm_mlp_tail, recman_hip.h) in the epilogue - final logit, prediction,
+// loss term, dLoss/dlogit and the dh chain, while h_l are still in registers.
+template <int NL, bool TAIL>
 __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
     const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn, MlpW w,
     const float *__restrict__ w_out, const float *__restrict__ w0_out, int act, int64_t B,
     float *__restrict__ h0, float *__restrict__ h1, float *__restrict__ h2,
-    float *__restrict__ logit) {
+    float *__restrict__ logit, rm_mlp_tail tl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = FD + Dn;
   const int Kp = ((K + 63) / 64) * 64;
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
   float *W0t = smem;                         // [32][LDW]: W0t[u][k] = W0[k][u]
   float *WA = W0t + 32 * LDW;                // [NL-1][16][2][32]: W_l[u(s,h)][c]
   float *bs = WA + (NL - 1) * 1024;          // [NL][32] biases, then [32] w_out
-  float *xs_all = bs + (NL + 1) * 32;        // [waves][32][kLDX]
+  float *WBt = bs + (NL + 1) * 32;           // TAIL: [NL-1][16][2][32]: W_l[c][u(s,h)] (the chain's operand)
+  float *xs_all = WBt + (TAIL ? (NL - 1) * 1024 : 0);  // [waves][32][kLDX]
   constexpr int NW = RM_MLP_FWD_WAVES, NTHR = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
 
@@ -190,6 +193,20 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
     }
   // biases / w_out: static layer index and unconditional clamped loads (a dynamic `w.b[tid >> 5]`
   // made hipcc index the kernel-argument struct through memory, three dependent round trips)
+  float wbv[(NL > 1 ? NL - 1 : 1) * 2];
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int l = 1; l < NL; ++l)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int t = tid + i * NTHR;
+        const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
+        const int ku = unit_of(s, hh);  // unit of layer l (the chain's reduction index)
+        const bool ok = cc < w.H[l - 1] && ku < w.H[l];
+        const float x = w.W[l][ok ? cc * w.H[l] + ku : 0];
+        wbv[(l - 1) * 2 + i] = ok ? x : 0.f;
+      }
+  }
   float bsv = 0.f;
   {
     const int u = tid & 31, lsel = tid >> 5;
@@ -217,7 +234,10 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
 #pragma unroll
   for (int l = 1; l < NL; ++l)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) WA[(l - 1) * 1024 + tid + i * NTHR] = wav[(l - 1) * 2 + i];
+    for (int i = 0; i < 2; ++i) {
+      WA[(l - 1) * 1024 + tid + i * NTHR] = wav[(l - 1) * 2 + i];
+      if constexpr (TAIL) WBt[(l - 1) * 1024 + tid + i * NTHR] = wbv[(l - 1) * 2 + i];
+    }
   if (tid < (NL + 1) * 32) bs[tid] = bsv;
   __syncthreads();
 
@@ -259,6 +279,7 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
     const int64_t b = ex0 + c;
     const bool valid = b < B;
     float hv[16];
+    float hl[TAIL ? NL : 1][16];  // TAIL: every layer's post-activation values, for the chain
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (l > 0) {
@@ -271,6 +292,10 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) hv[r] = actf(acc[r] + bs[l * 32 + unit_of(r, h)], act);
+      if constexpr (TAIL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hl[l][r] = hv[r];
+      }
       float *hp = l == 0 ? h0 : (l == 1 ? h1 : h2);
       if (valid && hp != nullptr) {
 #pragma unroll
@@ -283,7 +308,56 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) part += hv[r] * bs[NL * 32 + unit_of(r, h)];
     part += __shfl_xor(part, 32, 64);
-    if (valid && h == 0) logit[b] = part + (w0_out ? w0_out[0] : 0.f);
+    const float dnn = part + (w0_out ? w0_out[0] : 0.f);
+    if (valid && h == 0) logit[b] = dnn;
+    if constexpr (TAIL) {
+      // ---- final logit, PredictionLayer, loss term, dLoss/dlogit (rm_logit_loss's arithmetic, same
+      // order of the branch sum), then the dh chain; both lane halves compute the example's scalars
+      const int64_t bc = valid ? b : B - 1;
+      float z = 0.f;
+      if (tl.logit_a) z += tl.coef_a * tl.logit_a[bc];
+      if (tl.logit_b) z += tl.coef_b * tl.logit_b[bc];
+      z += tl.coef_mlp * dnn;
+      const float t = tl.y ? (float)tl.y[bc] : tl.y_f[bc];
+      float p, dz;
+      const float lt = rm_loss_point(z, t, tl.task, &p, &dz);
+      float gb = dz * (1.0f / (float)B);
+      gb *= tl.grad_scale;
+      if (valid && h == 0) {
+        if (tl.logit) tl.logit[b] = z;
+        if (tl.pred) tl.pred[b] = p;
+        tl.dlogit[b] = gb;
+      }
+      const float ls = rm_wave_sum((valid && h == 0) ? lt : 0.f);
+      if (lane == 0) tl.loss_partial[tile] = ls;
+      float dh[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dh[r] = gb * bs[NL * 32 + unit_of(r, h)] * actg(hl[NL - 1][r], act);
+#pragma unroll
+      for (int l = NL - 1; l >= 1; --l) {
+        if (valid) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4 *>(tl.dh[l] + b * 32 + 8 * gq + 4 * h) =
+                make_float4(dh[4 * gq], dh[4 * gq + 1], dh[4 * gq + 2], dh[4 * gq + 3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WBt[(l - 1) * 1024 + (s * 2 + h) * 32 + c], dh[s],
+                                                     acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = acc[r] * actg(hl[l - 1][r], act);
+      }
+      if (valid) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<float4 *>(tl.dh[0] + b * 32 + 8 * gq + 4 * h) =
+              make_float4(dh[4 * gq], dh[4 * gq + 1], dh[4 * gq + 2], dh[4 * gq + 3]);
+      }
+    }
   }
 }
 
@@ -774,15 +848,30 @@ __device__ __forceinline__ void mlp_small_grads_stage2_body(float (*sm)[64], int
 __global__ __launch_bounds__(256) void mlp_finish_kernel(const float *__restrict__ part, int nslab, int K,
                                                          int Kp, int H0, float *__restrict__ dW0, int n_dw0,
                                                          const float *__restrict__ part2, int nblk2, int NL,
-                                                         SgOut o) {
+                                                         SgOut o, int n_sg,
+                                                         const float *__restrict__ loss_partial,
+                                                         int64_t n_loss, float invB,
+                                                         float *__restrict__ loss) {
   __shared__ float sm[4][64];
-  if ((int)blockIdx.x < n_dw0) mlp_dw0_reduce_body(sm, blockIdx.x, part, nslab, K, Kp, H0, dW0);
-  else mlp_small_grads_stage2_body(sm, blockIdx.x - n_dw0, part2, nblk2, NL, o);
+  if ((int)blockIdx.x < n_dw0) {
+    mlp_dw0_reduce_body(sm, blockIdx.x, part, nslab, K, Kp, H0, dW0);
+  } else if ((int)blockIdx.x < n_dw0 + n_sg) {
+    mlp_small_grads_stage2_body(sm, blockIdx.x - n_dw0, part2, nblk2, NL, o);
+  } else {
+    // the fused head's loss: mean over B of the per-tile sums, fixed order -> deterministic
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n_loss; i += 256) acc += loss_partial[i];
+    acc = rm_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[0][threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3])) * invB;
+  }
 }
 
-size_t mlp_fwd_smem(int K, int NL) {
+size_t mlp_fwd_smem(int K, int NL, bool tail) {
   const int Kp = ((K + 63) / 64) * 64;
-  return (size_t)(32 * (Kp + 4) + (NL - 1) * 1024 + (NL + 1) * 32 + RM_MLP_FWD_WAVES * 32 * kLDX) * sizeof(float);
+  return (size_t)(32 * (Kp + 4) + (NL - 1) * 1024 * (tail ? 2 : 1) + (NL + 1) * 32 +
+                  RM_MLP_FWD_WAVES * 32 * kLDX) * sizeof(float);
 }
 size_t mlp_bwd_smem(int K, int Ds) {  // Ds: columns of the per-wave g*S tiles (0 = none)
   const int Kp = ((K + 63) / 64) * 64;
@@ -807,34 +896,49 @@ extern "C" int rm_mlp_supported(int FD, int Dn, int NL, const int *H) {
   return 1;
 }
 
+static int mlp_tail_check(const char *fn, const rm_mlp_tail *t, int NL) {
+  RM_REQUIRE(t->dlogit && t->loss_partial, "%s: tail needs dlogit and loss_partial", fn);
+  RM_REQUIRE((t->y != nullptr) != (t->y_f != nullptr), "%s: tail needs exactly one of y / y_f", fn);
+  RM_REQUIRE(t->task == 0 || t->task == 1, "%s: tail task must be 0 or 1", fn);
+  for (int l = 0; l < NL; ++l) RM_REQUIRE(t->dh[l], "%s: tail needs dh[%d]", fn, l);
+  return RM_OK;
+}
+
 extern "C" int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
                           const float *const *W, const float *const *bias, const float *w_out,
                           const float *w0_out, int act, int64_t B, float *const *h_out,
-                          float *logit, rm_stream_t stream) {
+                          float *logit, const rm_mlp_tail *tail, rm_stream_t stream) {
   int rc = mlp_check("rm_mlp_fwd", FD, Dn, NL, H);
   if (rc != RM_OK) return rc;
   if (B == 0) return RM_OK;
   RM_REQUIRE((FD == 0 || (xe && rm_aligned16(xe))) && (Dn == 0 || xd) && W && bias && w_out && logit &&
                  h_out, "rm_mlp_fwd: NULL or unaligned argument");
+  for (int l = 0; l < NL; ++l) RM_REQUIRE(W[l] && bias[l], "rm_mlp_fwd: NULL weight / bias of layer %d", l);
+  if (tail && (rc = mlp_tail_check("rm_mlp_fwd", tail, NL)) != RM_OK) return rc;
   MlpW w;
   for (int l = 0; l < kMaxNL; ++l) {
     w.W[l] = l < NL ? W[l] : nullptr;
     w.b[l] = l < NL ? bias[l] : nullptr;
     w.H[l] = l < NL ? H[l] : 0;
   }
-  const size_t smem = mlp_fwd_smem(FD + Dn, NL);
+  const size_t smem = mlp_fwd_smem(FD + Dn, NL, tail != nullptr);
   const int64_t ntiles = (B + 31) / 32;
   dim3 grid((unsigned)rm_grid_cap((ntiles + RM_MLP_FWD_WAVES - 1) / RM_MLP_FWD_WAVES, 256));
   hipStream_t st = (hipStream_t)stream;
   float *h0 = h_out[0], *h1 = NL > 1 ? h_out[1] : nullptr, *h2 = NL > 2 ? h_out[2] : nullptr;
-#define RM_MLP_FWD(NL_)                                                                        \
-  {                                                                                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwd_kernel<NL_>),             \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);          \
-    hipLaunchKernelGGL((mlp_fwd_kernel<NL_>), grid, dim3(64 * RM_MLP_FWD_WAVES), smem, st, xe, xd, FD, Dn, w, \
-                       w_out, w0_out, act, B, h0, h1, h2, logit);                              \
+  const rm_mlp_tail tl = tail ? *tail : rm_mlp_tail{};
+#define RM_MLP_FWD(NL_, TAIL_)                                                                       \
+  {                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwd_kernel<NL_, TAIL_>),            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                \
+    hipLaunchKernelGGL((mlp_fwd_kernel<NL_, TAIL_>), grid, dim3(64 * RM_MLP_FWD_WAVES), smem, st, xe, \
+                       xd, FD, Dn, w, w_out, w0_out, act, B, h0, h1, h2, logit, tl);                  \
   }
-  if (NL == 1) RM_MLP_FWD(1) else if (NL == 2) RM_MLP_FWD(2) else RM_MLP_FWD(3)
+  if (tail) {
+    if (NL == 1) RM_MLP_FWD(1, true) else if (NL == 2) RM_MLP_FWD(2, true) else RM_MLP_FWD(3, true)
+  } else {
+    if (NL == 1) RM_MLP_FWD(1, false) else if (NL == 2) RM_MLP_FWD(2, false) else RM_MLP_FWD(3, false)
+  }
 #undef RM_MLP_FWD
   RM_CHECK_LAUNCH("rm_mlp_fwd");
   return RM_OK;
@@ -850,10 +954,11 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
                           const float *g, const float *const *h, const float *fm_sum, int D,
                           float *d_rows, float *const *dh, float *const *dW, float *const *db,
                           float *d_w_out, float *d_w0_out, float *d_xd_wsum, float *d_g_sum,
-                          float *workspace, rm_stream_t stream) {
+                          float *workspace, const rm_mlp_tail *tail, rm_stream_t stream) {
   int rc = mlp_check("rm_mlp_bwd", FD, Dn, NL, H);
   if (rc != RM_OK) return rc;
   if (B == 0) return RM_OK;
+  if (tail && (rc = mlp_tail_check("rm_mlp_bwd", tail, NL)) != RM_OK) return rc;
   RM_REQUIRE((FD == 0 || (xe && rm_aligned16(xe))) && (Dn == 0 || xd) && W && w_out && g && h && dh &&
                  dW && workspace && (FD == 0 || (d_rows && rm_aligned16(d_rows))),
              "rm_mlp_bwd: NULL or unaligned argument");
@@ -874,8 +979,8 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
   hipStream_t st = (hipStream_t)stream;
   float *part = workspace;
   float *part2 = workspace + (int64_t)512 * Kp * 32;
-  // 1. the dh chain, one wave per tile: dh_l for every layer
-  {
+  // 1. the dh chain, one wave per tile: dh_l for every layer (already there after a fused forward)
+  if (!tail) {
     const dim3 cgrid((unsigned)((ntiles + 3) / 4));
     const float *h1p = NL > 1 ? h[1] : nullptr, *h2p = NL > 2 ? h[2] : nullptr;
     float *d1p = NL > 1 ? dh[1] : nullptr, *d2p = NL > 2 ? dh[2] : nullptr;
@@ -919,9 +1024,12 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     else
       hipLaunchKernelGGL((mlp_small_grads_mfma<3>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
                          dh[0], d1p, d2p, g, xdp, Dn, B, part2);
-    const int n_dw0 = Kp * 32 / 64;
-    hipLaunchKernelGGL(mlp_finish_kernel, dim3(n_dw0 + (kSgStride + 63) / 64), dim3(256), 0, st, part, nblk,
-                       K, Kp, H[0], dW[0], n_dw0, part2, sblk, NL, o);
+    const int n_dw0 = Kp * 32 / 64, n_sg = (kSgStride + 63) / 64;
+    const bool with_loss = tail && tail->loss;
+    hipLaunchKernelGGL(mlp_finish_kernel, dim3(n_dw0 + n_sg + (with_loss ? 1 : 0)), dim3(256), 0, st, part,
+                       nblk, K, Kp, H[0], dW[0], n_dw0, part2, sblk, NL, o, n_sg,
+                       with_loss ? tail->loss_partial : nullptr, ntiles, 1.0f / (float)B,
+                       with_loss ? tail->loss : nullptr);
   }
   RM_CHECK_LAUNCH("rm_mlp_bwd");
   return RM_OK;

@@ -41,6 +41,28 @@ __device__ __forceinline__ float rm_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// PredictionLayer + loss of ONE example (layers.py:796-808, utils.py:192-198): z = summed branch
+// logits, t = label.  task 0: p = sigmoid(z), Keras binary_crossentropy on the probability (clip to
+// [1e-7, 1 - 1e-7], epsilon inside the logs), gradient only inside the clip; task 1: MSE.
+// Returns the example's loss term; *pred and *dz (dLoss_term/dz, NOT yet divided by B).
+__device__ __forceinline__ float rm_loss_point(float z, float t, int task, float *pred, float *dz) {
+  constexpr float kEps = 1e-7f;  // Keras backend epsilon()
+  if (task == 0) {
+    const float p = 1.0f / (1.0f + expf(-z));
+    *pred = p;
+    const float lo = kEps, hi = 1.0f - kEps;
+    const float pc = fminf(fmaxf(p, lo), hi);
+    const float a = pc + kEps, c = 1.0f - pc + kEps;
+    const bool inside = p >= lo && p <= hi;  // clip passes the gradient only inside
+    const float dp = inside ? -(t / a - (1.0f - t) / c) : 0.f;
+    *dz = dp * p * (1.0f - p);
+    return -(t * logf(a) + (1.0f - t) * logf(c));
+  }
+  *pred = z;
+  const float e = z - t;
+  *dz = 2.0f * e;
+  return e * e;
+}
 // sum within aligned groups of G lanes (G power of two <= 64)
 template <int G>
 __device__ __forceinline__ float rm_group_sum(float v) {

@@ -140,9 +140,12 @@ class MLP:
             torch.nn.functional.leaky_relu_(h, 0.2)
         return h
 
-    def forward(self, xe, xd, keep=None, masks=None):
+    def forward(self, xe, xd, keep=None, masks=None, head=None):
         """xe [B,FD], xd [B,Dn] or None -> logit [B] (a view of an internal buffer).
-        keep/masks: DNN dropout keep-probabilities and 0/1 masks (layers.py:589,602)."""
+        keep/masks: DNN dropout keep-probabilities and 0/1 masks (layers.py:589,602).
+        head: keyword arguments of ops.mlp_tail (minus dh) - when the fused kernel runs, the final
+        logit, prediction, loss and dLoss/dlogit are produced in its epilogue together with the dh
+        chain (self.head_done tells the caller; otherwise it runs rm_logit_loss as usual)."""
         B = xe.shape[0]
         self._alloc(B, xe.device)
         p, pre = self.p, self.prefix
@@ -152,11 +155,15 @@ class MLP:
         self.xe, self.xd = xe, xd
         dropping = any(k < 1 and mk is not None for k, mk in zip(self.keep, self.masks))
         self.fused = self.fused_ok and not dropping
+        self.head_done, self.tail = False, None
         if self.fused:
+            if head is not None:
+                self.tail = ops.mlp_tail(B, dh=self.dhb, **head)
+                self.head_done = True
             ops.mlp_fwd(xe, xd if self.Dn else None,
                         [p[f"{pre}dnn_layer_{i}_weights"] for i in range(n)],
                         [p[f"{pre}dnn_layer_{i}_bias"] for i in range(n)], p[f"{pre}dnn_w"].view(-1),
-                        p[f"{pre}dnn_w0"], self.act, self.hb, self.out.view(B))
+                        p[f"{pre}dnn_w0"], self.act, self.hb, self.out.view(B), tail=self.tail)
             return self.out.view(B)
         if self.keep[0] < 1 and self.masks[0] is not None:
             m = self.masks[0] / self.keep[0]
@@ -207,7 +214,8 @@ class MLP:
                         db=[gr[f"{pre}dnn_layer_{i}_bias"] for i in range(n)],
                         d_w_out=gr[f"{pre}dnn_w"].view(-1), d_w0_out=gr[f"{pre}dnn_w0"],
                         d_xd_wsum=lin_grads[0] if (lin_grads and 1 <= self.Dn <= 32) else None,
-                        d_g_sum=lin_grads[1] if (lin_grads and 1 <= self.Dn <= 32) else None)
+                        d_g_sum=lin_grads[1] if (lin_grads and 1 <= self.Dn <= 32) else None,
+                        tail=self.tail if self.head_done else None)
             self.lin_done = bool(lin_grads and 1 <= self.Dn <= 32)
             return fm_sum is not None
         ops.linear_dense_bwd(g, self.a[-1], gr[f"{pre}dnn_w"].view(-1), gr[f"{pre}dnn_w0"], self._ws)
@@ -422,6 +430,7 @@ class Engine:
         self.pred = torch.empty(B, dtype=F32, device=dev)
         self.dlogit = torch.empty(B, dtype=F32, device=dev)
         self.loss = torch.zeros(1, dtype=F32, device=dev)
+        self.loss_part = torch.empty((B + 31) // 32, dtype=F32, device=dev)  # fused head: per-tile loss sums
         self.ws = torch.empty(256 * 1024, dtype=F32, device=dev)
         self.mv_fields = [f for f, n in enumerate(self.spec.sparse_names) if n in self.spec.scratch_names]
         if self.mv_fields:
@@ -519,14 +528,24 @@ class Engine:
         B = idx.shape[0]
         self._alloc(B)
         self._mv = mv
-        branches = self._branches_fwd(idx, dense, True, masks, None)
         yk = dict(y=y) if y.dtype == I64 else dict(y_f=y)
-        ops.logit_loss(branches, task=self.task, logit=self.logit, pred=self.pred,
-                       dlogit=self.dlogit, loss=self.loss, workspace=self.ws, **yk)
-        if getattr(self, "grad_scale", 1.0) != 1.0:
-            # this batch is one of several micro-batches of a step: its gradients are its share
-            # of the full-batch mean (recman_amd/dist.py)
-            self.dlogit.mul_(self.grad_scale)
+        scale = getattr(self, "grad_scale", 1.0)
+        # models whose DNN is the last branch of the forward offer it the fused head (rm_mlp_tail):
+        # final logit, prediction, loss and dLoss/dlogit in the MLP kernel's epilogue
+        self._head_req = dict(task=self.task, grad_scale=scale, logit=self.logit, pred=self.pred,
+                              dlogit=self.dlogit, loss_partial=self.loss_part, loss=self.loss, **yk)
+        self._head_done = False
+        try:
+            branches = self._branches_fwd(idx, dense, True, masks, None)
+        finally:
+            self._head_req = None
+        if not self._head_done:
+            ops.logit_loss(branches, task=self.task, logit=self.logit, pred=self.pred,
+                           dlogit=self.dlogit, loss=self.loss, workspace=self.ws, **yk)
+            if scale != 1.0:
+                # this batch is one of several micro-batches of a step: its gradients are its share
+                # of the full-batch mean (recman_amd/dist.py)
+                self.dlogit.mul_(scale)
         self._lin_done = False
         self._branches_bwd(idx, dense, self.dlogit, masks)
         if self.use_linear and not self._lin_done:
@@ -534,6 +553,18 @@ class Engine:
                                  self.grads["linear_w_dense"] if self.Dn else None,
                                  self.grads["linear_w0"], self.ws)
         return self._add_l2(self.loss)
+
+    fuse_head = True  # tests switch it off to compare against rm_logit_loss + the chain kernel
+
+    def _mlp_last(self, mlp, xe, xd, keep, masks, others):
+        """The DNN as the LAST branch of the forward: `others` = the (logit, coefficient) pairs
+        already computed.  Hands the fused head to the MLP when fwd_bwd asked for it and at most two
+        other branches exist; returns the DNN logit."""
+        req = getattr(self, "_head_req", None) if self.fuse_head else None
+        head = dict(req, branches=others, coef_mlp=1.0) if (req is not None and len(others) <= 2) else None
+        out = mlp.forward(xe, xd, keep, masks, head=head)
+        self._head_done = bool(head is not None and mlp.head_done)
+        return out
 
     def _lin_grads(self):
         """(d linear_w_dense, d linear_w0) for MLP.backward to fill when the linear term is on."""
@@ -698,8 +729,8 @@ class DeepFMEngine(Engine):
         if self.use_deep:
             n = len(hp["deep_hidden_units"])
             keep = list(hp.get("deep_dropout", [1] * (n + 1))) if training else [1] * (n + 1)
-            self.dnn_logit = self.mlp.forward(self.E.view(-1, self.FD), dense if self.Dn else None,
-                                              keep, m.get("dnn"))
+            self.dnn_logit = self._mlp_last(self.mlp, self.E.view(-1, self.FD), dense if self.Dn else None,
+                                            keep, m.get("dnn"), list(branches))
             branches.append((self.dnn_logit, 1.0))
         return branches
 
@@ -995,8 +1026,8 @@ class XDeepFMEngine(Engine):
         self._cin_fwd(ck if ck and any(k < 1 for k in ck) else None, m.get("cin"))
         n = len(hp["deep_hidden_units"])
         keep = list(hp.get("deep_dropout", [1] * (n + 1))) if training else [1] * (n + 1)
-        self.dnn_logit = self.mlp.forward(self.E.view(-1, self.FD), dense if self.Dn else None, keep,
-                                          m.get("dnn"))
+        self.dnn_logit = self._mlp_last(self.mlp, self.E.view(-1, self.FD), dense if self.Dn else None, keep,
+                                        m.get("dnn"), [(self.lin_logit, 1.0), (self.cin_logit, 1.0)])
         return [(self.lin_logit, 1.0), (self.cin_logit, 1.0), (self.dnn_logit, 1.0)]
 
     def _branches_bwd(self, idx, dense, g, masks):

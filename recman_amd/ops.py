@@ -254,8 +254,46 @@ def mlp_bwd_workspace(FD, Dn):
     return int(_lib.lib().rm_mlp_bwd_workspace(FD, Dn))
 
 
-def mlp_fwd(xe, xd, Ws, bs, w_out, w0_out, act, h_out, logit):
-    """Fused skinny-MLP forward.  Ws[l] / bs[l]: layer weights; h_out[l] [B,32]."""
+def mlp_tail(B, branches, coef_mlp, *, y=None, y_f=None, task="classification", grad_scale=1.0,
+             logit=None, pred=None, dlogit, loss_partial, loss=None, dh):
+    """Builds the rm_mlp_tail struct of the fused training head (see include/recman_hip.h):
+    branches = up to two (tensor [B], coefficient) pairs summed BEFORE the MLP's own logit.
+    Returns the struct; pass it to mlp_fwd and then to mlp_bwd (the tensors must stay alive)."""
+    if len(branches) > 2:
+        raise ValueError("mlp_tail takes at most two other branch logits")
+    if (y is None) == (y_f is None):
+        raise ValueError("mlp_tail needs exactly one of y / y_f")
+    if loss_partial.numel() < (B + 31) // 32:
+        raise ValueError("mlp_tail: loss_partial needs ceil(B/32) floats")
+    t = _lib.MlpTail()
+    for name, i in (("a", 0), ("b", 1)):
+        if i < len(branches):
+            setattr(t, f"logit_{name}", _chk(branches[i][0], f"logit_{name}", F32, (B,)))
+            setattr(t, f"coef_{name}", float(branches[i][1]))
+    t.coef_mlp = float(coef_mlp)
+    t.y = _chk(y, "y", I64, (B,), allow_none=True)
+    t.y_f = _chk(y_f, "y_f", F32, (B,), allow_none=True)
+    t.task = 0 if task == "classification" else 1
+    t.grad_scale = float(grad_scale)
+    t.logit = _chk(logit, "logit", F32, (B,), allow_none=True)
+    t.pred = _chk(pred, "pred", F32, (B,), allow_none=True)
+    t.dlogit = _chk(dlogit, "dlogit", F32, (B,))
+    t.loss_partial = _chk(loss_partial, "loss_partial", F32)
+    t.loss = _chk(loss, "loss", F32, (1,), allow_none=True)
+    for l, d in enumerate(dh):
+        t.dh[l] = _chk(d, f"dh[{l}]", F32, (B, 32))
+    return t
+
+
+def _tail_ref(tail):
+    import ctypes
+
+    return None if tail is None else ctypes.cast(ctypes.pointer(tail), ctypes.c_void_p)
+
+
+def mlp_fwd(xe, xd, Ws, bs, w_out, w0_out, act, h_out, logit, tail=None):
+    """Fused skinny-MLP forward.  Ws[l] / bs[l]: layer weights; h_out[l] [B,32].
+    tail (mlp_tail(...)): also the final logit, prediction, loss terms, dLoss/dlogit and the dh chain."""
     B, FD = xe.shape
     Dn = 0 if xd is None else xd.shape[1]
     H = [W.shape[1] for W in Ws]
@@ -266,11 +304,13 @@ def mlp_fwd(xe, xd, Ws, bs, w_out, w0_out, act, h_out, logit):
     _lib.call("rm_mlp_fwd", _chk(xe, "xe", F32), _chk(xd, "xd", F32, (B, Dn), allow_none=True), FD,
               Dn, len(Ws), _int_array(H), _ptr_array(Ws), _ptr_array(bs),
               _chk(w_out, "w_out", F32, (H[-1],)), _chk(w0_out, "w0_out", F32, (1,)), ACT_IDS[act], B,
-              _ptr_array(h_out), _chk(logit, "logit", F32, (B,)), _stream())
+              _ptr_array(h_out), _chk(logit, "logit", F32, (B,)), _tail_ref(tail), _stream())
 
 
 def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None, db=None,
-            d_w_out=None, d_w0_out=None, d_xd_wsum=None, d_g_sum=None):
+            d_w_out=None, d_w0_out=None, d_xd_wsum=None, d_g_sum=None, tail=None):
+    """tail: the struct the forward ran with - dh is already there (no chain launch) and the
+    finishing kernel also reduces the loss."""
     B, FD = xe.shape
     Dn = 0 if xd is None else xd.shape[1]
     H = [W.shape[1] for W in Ws]
@@ -291,7 +331,7 @@ def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None
               _chk(d_w0_out, "d_w0_out", F32, (1,), allow_none=True),
               _chk(d_xd_wsum, "d_xd_wsum", F32, (Dn,), allow_none=True),
               _chk(d_g_sum, "d_g_sum", F32, (1,), allow_none=True),
-              _chk(workspace, "workspace", F32), _stream())
+              _chk(workspace, "workspace", F32), _tail_ref(tail), _stream())
 
 
 def shard_route(idx, field_off, world, pos, send_ids, counts, workspace):

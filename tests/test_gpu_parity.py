@@ -444,3 +444,43 @@ def test_cin_dropout_masks_injected(hip_lib, keep):
     logit_i, _ = e.forward(idx.cuda(), dense.cuda(), training=False)
     want = T.xdeepfm_logit(p, spec, idx, dense, hp, training=False).reshape(-1)
     _close(logit_i, want, rtol=0, atol=1e-5, what="inference logit")
+
+
+@pytest.mark.parametrize("model,kw,task,B,scale", [
+    ("deepfm", {}, "classification", 37, 1.0),
+    ("deepfm", dict(hp_extra=dict(use_fm=False)), "classification", 64, 0.25),
+    ("deepfm", {}, "regression", 33, 1.0),
+    ("xdeepfm", dict(cin_units=(16, 8), scale=0.2), "classification", 45, 0.5),
+    ("deepfm", dict(hidden=(24,)), "classification", 31, 1.0),
+    ("deepfm", dict(hidden=(32, 16, 8)), "classification", 70, 1.0),
+])
+def test_fused_mlp_head_equals_logit_loss_and_chain_kernels(hip_lib, model, kw, task, B, scale):
+    """rm_mlp_tail (final logit, prediction, loss, dLoss/dlogit and the dh chain in the MLP forward's
+    epilogue) against the unfused sequence rm_logit_loss -> mlp_dh_chain_kernel on the same engine:
+    same arithmetic in the same order, so everything but the loss (another summation order) is
+    bit-identical."""
+    from recman_amd import engine as eng
+
+    spec, p, idx, dense, y, hp = make_case(model, B=B, D=8, **kw)
+    yy = torch.randn(B) if task == "regression" else y
+    espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names)
+    res = []
+    for fuse in (False, True):
+        e = eng.ENGINES[model](espec, 8, hp, task=task)
+        e.load_params({k: v for k, v in p.items() if k in e.params or k == "linear_w"})
+        e.fuse_head = fuse
+        e.grad_scale = scale
+        loss = e.fwd_bwd(idx.cuda(), dense.cuda(), yy.cuda())
+        torch.cuda.synchronize()
+        assert e._head_done == fuse
+        res.append((loss.clone(), e.logit.clone(), e.pred.clone(), e.dlogit.clone(),
+                    [d.clone() for d in e.mlp.dhb], e.d_rows.clone(),
+                    {k: v.clone() for k, v in e.grads.items()}))
+    a, b = res
+    _close(b[0], a[0], rtol=1e-6, atol=1e-7, what="loss")
+    for i, what in ((1, "logit"), (2, "pred"), (3, "dlogit"), (5, "d_rows")):
+        assert torch.equal(a[i], b[i]), what
+    for l, (x, z) in enumerate(zip(a[4], b[4])):
+        assert torch.equal(x[:B], z[:B]), f"dh[{l}]"
+    for k in a[6]:
+        assert torch.equal(a[6][k], b[6][k]), k
