@@ -1014,7 +1014,7 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     const float *xdp = d_xd_wsum ? xd : nullptr;
     const float *h1p = NL > 1 ? h[1] : nullptr, *h2p = NL > 2 ? h[2] : nullptr;
     const float *d1p = NL > 1 ? dh[1] : nullptr, *d2p = NL > 2 ? dh[2] : nullptr;
-    const int sblk = 256;  // one 4-wave block per CU, one partial per block
+    const int sblk = (int)rm_grid_cap((ntiles + 3) / 4, 512);  // 4-wave blocks, one 32-example chunk per wave up to B = 65536; one partial per block
     if (NL == 1)
       hipLaunchKernelGGL((mlp_small_grads_mfma<1>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
                          dh[0], d1p, d2p, g, xdp, Dn, B, part2);
