@@ -200,6 +200,14 @@ int rm_act_bwd(float *da, const float *a, int64_t B, int N, int act, rm_stream_t
  * activation in one pass.  N % 4 == 0. */
 int rm_outer_actgrad(const float *g, const float *w, const float *a, int64_t B, int N, int act,
                      float *da, rm_stream_t stream);
+/* The same pass also reduces the columns of the two arrays it touches: d_w[j] = sum_b g[b] a[b,j]
+ * (gradient of dnn_w), d_w0 = sum_b g[b] (dnn_w0), db[j] = sum_b da[b,j] (bias of the last hidden
+ * layer) - three reads of a [B,N] array less.  a is required; d_w / d_w0 / db may be NULL;
+ * workspace: rm_outer_actgrad_sums_workspace(B, N) floats.  Deterministic. */
+int64_t rm_outer_actgrad_sums_workspace(int64_t B, int N);
+int rm_outer_actgrad_sums(const float *g, const float *w, const float *a, int64_t B, int N, int act,
+                          float *da, float *d_w, float *d_w0, float *db, float *workspace,
+                          rm_stream_t stream);
 
 /* out[b] = sum_j X[b,j]*w[j] + w0[0]: the [*,1] output projections (dnn_w/dnn_w0,
  * layers.py:606-609; cin_w/cin_w0, layers.py:757-760).  w0 may be NULL. */

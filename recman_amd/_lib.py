@@ -46,6 +46,7 @@ SIGNATURES = {
     "rm_bias_act": [P, P, I64, c_int, c_int, P],
     "rm_act_bwd": [P, P, I64, c_int, c_int, P],
     "rm_outer_actgrad": [P, P, P, I64, c_int, c_int, P, P],
+    "rm_outer_actgrad_sums": [P, P, P, I64, c_int, c_int, P, P, P, P, P, P],
     "rm_rowdot": [P, P, P, I64, c_int, P, P],
     "rm_cross_fwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P],
     "rm_cross_bwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P, P, P, P, P, P],
@@ -74,6 +75,7 @@ SIGNATURES_I64 = {
     "rm_cin_filter_workspace": [c_int, c_int, c_int],
     "rm_cin_bwd_workspace": [I64, c_int, c_int, c_int, c_int],
     "rm_mlp_bwd_workspace": [c_int, c_int],
+    "rm_outer_actgrad_sums_workspace": [I64, c_int],
     "rm_shard_route_workspace": [c_int],
     "rm_dense_filter_workspace": [c_int, c_int],
     "rm_dense_wgrad_workspace": [c_int, c_int, I64],

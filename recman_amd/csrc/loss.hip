@@ -163,6 +163,86 @@ extern "C" int rm_outer_actgrad(const float *g, const float *w, const float *a, 
   return RM_OK;
 }
 
+// rm_outer_actgrad + the three column reductions of the same two arrays in ONE pass:
+//   da[b,j] = g[b] w[j] act'(a[b,j]);  d_w[j] = sum_b g[b] a[b,j];  db[j] = sum_b da[b,j];  d_w0 = sum_b g[b].
+// A block owns rows_per_block rows, a thread a float4 column group (the layout of
+// colsum_w_wide_stage1): per-block partials [nblk][N+1] x 2, reduced by sums_stage2 in a fixed order.
+__global__ __launch_bounds__(kBlock) void outer_actgrad_sums_kernel(
+    const float *__restrict__ g, const float *__restrict__ w, const float *__restrict__ a, int64_t B,
+    int N, int act, int64_t rows_per_block, float *__restrict__ da, float *__restrict__ part_w,
+    float *__restrict__ part_b) {
+  const int N4 = N / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
+  float *ow = part_w + (int64_t)blockIdx.x * (N + 1);
+  float *ob = part_b + (int64_t)blockIdx.x * (N + 1);
+  for (int c4 = threadIdx.x; c4 < N4; c4 += kBlock) {
+    const float4 w4 = *reinterpret_cast<const float4 *>(w + 4 * c4);
+    float4 sw = make_float4(0.f, 0.f, 0.f, 0.f), sb = sw;
+#pragma unroll 4
+    for (int64_t r = r0; r < r1; ++r) {
+      const float gv = g[r];
+      const float4 o = *reinterpret_cast<const float4 *>(a + r * N + 4 * c4);
+      float4 d = make_float4(gv * w4.x, gv * w4.y, gv * w4.z, gv * w4.w);
+      d.x *= act_g(o.x, act); d.y *= act_g(o.y, act); d.z *= act_g(o.z, act); d.w *= act_g(o.w, act);
+      *reinterpret_cast<float4 *>(da + r * N + 4 * c4) = d;
+      sw.x += gv * o.x; sw.y += gv * o.y; sw.z += gv * o.z; sw.w += gv * o.w;
+      sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+    }
+    ow[4 * c4 + 0] = sw.x; ow[4 * c4 + 1] = sw.y; ow[4 * c4 + 2] = sw.z; ow[4 * c4 + 3] = sw.w;
+    ob[4 * c4 + 0] = sb.x; ob[4 * c4 + 1] = sb.y; ob[4 * c4 + 2] = sb.z; ob[4 * c4 + 3] = sb.w;
+  }
+  if (threadIdx.x == kBlock - 1) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += g[r];
+    ow[N] = s;
+  }
+}
+
+// column j of either partial array (blockIdx.y) summed over the blocks by one wave, fixed order
+__global__ void sums_stage2_kernel(const float *__restrict__ part_w, const float *__restrict__ part_b,
+                                   int nblk, int N, float *__restrict__ d_w, float *__restrict__ d_w0,
+                                   float *__restrict__ db) {
+  const int j = blockIdx.x;
+  const float *part = blockIdx.y == 0 ? part_w : part_b;
+  if (blockIdx.y == 1 && j == N) return;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 64) acc += part[(int64_t)i * (N + 1) + j];
+  acc = rm_wave_sum(acc);
+  if (threadIdx.x != 0) return;
+  if (blockIdx.y == 1) {
+    if (db) db[j] = acc;
+  } else if (j < N) {
+    if (d_w) d_w[j] = acc;
+  } else if (d_w0) {
+    d_w0[0] = acc;
+  }
+}
+
+static int outer_sums_blocks(int64_t B) { return rm_grid_cap((B + 63) / 64, 2048); }
+
+extern "C" int64_t rm_outer_actgrad_sums_workspace(int64_t B, int N) {
+  return 2 * (int64_t)outer_sums_blocks(B) * (N + 1);
+}
+
+extern "C" int rm_outer_actgrad_sums(const float *g, const float *w, const float *a, int64_t B, int N,
+                                     int act, float *da, float *d_w, float *d_w0, float *db,
+                                     float *workspace, rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && N > 0 && N % 4 == 0, "rm_outer_actgrad_sums: N must be a multiple of 4");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(g && w && a && da && workspace && rm_aligned16(da) && rm_aligned16(a) && rm_aligned16(w),
+             "rm_outer_actgrad_sums: NULL or unaligned");
+  const int nblk = outer_sums_blocks(B);
+  const int64_t rpb = (B + nblk - 1) / nblk;
+  float *pw = workspace, *pb = workspace + (int64_t)nblk * (N + 1);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(outer_actgrad_sums_kernel, dim3(nblk), dim3(kBlock), 0, st, g, w, a, B, N, act, rpb, da,
+                     pw, pb);
+  hipLaunchKernelGGL(sums_stage2_kernel, dim3(N + 1, 2), dim3(64), 0, st, pw, pb, nblk, N, d_w, d_w0, db);
+  RM_CHECK_LAUNCH("rm_outer_actgrad_sums");
+  return RM_OK;
+}
+
 extern "C" int rm_act_bwd(float *da, const float *a, int64_t B, int N, int act, rm_stream_t stream) {
   RM_REQUIRE(B >= 0 && N > 0 && (B * N) % 4 == 0, "rm_act_bwd: B*N must be a multiple of 4");
   if (B == 0) return RM_OK;

@@ -218,13 +218,26 @@ class MLP:
                         tail=self.tail if self.head_done else None)
             self.lin_done = bool(lin_grads and 1 <= self.Dn <= 32)
             return fm_sum is not None
-        ops.linear_dense_bwd(g, self.a[-1], gr[f"{pre}dnn_w"].view(-1), gr[f"{pre}dnn_w0"], self._ws)
         # d(pre-activation of the last layer) = (g w_out^T) o mask o act'(a): one elementwise pass
         # (rm_outer_actgrad; widths that are not a multiple of 4 take the K = 1 GEMM instead)
         da = self.da[-1]
         last_drop = self.keep[n] < 1 and self.masks[n] is not None
         plain = last_drop or self.act == "identity"
-        if da.shape[1] % 4 == 0:
+        # ... which, without dropout on that layer, also reduces the columns it reads and writes:
+        # d dnn_w = a^T g, d dnn_w0 = sum g and the last hidden layer's bias gradient
+        sums = (not plain) and da.shape[1] % 4 == 0 and da.shape[1] >= 64
+        if sums:
+            need = ops.outer_actgrad_sums_workspace(da.shape[0], da.shape[1])
+            if getattr(self, "_sums_ws", None) is None or self._sums_ws.numel() < need:
+                self._sums_ws = torch.empty(need, dtype=F32, device=da.device)
+            ops.outer_actgrad_sums(g, p[f"{pre}dnn_w"].view(-1), self.a[-1], self.act, da,
+                                   gr[f"{pre}dnn_w"].view(-1), gr[f"{pre}dnn_w0"],
+                                   gr[f"{pre}dnn_layer_{n - 1}_bias"], self._sums_ws)
+        else:
+            ops.linear_dense_bwd(g, self.a[-1], gr[f"{pre}dnn_w"].view(-1), gr[f"{pre}dnn_w0"], self._ws)
+        if sums:
+            pass
+        elif da.shape[1] % 4 == 0:
             ops.outer_actgrad(g, p[f"{pre}dnn_w"].view(-1), None if plain else self.a[-1], self.act, da)
         else:
             ops.dense_fwd(g.view(-1, 1), None, p[f"{pre}dnn_w"], da, self._fws, transposed=True,
@@ -238,7 +251,9 @@ class MLP:
         for i in range(n - 1, -1, -1):
             W = p[f"{pre}dnn_layer_{i}_weights"]
             gW = gr[f"{pre}dnn_layer_{i}_weights"]
-            if da.shape[1] <= 1023:
+            if sums and i == n - 1:
+                pass  # bias gradient already reduced by rm_outer_actgrad_sums
+            elif da.shape[1] <= 1023:
                 ops.linear_dense_bwd(self._ones, da, gr[f"{pre}dnn_layer_{i}_bias"], None, self._ws)
             else:
                 gr[f"{pre}dnn_layer_{i}_bias"].copy_(da.sum(0))

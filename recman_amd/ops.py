@@ -438,6 +438,21 @@ def outer_actgrad(g, w, a, act, da):
               _chk(a, "a", F32, (B, N), allow_none=True), B, N, ACT_IDS[act], _chk(da, "da", F32), _stream())
 
 
+def outer_actgrad_sums_workspace(B, N):
+    return int(_lib.lib().rm_outer_actgrad_sums_workspace(B, N))
+
+
+def outer_actgrad_sums(g, w, a, act, da, d_w, d_w0, db, workspace):
+    """outer_actgrad + d_w[j] = sum_b g[b] a[b,j], d_w0 = sum_b g[b], db[j] = sum_b da[b,j] in one pass."""
+    B, N = da.shape
+    if workspace.numel() < outer_actgrad_sums_workspace(B, N):
+        raise ValueError("outer_actgrad_sums: workspace too small")
+    _lib.call("rm_outer_actgrad_sums", _chk(g, "g", F32, (B,)), _chk(w, "w", F32, (N,)),
+              _chk(a, "a", F32, (B, N)), B, N, ACT_IDS[act], _chk(da, "da", F32),
+              _chk(d_w, "d_w", F32, (N,), allow_none=True), _chk(d_w0, "d_w0", F32, (1,), allow_none=True),
+              _chk(db, "db", F32, (N,), allow_none=True), _chk(workspace, "workspace", F32), _stream())
+
+
 def act_bwd_(da, a, act):
     B, N = da.shape
     _lib.call("rm_act_bwd", _chk(da, "da", F32), _chk(a, "a", F32, (B, N)), B, N, ACT_IDS[act], _stream())

@@ -161,3 +161,33 @@ def test_dense_argument_checks(hip_lib):
         ops.dense_fwd(a, None, W, out, ws, epilogue=ops.DENSE_CROSS)  # needs aux1/aux2
     with pytest.raises(RecmanHipError):
         ops.dense_fwd(a, None, W, out, ws, epilogue=ops.DENSE_MUL_ACTGRAD)  # needs aux1
+
+
+@pytest.mark.parametrize("B,N,act", [(1, 64, "relu"), (257, 400, "relu"), (5000, 128, "leaky_relu"),
+                                      (131, 68, "identity")])
+def test_outer_actgrad_sums(hip_lib, B, N, act):
+    """rm_outer_actgrad_sums: da = g w^T o act'(a) plus the three column reductions, against torch
+    in float64."""
+    from recman_amd import ops
+
+    gen = torch.Generator().manual_seed(B * 7 + N)
+    g = torch.randn(B, generator=gen)
+    w = torch.randn(N, generator=gen)
+    a = torch.randn(B, N, generator=gen)
+    if act == "relu":
+        a = a.clamp_min(0)
+    slope = {"relu": 0.0, "leaky_relu": 0.2, "identity": 1.0}[act]
+    fac = torch.where(a > 0, 1.0, slope) if act != "identity" else torch.ones_like(a)
+    want_da = (g.double()[:, None] * w.double()[None, :]) * fac.double()
+    gd, wd, ad = g.cuda(), w.cuda(), a.cuda()
+    da = torch.empty(B, N, device="cuda")
+    d_w, d_w0, db = torch.empty(N, device="cuda"), torch.empty(1, device="cuda"), torch.empty(N, device="cuda")
+    ws = torch.empty(ops.outer_actgrad_sums_workspace(B, N), device="cuda")
+    ops.outer_actgrad_sums(gd, wd, ad, act, da, d_w, d_w0, db, ws)
+    ref = torch.empty(B, N, device="cuda")
+    ops.outer_actgrad(gd, wd, ad, act, ref)
+    assert torch.equal(da, ref)
+    _close(da, want_da.float())
+    _close(d_w, (g.double()[:, None] * a.double()).sum(0).float())
+    _close(d_w0, g.double().sum().reshape(1).float())
+    _close(db, want_da.sum(0).float())

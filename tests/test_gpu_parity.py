@@ -86,6 +86,12 @@ def test_dcn_criteo_like_shape(hip_lib):
     _check_model("dcn", hip_lib, D=16, B=200, F=26, Dn=13, hidden=(40, 24), cross_layers=6, scale=0.03)
 
 
+def test_dcn_wide_hidden_layers_fused_last_layer_sums(hip_lib):
+    # last hidden width >= 64: the output projection's backward also reduces d dnn_w / d dnn_w0 / the
+    # last bias gradient (rm_outer_actgrad_sums)
+    _check_model("dcn", hip_lib, D=8, B=150, hidden=(72, 64), cross_layers=2, scale=0.1)
+
+
 def test_dcn_strict_reference_counts_dnn_twice_and_no_linear(hip_lib):
     _check_model("dcn", hip_lib, D=8, cross_layers=2, scale=0.15, hp_extra=dict(strict_reference=True))
     _check_model("dcn", hip_lib, D=8, cross_layers=2, scale=0.15, hp_extra=dict(use_linear=False))
