@@ -306,7 +306,9 @@ int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int x
  *                           (x_{l+1} = x0 o (W x_l + b) + x_l with aux1 = x0, aux2 = x_l)
  *   filter_ws: rm_dense_filter_workspace(K1+K2, N) floats (the weights re-laid for the kernel).
  * rm_dense_wgrad: dW[K1+K2, N] (+)= [A1 | A2]^T . G[M,N]  (reduction over the batch, split
- *   into slabs + a deterministic second-stage sum); workspace: rm_dense_wgrad_workspace floats. */
+ *   into slabs + a deterministic second-stage sum); db [N] (NULL ok) = the column sums of G, i.e. the
+ *   bias gradient of the same layer, from the G tiles the kernel stages anyway;
+ *   workspace: rm_dense_wgrad_workspace floats. */
 enum { RM_DENSE_BIAS_ACT = 0, RM_DENSE_MUL_ACTGRAD = 1, RM_DENSE_ADD = 2, RM_DENSE_CROSS = 3 };
 int64_t rm_dense_filter_workspace(int K, int N);
 int rm_dense_fwd(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2,
@@ -317,7 +319,8 @@ int rm_dense_fwd(const float *A1, int64_t lda1, int K1, const float *A2, int64_t
 int64_t rm_dense_wgrad_workspace(int K, int N, int64_t M);
 int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2,
                    const float *G, int64_t ldg, int N, int64_t M, float *dW, int64_t lddw,
-                   int accumulate, float *workspace, int64_t workspace_floats, rm_stream_t stream);
+                   int accumulate, float *db, float *workspace, int64_t workspace_floats,
+                   rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Multi-valued tag-list features (MultiValCsvFeat, inputs.py:380-425): the sqrtn-pooled

@@ -66,7 +66,7 @@ SIGNATURES = {
     "rm_permute_rows": [P, P, I64, c_int, c_int, P, P],
     "rm_dense_fwd": [P, I64, c_int, P, I64, c_int, P, I64, c_int, c_int, P, c_int, c_int, P, I64, P, I64,
                      I64, P, I64, P, I64, P, P],
-    "rm_dense_wgrad": [P, I64, c_int, P, I64, c_int, P, I64, c_int, I64, P, I64, c_int, P, I64, P],
+    "rm_dense_wgrad": [P, I64, c_int, P, I64, c_int, P, I64, c_int, I64, P, I64, c_int, P, P, I64, P],
 }
 
 

@@ -311,6 +311,7 @@ struct TNArgs {
   int a_vec;           // A1 rows are 16-byte aligned and K1 % 4 == 0
   int64_t slab_rows;   // multiple of TRC
   float *ws;           // [slabs][K][N]
+  float *db_ws;        // [slabs][N] column sums of G per slab (the bias gradient), or NULL
 };
 
 // TN: one block = 128 rows of K (4 row groups) x one column tile, one slab of the batch.  Per
@@ -433,8 +434,11 @@ __device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, i
     const bool rok = full || bl < rows_left;
     const uint32_t off = rok ? off0 : off0 - bl * (uint32_t)a.ldg;
     const float *Gp = a.G + r0 * a.ldg;
+    // (rows past the end of the batch: zero - A's zero rows already keep them out of dW, the
+    // column sums for db need G's own)
     if constexpr (FASTG) {
-      return *reinterpret_cast<const float4 *>(Gp + off);
+      const float4 v = *reinterpret_cast<const float4 *>(Gp + off);
+      return rok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       // per-element path (N % 4 != 0 or unaligned rows - typically a skinny G such as the 7
       // coefficient columns of the cross-net gradients): lanes whose columns lie past the tile
@@ -445,7 +449,7 @@ __device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, i
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[e] = Gp[off + ((4 * c4 + e < ncols) ? e : 0)];
       }
-      return make_float4(t[0], t[1], t[2], t[3]);
+      return rok ? make_float4(t[0], t[1], t[2], t[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
 #define RM_TN_PREFETCH(r0_, full_)                                                          \
@@ -474,6 +478,22 @@ __device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, i
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
   const bool rg_live = ka0 + 32 * rg < K;  // a row group past the end of K only helps staging
 
+  // db (optional): the column sums of G ride along in the K-tile-0 blocks - the G piece of every
+  // chunk is in LDS anyway, thread t adds up column t of it (a pass over G less than a separate
+  // bias-gradient kernel: 45 us at DCN's shape).  Block-uniform.
+  const bool do_db = a.db_ws != nullptr && kt == 0;
+  const int dbc = tid < kTileCols ? tid : 0;
+  float csum = 0.f;
+  auto colsum = [&]() {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int bl = 0; bl < TRC; bl += 2) {
+      s0 += Gs[bl * TLDG + dbc];
+      s1 += Gs[(bl + 1) * TLDG + dbc];
+    }
+    csum += s0 + s1;
+  };
+
   const int64_t nrows = b_end > b_begin ? b_end - b_begin : 0;
   const int64_t nfull = nrows / TRC;  // full chunks; a partial one may follow
   const bool partial = nrows % TRC != 0;
@@ -487,6 +507,7 @@ __device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, i
     const int64_t nx = ci + 1 < nfull ? ci + 1 : ci;
     RM_TN_PREFETCH(b_begin + nx * TRC, true)
     __builtin_amdgcn_sched_barrier(0);
+    if (do_db) colsum();
     if (rg_live) tn_compute<NT>(As, Gs, acc, c, h, rg, colb);
   }
   if (partial) {  // the batch's ragged end (last slab only): rows past the end staged as zeros
@@ -494,8 +515,10 @@ __device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, i
     __syncthreads();
     RM_TN_COMMIT()
     __syncthreads();
+    if (do_db) colsum();
     if (rg_live) tn_compute<NT>(As, Gs, acc, c, h, rg, colb);
   }
+  if (do_db && tid < ncols) a.db_ws[(int64_t)slab * a.N + col0 + tid] = csum;
   if (!rg_live) return;
   float *out = a.ws + (int64_t)slab * K * a.N;
 #pragma unroll
@@ -539,7 +562,8 @@ __global__ __launch_bounds__(kThreads, 1) void dense_tn_kernel(TNArgs a) {
 
 // dW[k][n] (+)= sum_slab ws[slab][k][n]
 __global__ void dense_tn_reduce(const float *__restrict__ ws, int slabs, int64_t KN, int N, float *dW,
-                                int64_t lddw, int accumulate) {
+                                int64_t lddw, int accumulate, const float *__restrict__ db_ws,
+                                float *__restrict__ db) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < KN;
        t += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -547,6 +571,14 @@ __global__ void dense_tn_reduce(const float *__restrict__ ws, int slabs, int64_t
     const int64_t k = t / N, n = t - k * N;
     float *d = dW + k * lddw + n;
     *d = accumulate ? *d + s : s;
+  }
+  if (db != nullptr) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N;
+         t += (int64_t)gridDim.x * blockDim.x) {
+      float s = 0.f;
+      for (int q = 0; q < slabs; ++q) s += db_ws[(int64_t)q * N + t];
+      db[t] = s;
+    }
   }
 }
 
@@ -623,13 +655,13 @@ extern "C" int64_t rm_dense_wgrad_workspace(int K, int N, int64_t M) {
   if (K <= 0 || N <= 0 || M <= 0) return 0;
   const int kts = (K + kRowsPerBlock - 1) / kRowsPerBlock;
   const int nct = ((N + 31) / 32 + kMaxNB - 1) / kMaxNB;
-  return (int64_t)tn_slabs(M, kts, nct) * K * N;
+  return (int64_t)tn_slabs(M, kts, nct) * ((int64_t)K * N + N);  // + the per-slab column sums (db)
 }
 
 extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2,
                               int K2, const float *G, int64_t ldg, int N, int64_t M, float *dW,
-                              int64_t lddw, int accumulate, float *workspace, int64_t workspace_floats,
-                              rm_stream_t stream) {
+                              int64_t lddw, int accumulate, float *db, float *workspace,
+                              int64_t workspace_floats, rm_stream_t stream) {
   RM_REQUIRE(M >= 0 && K1 > 0 && K2 >= 0 && N > 0, "rm_dense_wgrad: bad sizes");
   RM_REQUIRE(A1 && G && dW && workspace, "rm_dense_wgrad: NULL argument");
   RM_REQUIRE(K2 == 0 || A2, "rm_dense_wgrad: K2 > 0 needs A2");
@@ -656,7 +688,7 @@ extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float
     RM_REQUIRE(slab_rows * (ldg > lda1 ? ldg : lda1) < ((int64_t)1 << 30),
                "rm_dense_wgrad: rows too long for 32-bit slab offsets");
     TNArgs a{A1, A2, lda1, lda2, K1, K2, G, ldg, N, M, slabs, kts, kts_fast, (a_al && K1 % 4 == 0 && K1 >= 4) ? 1 : 0,
-             slab_rows, workspace};
+             slab_rows, workspace, db ? workspace + (int64_t)slabs * K * N : nullptr};
     const dim3 grid((unsigned)(slabs * kts), (unsigned)nct);
 #define RM_TN(P0, P1, FAST_)                                                                      \
   {                                                                                               \
@@ -684,7 +716,8 @@ extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float
   }
   const int64_t KN = (int64_t)K * N;
   hipLaunchKernelGGL(dense_tn_reduce, dim3(rm_grid_cap((KN + 255) / 256, 2048)), dim3(256), 0, st,
-                     workspace, slabs, KN, N, dW, lddw, accumulate);
+                     workspace, slabs, KN, N, dW, lddw, accumulate,
+                     db ? workspace + (int64_t)slabs * KN : nullptr, db);  // (no slabs: db = 0)
   RM_CHECK_LAUNCH("rm_dense_wgrad(reduce)");
   return RM_OK;
 }

@@ -251,21 +251,18 @@ class MLP:
         for i in range(n - 1, -1, -1):
             W = p[f"{pre}dnn_layer_{i}_weights"]
             gW = gr[f"{pre}dnn_layer_{i}_weights"]
-            if sums and i == n - 1:
-                pass  # bias gradient already reduced by rm_outer_actgrad_sums
-            elif da.shape[1] <= 1023:
-                ops.linear_dense_bwd(self._ones, da, gr[f"{pre}dnn_layer_{i}_bias"], None, self._ws)
-            else:
-                gr[f"{pre}dnn_layer_{i}_bias"].copy_(da.sum(0))
+            # the bias gradient colsum(da): from rm_outer_actgrad_sums for the last layer, otherwise
+            # it rides along in the weight-gradient kernel (which stages da in LDS anyway)
+            db = None if (sums and i == n - 1) else gr[f"{pre}dnn_layer_{i}_bias"]
             if i == 0:
-                ops.dense_wgrad(self.xe, self.xd if self.Dn else None, da, gW, self._wws)
+                ops.dense_wgrad(self.xe, self.xd if self.Dn else None, da, gW, self._wws, db=db)
                 # dLoss/dxe = da W[:FD]^T (the dense inputs need no gradient)
                 ops.dense_fwd(da, None, W[: self.FD], dxe, self._fws, transposed=True, epilogue=ops.DENSE_ADD)
                 if self.keep[0] < 1 and self.masks[0] is not None:
                     dxe.mul_(self.masks[0][:, : self.FD] / self.keep[0])
             else:
                 prev = self.a[i - 1]
-                ops.dense_wgrad(prev, None, da, gW, self._wws)
+                ops.dense_wgrad(prev, None, da, gW, self._wws, db=db)
                 dropped = self.keep[i] < 1 and self.masks[i] is not None
                 # d(pre-activation of layer i-1) = (da W^T) o mask o act'(prev), act' from the stored
                 # post-activation values (dropped positions are zeroed by the mask)

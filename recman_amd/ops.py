@@ -511,8 +511,8 @@ def dense_fwd(a1, a2, W, out, filter_ws, *, transposed=False, bias=None, epilogu
               M, pc, ldc, pc2, ldc2, _chk(filter_ws, "filter_ws", F32), _stream())
 
 
-def dense_wgrad(a1, a2, G, dW, ws, accumulate=False):
-    """dW[K,N] (+)= [a1 | a2].T @ G (rm_dense_wgrad)."""
+def dense_wgrad(a1, a2, G, dW, ws, accumulate=False, db=None):
+    """dW[K,N] (+)= [a1 | a2].T @ G (rm_dense_wgrad); db [N] = G.sum(0) when given."""
     p1, lda1, K1 = _rows2d(a1, "a1")
     p2, lda2, K2 = _rows2d(a2, "a2", allow_none=True)
     pg, ldg, N = _rows2d(G, "G")
@@ -523,4 +523,4 @@ def dense_wgrad(a1, a2, G, dW, ws, accumulate=False):
     if dW.shape[0] != K1 + K2 or nd != N:
         raise ValueError(f"dW {tuple(dW.shape)} must be [{K1 + K2},{N}]")
     _lib.call("rm_dense_wgrad", p1, lda1, K1, p2, lda2, K2, pg, ldg, N, M, pd, lddw, int(bool(accumulate)),
-              _chk(ws, "ws", F32), ws.numel(), _stream())
+              _chk(db, "db", F32, (N,), allow_none=True), _chk(ws, "ws", F32), ws.numel(), _stream())

@@ -124,6 +124,11 @@ def test_dense_wgrad(hip_lib, M, K1, K2, N):
     assert torch.equal(dW, first)  # deterministic
     ops.dense_wgrad(a1d, a2d, G.cuda(), dW, ws, accumulate=True)
     _close(dW, 2 * want, tol=3e-5, what="wgrad accumulate")
+    # db: the column sums of G (the layer's bias gradient) from the same launch
+    db = torch.full((N,), float("nan"), device="cuda")
+    ops.dense_wgrad(a1d, a2d, G.cuda(), dW, ws, db=db)
+    _close(dW, want, tol=3e-5, what="wgrad with db")
+    _close(db, G.double().sum(0), tol=3e-5, what="db")
 
 
 def test_dense_fwd_unaligned_rows_and_k1(hip_lib):
