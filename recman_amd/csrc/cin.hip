@@ -104,6 +104,9 @@ __global__ void cin_prep_fwd_kernel(const float *__restrict__ W, int m, int H, i
 // MT = 32-row M-tiles per wave; the block always covers 256 rows with 8/MT waves.
 // MT = 1 (8 waves, 2 per SIMD) lets one wave's s_waitcnt / barrier time be covered by its
 // SIMD partner: rocprofv3 showed 26 % of wave-cycles parked in waits at 1 wave per SIMD.
+#ifndef RM_CIN_EXP
+#define RM_CIN_EXP 0  // ablation builds only (profiles/): 1 = no per-chunk barrier in cin_fwd
+#endif
 template <int NT, int MT>
 __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
     const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride,
@@ -173,32 +176,46 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
     if constexpr (PF > 1) pf1 = *reinterpret_cast<const float4 *>(Wp + (int64_t)nx * WCH + pfi1 * 4);
     __builtin_amdgcn_sched_barrier(0);  // keep the loads here, ahead of the MFMA steps
     const float *Wb = Ws + (ch & 1) * WCH;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    // Operands one k-step ahead.  Left to itself hipcc issued every step's filter read right before
+    // its first MFMA (ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs): the whole LDS latency sat in
+    // front of every group of four MFMAs and the kernel ran at 67 % with or without its per-chunk
+    // barrier (ablation, profiles/r01_p11).  The sched_group_barriers pin the order
+    // [next step's 3 reads] [this step's product] [this step's 4 MFMAs].
+    auto read_step = [&](int sidx, float &x0v, float &xkv, float (&wv)[NT]) {
       const int irow = i_cur < m ? i_cur : m;
-      const float *x0p = X0s + irow * kRows + prow;
-      const float *xkp = Xks + (j_cur + h) * kRows + prow;
-      float av[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[mt] = x0p[32 * mt] * xkp[32 * mt];
-      float bv[NT];
-      const float *wp = Wb + (2 * s + h) * Np + c * NT;
+      x0v = X0s[irow * kRows + prow];
+      xkv = Xks[(j_cur + h) * kRows + prow];
+      const float *wp = Wb + (2 * sidx + h) * Np + c * NT;
       if constexpr (NT == 4) {
         const float4 t4 = *reinterpret_cast<const float4 *>(wp);
-        bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
+        wv[0] = t4.x; wv[1] = t4.y; wv[2] = t4.z; wv[3] = t4.w;
       } else if constexpr (NT == 2) {
         const float2 t2 = *reinterpret_cast<const float2 *>(wp);
-        bv[0] = t2.x; bv[1] = t2.y;
+        wv[0] = t2.x; wv[1] = t2.y;
       } else {
-        bv[0] = wp[0];
+        wv[0] = wp[0];
       }
+      j_cur += 2;  // (i, j) of the NEXT read
+      if (j_cur >= He) { ++i_cur; j_cur = sym ? (i_cur & ~1) : 0; }
+    };
+    static_assert(MT == 1, "the pipelined step loop is written for one M-tile per wave");
+    float x0c, xkc, x0n, xkn, wc[NT], wn[NT];
+    read_step(0, x0c, xkc, wc);
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // (the groups are filled in program order)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) read_step(s + 1, x0n, xkn, wn);
+      const float av = x0c * xkc;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wc[nt], acc[0][nt], 0, 0, 0);
+      if (s + 1 < 16) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS reads of step s + 1
+        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0); // MFMAs of step s
+        x0c = x0n; xkc = xkn;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-      j_cur += 2;
-      if (j_cur >= He) { ++i_cur; j_cur = sym ? (i_cur & ~1) : 0; }
+        for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
+      }
     }
     {
       // stores are unconditional wherever the chunk divides evenly over the threads: a store
@@ -210,7 +227,9 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
         if (kExact || tid + NTHR < NT * 256) *reinterpret_cast<float4 *>(Wn + (tid + NTHR) * 4) = pf1;
       }
     }
+#if !(RM_CIN_EXP & 1)
     __syncthreads();
+#endif
   }
 
   // ---- epilogue: bias + activation, [B,N,D] store, pooled sums through LDS ----
