@@ -203,6 +203,13 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
     for (int q = 0; q < AQ; ++q) acur[q] = *reinterpret_cast<const float4 *>(ap + 8 * q);
     float4 b0[2], b1[2];
     read_b(Wb, 0, b0[0], b1[0]);
+#if RM_GEMM_SGB
+    // the schedule groups are filled in PROGRAM order: this one takes the chunk's opening reads (A
+    // fragments + step 0's weights), so that inside the loop [reads of step s + 1] precede [MFMAs of
+    // step s].  Without the pinning hipcc issued every step's reads right before their MFMAs behind
+    // an s_waitcnt lgkmcnt (two exposed LDS latencies per k-step: profiles/r01_p11).
+    __builtin_amdgcn_sched_group_barrier(0x100, AQ + (NT > 4 ? 2 : 1), 0);
+#endif
 #pragma unroll
     for (int s = 0; s < KC / 2; ++s) {
       if (s + 1 < KC / 2) read_b(Wb, s + 1, b0[(s + 1) & 1], b1[(s + 1) & 1]);
@@ -214,10 +221,13 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
       for (int nt = 0; nt < NT; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt], acc[nt], 0, 0, 0);
 #if RM_GEMM_SGB
-      __builtin_amdgcn_sched_group_barrier(0x100, NT > 4 ? 2 : 1, 0);
+      if (s + 1 < KC / 2) __builtin_amdgcn_sched_group_barrier(0x100, NT > 4 ? 2 : 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
 #endif
     }
+#if RM_GEMM_SGB
+    __builtin_amdgcn_sched_barrier(0);  // the commit of the prefetch stays BEHIND the chunk's MFMAs
+#endif
     float *wdst = Ws + ((ch + 1) & 1) * WCH + tid * 4;
 #define RM_W(q) \
   if constexpr (q < WQ) *reinterpret_cast<float4 *>(wdst + q * kNNThreads * 4) = w##q
