@@ -994,12 +994,7 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
       hipLaunchKernelGGL((mlp_dh_chain_kernel<3>), cgrid, dim3(256), 0, st, w, w_out, act, B, g, h[0], h1p,
                          h2p, dh[0], d1p, d2p);
   }
-  // 2. dX (+ FM term) -> d_rows and the dW0 slabs, from x and dh0
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(nblk), dim3(512), smem, st, xe, xd, FD, Dn, W[0], H[0], B, g,
-                     (const float *)dh[0], fm_sum, D, d_rows, part, s_lds);
-  {
+  {  // 2. the small gradients
     SgOut o;
     for (int l = 0; l < kMaxNL; ++l) {
       o.dW[l] = (l >= 1 && l < NL) ? dW[l] : nullptr;
@@ -1024,6 +1019,13 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     else
       hipLaunchKernelGGL((mlp_small_grads_mfma<3>), dim3(sblk), dim3(256), 0, st, h[0], h1p, h2p,
                          dh[0], d1p, d2p, g, xdp, Dn, B, part2);
+    // 3. dX (+ FM term) -> d_rows and the dW0 slabs, from x and dh0.  (After the small gradients:
+    // those read h_l / dh_l, which the forward's epilogue wrote a moment ago - still in L2 / the
+    // Infinity Cache now, gone from them after this kernel's 220 MB.)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(nblk), dim3(512), smem, st, xe, xd, FD, Dn, W[0], H[0], B, g,
+                       (const float *)dh[0], fm_sum, D, d_rows, part, s_lds);
     const int n_dw0 = Kp * 32 / 64, n_sg = (kSgStride + 63) / 64;
     const bool with_loss = tail && tail->loss;
     hipLaunchKernelGGL(mlp_finish_kernel, dim3(n_dw0 + n_sg + (with_loss ? 1 : 0)), dim3(256), 0, st, part,
