@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prewarm", type=float, default=0.25,
+                    help="seconds of untimed steps BEFORE the W warmup steps (GPU clock ramp); 0 = none")
     ap.add_argument("--workload", default="deepfm", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (tests)")
     ap.add_argument("--vocab", type=int, default=0, help="override rows per field (tests)")
@@ -270,6 +272,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock ramp: a step takes 0.2 ms, so W warmup steps alone end before the GPU has left its idle
+    # clocks (50 timed steps measured 2.5 % slower than 1000).  Untimed, before the W warmup steps.
+    if a.prewarm > 0 and sharded:
+        # (a FIXED count with collectives inside: every rank must issue the same number of them)
+        for _ in range(100):
+            run()
+        torch.cuda.synchronize()
+    elif a.prewarm > 0:
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < a.prewarm:
+            for _ in range(20):
+                run()
+            torch.cuda.synchronize()
     for _ in range(a.warmup):
         run()
     barrier()
@@ -322,6 +337,7 @@ def main():
                    "indices": "uniform" if a.zipf == 0 else f"zipf({a.zipf})",
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
                    "host_enqueue_ms_per_step": round(enqueue / a.steps * 1e3, 4),
+                   "prewarm_s": a.prewarm,
                    "hipgraph": ("segments between the collectives" if segments else graph is not None),
                    "table": (f"row-sharded mod {world}, fused [D+4] rows, all_to_all over xGMI, "
                              + ("fixed-capacity exchange (equal splits, no host sync)" if fixed
