@@ -697,6 +697,19 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
 // dW0[k][u] = sum_slabs part[slab][k][u]   (k < K, u < H0).  A block owns 64 consecutive
 // slab elements; its 4 waves take every 4th slab (coalesced 256-byte reads), partial sums
 // meet in LDS in a fixed order -> deterministic.
+// The finishing reductions run 16 waves per block: a thread's chain of dependent-latency loads is
+// nslab / 16 long (with 4 waves the 512-partial small-gradient reduction alone took 9 us).
+constexpr int kFinG = 16;
+__device__ __forceinline__ float fin_tree(float (*sm)[64], int o) {
+  float v[kFinG];
+#pragma unroll
+  for (int q = 0; q < kFinG; ++q) v[q] = sm[q][o];
+#pragma unroll
+  for (int st = 1; st < kFinG; st *= 2)
+#pragma unroll
+    for (int q = 0; q < kFinG; q += 2 * st) v[q] += v[q + st];
+  return v[0];
+}
 __device__ __forceinline__ void mlp_dw0_reduce_body(float (*sm)[64], int blk,
                                                     const float *__restrict__ part, int nslab, int K,
                                                     int Kp, int H0, float *__restrict__ dW0) {
@@ -705,11 +718,11 @@ __device__ __forceinline__ void mlp_dw0_reduce_body(float (*sm)[64], int blk,
   const int64_t slab = (int64_t)Kp * 32;
   float acc = 0.f;
 #pragma unroll 8
-  for (int i = grp; i < nslab; i += 4) acc += part[(int64_t)i * slab + e];
+  for (int i = grp; i < nslab; i += kFinG) acc += part[(int64_t)i * slab + e];
   sm[grp][o] = acc;
   __syncthreads();
   if (grp == 0) {
-    const float v = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
+    const float v = fin_tree(sm, o);
     const int k = e >> 5, u = e & 31;
     if (k < K && u < H0) dW0[k * H0 + u] = v;
   }
@@ -816,12 +829,12 @@ __device__ __forceinline__ void mlp_small_grads_stage2_body(float (*sm)[64], int
   float acc = 0.f;
   if (src < kSgStride) {
 #pragma unroll 8
-    for (int i = grp; i < nblk; i += 4) acc += part[(int64_t)i * kSgStride + src];
+    for (int i = grp; i < nblk; i += kFinG) acc += part[(int64_t)i * kSgStride + src];
   }
   sm[grp][lane] = acc;
   __syncthreads();
   if (grp != 0 || src >= kSgStride) return;
-  acc = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+  acc = fin_tree(sm, lane);
   if (src >= kSgDense) {
     if (o.dxd && src - kSgDense < o.Dn) o.dxd[src - kSgDense] = acc;
   } else if (src < 2 * 1024) {
@@ -845,14 +858,14 @@ __device__ __forceinline__ void mlp_small_grads_stage2_body(float (*sm)[64], int
 // The two finishing reductions of the backward in ONE launch (each was a ~5 us launch of its own on
 // a 250 us step): blocks [0, n_dw0) finish dW0 from mlp_bwd's slabs, the rest finish the small
 // gradients from mlp_small_grads_mfma's per-block partials.
-__global__ __launch_bounds__(256) void mlp_finish_kernel(const float *__restrict__ part, int nslab, int K,
+__global__ __launch_bounds__(64 * kFinG) void mlp_finish_kernel(const float *__restrict__ part, int nslab, int K,
                                                          int Kp, int H0, float *__restrict__ dW0, int n_dw0,
                                                          const float *__restrict__ part2, int nblk2, int NL,
                                                          SgOut o, int n_sg,
                                                          const float *__restrict__ loss_partial,
                                                          int64_t n_loss, float invB,
                                                          float *__restrict__ loss) {
-  __shared__ float sm[4][64];
+  __shared__ float sm[kFinG][64];
   if ((int)blockIdx.x < n_dw0) {
     mlp_dw0_reduce_body(sm, blockIdx.x, part, nslab, K, Kp, H0, dW0);
   } else if ((int)blockIdx.x < n_dw0 + n_sg) {
@@ -860,11 +873,11 @@ __global__ __launch_bounds__(256) void mlp_finish_kernel(const float *__restrict
   } else {
     // the fused head's loss: mean over B of the per-tile sums, fixed order -> deterministic
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < n_loss; i += 256) acc += loss_partial[i];
+    for (int64_t i = threadIdx.x; i < n_loss; i += 64 * kFinG) acc += loss_partial[i];
     acc = rm_wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) sm[0][threadIdx.x >> 6] = acc;
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][0] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = ((sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3])) * invB;
+    if (threadIdx.x == 0) loss[0] = fin_tree(sm, 0) * invB;
   }
 }
 
@@ -1028,7 +1041,7 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
                        (const float *)dh[0], fm_sum, D, d_rows, part, s_lds);
     const int n_dw0 = Kp * 32 / 64, n_sg = (kSgStride + 63) / 64;
     const bool with_loss = tail && tail->loss;
-    hipLaunchKernelGGL(mlp_finish_kernel, dim3(n_dw0 + n_sg + (with_loss ? 1 : 0)), dim3(256), 0, st, part,
+    hipLaunchKernelGGL(mlp_finish_kernel, dim3(n_dw0 + n_sg + (with_loss ? 1 : 0)), dim3(64 * kFinG), 0, st, part,
                        nblk, K, Kp, H[0], dW[0], n_dw0, part2, sblk, NL, o, n_sg,
                        with_loss ? tail->loss_partial : nullptr, ntiles, 1.0f / (float)B,
                        with_loss ? tail->loss : nullptr);
