@@ -278,6 +278,16 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
     }
     const int64_t b = ex0 + c;
     const bool valid = b < B;
+    // TAIL: the head's per-example inputs are requested HERE, behind the main loop (its registers are
+    // free now; under it they cost the loop 3 VGPRs it did not have) and ahead of the layer
+    // epilogue, which covers most of their latency
+    float ta = 0.f, tb = 0.f, ty = 0.f;
+    if constexpr (TAIL) {
+      const int64_t bq = valid ? b : B - 1;
+      ta = tl.logit_a ? tl.logit_a[bq] : 0.f;
+      tb = tl.logit_b ? tl.logit_b[bq] : 0.f;
+      ty = tl.y ? (float)tl.y[bq] : tl.y_f[bq];
+    }
     float hv[16];
     float hl[TAIL ? NL : 1][16];  // TAIL: every layer's post-activation values, for the chain
 #pragma unroll
@@ -313,12 +323,11 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
     if constexpr (TAIL) {
       // ---- final logit, PredictionLayer, loss term, dLoss/dlogit (rm_logit_loss's arithmetic, same
       // order of the branch sum), then the dh chain; both lane halves compute the example's scalars
-      const int64_t bc = valid ? b : B - 1;
       float z = 0.f;
-      if (tl.logit_a) z += tl.coef_a * tl.logit_a[bc];
-      if (tl.logit_b) z += tl.coef_b * tl.logit_b[bc];
+      if (tl.logit_a) z += tl.coef_a * ta;
+      if (tl.logit_b) z += tl.coef_b * tb;
       z += tl.coef_mlp * dnn;
-      const float t = tl.y ? (float)tl.y[bc] : tl.y_f[bc];
+      const float t = ty;
       float p, dz;
       const float lt = rm_loss_point(z, t, tl.task, &p, &dz);
       float gb = dz * (1.0f / (float)B);
