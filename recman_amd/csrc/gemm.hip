@@ -592,6 +592,88 @@ __global__ void dense_tn_reduce(const float *__restrict__ ws, int slabs, int64_t
   }
 }
 
+// Skinny G (N <= 8: the cross-net's coefficient columns): dW[k][n] = sum_b x[b][k] G[b][n] is a
+// handful of weighted column sums of x - HBM-bound (x read once), not MFMA work: the tiled TN kernel
+// above padded N to 32 columns and spent its time in staging barriers (166 us at DCN's shape, 1.4 TB/s).
+// A block owns rows_per_block rows; G's rows of the block sit in LDS (every thread needs all N of a
+// row: broadcast reads); a thread owns one float4 column group of A1 or one column of A2 and keeps
+// its N x 4 partial sums in registers.  One partial [K][N] per block -> dense_tn_reduce.
+constexpr int kSkN = 8;       // max N of this path
+constexpr int kSkRows = 128;  // rows per block
+__global__ __launch_bounds__(128) void dense_tn_skinny_kernel(
+    const float *__restrict__ A1, int64_t lda1, int K1, const float *__restrict__ A2, int64_t lda2, int K2,
+    const float *__restrict__ G, int64_t ldg, int N, int64_t M, float *__restrict__ ws) {
+  __shared__ float Gs[kSkRows][kSkN];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * kSkRows;
+  const int nrows = (int)((M - r0) < kSkRows ? (M - r0) : kSkRows);
+  for (int t = tid; t < kSkRows * kSkN; t += 128) {
+    const int r = t / kSkN, n = t - r * kSkN;
+    Gs[r][n] = (r < nrows && n < N) ? G[(r0 + r) * ldg + n] : 0.f;
+  }
+  __syncthreads();
+  const int K = K1 + K2, K14 = K1 / 4;       // (host: K1 % 4 == 0 and 16-byte rows)
+  float *out = ws + (int64_t)blockIdx.x * K * N;
+  for (int item = tid; item < K14 + K2; item += 128) {
+    float acc[kSkN][4];
+#pragma unroll
+    for (int n = 0; n < kSkN; ++n)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[n][e] = 0.f;
+    if (item < K14) {
+      const float *ap = A1 + r0 * lda1 + 4 * item;
+#pragma unroll 4
+      for (int r = 0; r < nrows; ++r) {
+        const float4 x = *reinterpret_cast<const float4 *>(ap + (int64_t)r * lda1);
+        const float4 g0 = *reinterpret_cast<const float4 *>(&Gs[r][0]);
+        const float4 g1 = *reinterpret_cast<const float4 *>(&Gs[r][4]);
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int n = 0; n < kSkN; ++n) {
+          acc[n][0] += gv[n] * x.x; acc[n][1] += gv[n] * x.y;
+          acc[n][2] += gv[n] * x.z; acc[n][3] += gv[n] * x.w;
+        }
+      }
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[(int64_t)(4 * item + e) * N + n] = acc[n][e];
+    } else {
+      const int k2 = item - K14;
+      const float *ap = A2 + r0 * lda2 + k2;
+#pragma unroll 4
+      for (int r = 0; r < nrows; ++r) {
+        const float x = ap[(int64_t)r * lda2];
+        const float4 g0 = *reinterpret_cast<const float4 *>(&Gs[r][0]);
+        const float4 g1 = *reinterpret_cast<const float4 *>(&Gs[r][4]);
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int n = 0; n < kSkN; ++n) acc[n][0] += gv[n] * x;
+      }
+      for (int n = 0; n < N; ++n) out[(int64_t)(K1 + k2) * N + n] = acc[n][0];
+    }
+  }
+}
+
+// first reduction stage of the skinny path's many partials: out[y][t] = sum of `group` consecutive
+// partials (coalesced over t, a short fixed-order chain per thread); dense_tn_reduce finishes
+__global__ void dense_tn_fold_kernel(const float *__restrict__ in, int n_in, int group, int64_t KN,
+                                     float *__restrict__ out) {
+  const int y = blockIdx.y;
+  const int q0 = y * group, q1 = q0 + group < n_in ? q0 + group : n_in;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < KN;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int q = q0; q < q1; ++q) s += in[(int64_t)q * KN + t];
+    out[(int64_t)y * KN + t] = s;
+  }
+}
+
+constexpr int kSkFold = 32;  // partials per first-stage group
+bool tn_skinny_ok(int K1, int N) { return N <= kSkN && K1 % 4 == 0; }
+int64_t tn_skinny_blocks(int64_t M) { return (M + kSkRows - 1) / kSkRows; }
+int64_t tn_skinny_groups(int64_t M) { return (tn_skinny_blocks(M) + kSkFold - 1) / kSkFold; }
+
 int tn_slabs(int64_t M, int kts, int ncts) {
   int64_t s = 256 / ((int64_t)kts * ncts);  // ONE round of blocks over the 256 CUs (1 block per CU)
   const int64_t cap = (M + 511) / 512;            // at least 512 batch rows per slab
@@ -665,7 +747,12 @@ extern "C" int64_t rm_dense_wgrad_workspace(int K, int N, int64_t M) {
   if (K <= 0 || N <= 0 || M <= 0) return 0;
   const int kts = (K + kRowsPerBlock - 1) / kRowsPerBlock;
   const int nct = ((N + 31) / 32 + kMaxNB - 1) / kMaxNB;
-  return (int64_t)tn_slabs(M, kts, nct) * ((int64_t)K * N + N);  // + the per-slab column sums (db)
+  int64_t need = (int64_t)tn_slabs(M, kts, nct) * ((int64_t)K * N + N);  // + the per-slab column sums (db)
+  if (N <= kSkN) {  // the skinny path's one partial per 128 rows (whichever path the call takes)
+    const int64_t sk = (tn_skinny_blocks(M) + tn_skinny_groups(M)) * (int64_t)K * N;
+    need = sk > need ? sk : need;
+  }
+  return need;
 }
 
 extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2,
@@ -681,6 +768,21 @@ extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float
   RM_REQUIRE(workspace_floats >= rm_dense_wgrad_workspace(K, N, M > 0 ? M : 1),
              "rm_dense_wgrad: workspace too small");
   hipStream_t st = (hipStream_t)stream;
+  if (M > 0 && !db && tn_skinny_ok(K1, N) && lda1 % 4 == 0 && rm_aligned16(A1)) {
+    const int nblk = (int)tn_skinny_blocks(M);
+    hipLaunchKernelGGL(dense_tn_skinny_kernel, dim3(nblk), dim3(128), 0, st, A1, lda1, K1, A2, lda2, K2, G, ldg,
+                       N, M, workspace);
+    RM_CHECK_LAUNCH("rm_dense_wgrad(skinny)");
+    const int64_t KNs = (int64_t)K * N;
+    const int ngrp = (int)tn_skinny_groups(M);
+    float *ws2 = workspace + (int64_t)nblk * KNs;
+    hipLaunchKernelGGL(dense_tn_fold_kernel, dim3((unsigned)rm_grid_cap((KNs + 255) / 256, 64), (unsigned)ngrp),
+                       dim3(256), 0, st, workspace, nblk, kSkFold, KNs, ws2);
+    hipLaunchKernelGGL(dense_tn_reduce, dim3(rm_grid_cap((KNs + 255) / 256, 2048)), dim3(256), 0, st, ws2,
+                       ngrp, KNs, N, dW, lddw, accumulate, (const float *)nullptr, (float *)nullptr);
+    RM_CHECK_LAUNCH("rm_dense_wgrad(reduce)");
+    return RM_OK;
+  }
   const int kts = (K + kRowsPerBlock - 1) / kRowsPerBlock;
   const int nbt = (N + 31) / 32;
   const int nct = (nbt + kMaxNB - 1) / kMaxNB;

@@ -104,7 +104,10 @@ def test_dense_fwd_other_epilogues(hip_lib, M, K1, K2, N):
     assert float(outp[:, N:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,K1,K2,N", SHAPES + [(5000, 416, 13, 400), (3, 8, 0, 8)])
+@pytest.mark.parametrize("M,K1,K2,N", SHAPES + [(5000, 416, 13, 400), (3, 8, 0, 8),
+                                                # skinny G (N <= 8): the weighted-column-sum path
+                                                (5000, 416, 13, 7), (129, 32, 0, 1), (4100, 64, 3, 8),
+                                                (300, 30, 2, 5)])   # K1 % 4 != 0: tiled path
 def test_dense_wgrad(hip_lib, M, K1, K2, N):
     from recman_amd import ops
 
