@@ -1,10 +1,11 @@
 """Micro-benchmark of the wide dense-layer kernels at DCN's shapes (run under rocprofv3
 --kernel-trace --stats; the kernel durations are the measurement, not the host loop)."""
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recman_amd import ops  # noqa: E402
 
 B, FD, Dn, H = 131072, 416, 13, 400
