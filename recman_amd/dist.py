@@ -352,6 +352,12 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
         sharded = True
 
         def __init__(self):
+            if spec.scratch_names:
+                # their pooled rows are built from table rows that live on other ranks: the tags
+                # would have to travel as an expanded occurrence list ("Next")
+                raise NotImplementedError(
+                    f"row-sharded table: multi-valued / value features {sorted(spec.scratch_names)} "
+                    "are not supported yet (single-GPU engines handle them)")
             self._shard_args = (rank, world, group)
             self._pending = None
             self._slot = None
