@@ -248,9 +248,16 @@ def main():
                 for _ in range(2):
                     step()
             torch.cuda.current_stream().wait_stream(side)
+            import gc
+
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
+            gc.collect()
+            gc.disable()  # (a collection inside the capture could free device memory: unsafe there)
+            try:
+                with torch.cuda.graph(graph):
+                    step()
+            finally:
+                gc.enable()
         except Exception as e:  # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture failed, running eager: {e}", file=sys.stderr)
             graph = None

@@ -562,16 +562,29 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             self._seg_bodies = (route, gather, compute)
             self._run_segments(eager=True)
             torch.cuda.synchronize()
+            import gc
+
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for c, s in enumerate(segs):
-                    s.graphs = []
-                    for body in (route, gather, compute):
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, stream=side):
-                            body(s, c)
-                        s.graphs.append(g)
+            # no cyclic garbage collection while a capture is open: the collector may free an OLDER
+            # engine's graphs (they sit in reference cycles with the closures above), and releasing a
+            # graph's memory pool is an unsafe call under torch's global capture mode - it aborted the
+            # process when it happened (tests/test_gpu_dist.py run after other segment tests)
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.stream(side):
+                    for c, s in enumerate(segs):
+                        s.graphs = []
+                        for body in (route, gather, compute):
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g, stream=side):
+                                body(s, c)
+                            s.graphs.append(g)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
 
