@@ -789,24 +789,46 @@ size_t cin_dw_smem(int m, int H, int NT) {
 
 // dW[(i*H+j)][n] = sum_s part[s][k'(i,j)][n]; in the symmetric ordering (i,j) and (j,i) read the
 // same k' (dLoss/dW[i][j] = dLoss/dW[j][i] = dLoss/dW'[min][max])
-__global__ void cin_dw_reduce_kernel(const float *__restrict__ part, DwPlan plan, int m, int H, int N,
-                                     int Np, int sym, float *__restrict__ dW) {
+// 16 waves per block: 64 consecutive outputs, wave w adds up every 16th slab (a thread's chain of
+// loads is S / 16 long instead of S), fixed-order tree in LDS -> deterministic
+constexpr int kDwrG = 16;
+__global__ __launch_bounds__(64 * kDwrG) void cin_dw_reduce_kernel(const float *__restrict__ part, DwPlan plan,
+                                                                   int m, int H, int N, int Np, int sym,
+                                                                   float *__restrict__ dW) {
+  __shared__ float sm[kDwrG][64];
   const int He = cin_He(H), Kp = sym ? cin_Kp_sym(m, H) : cin_Kp(m, H);
   const int total = m * H * N;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-    const int k = t / N, n = t - k * N;
-    const int i = k / H, j = k - i * H;
-    int kp;
-    if (sym) {
-      const int lo = i < j ? i : j, hi = i < j ? j : i;
-      kp = cin_sym_start(He, lo) + (hi - (lo & ~1));
-    } else {
-      kp = i * He + j;
-    }
-    const int S = plan.S[(kp / 32) / (kDWW * kKT)];
+  const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (int t0 = blockIdx.x * 64; t0 < total; t0 += gridDim.x * 64) {
+    const int t = t0 + o;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += part[((int64_t)s * Kp + kp) * Np + n];
-    dW[t] = acc;
+    if (t < total) {
+      const int k = t / N, n = t - k * N;
+      const int i = k / H, j = k - i * H;
+      int kp;
+      if (sym) {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        kp = cin_sym_start(He, lo) + (hi - (lo & ~1));
+      } else {
+        kp = i * He + j;
+      }
+      const int S = plan.S[(kp / 32) / (kDWW * kKT)];
+#pragma unroll 4
+      for (int s = grp; s < S; s += kDwrG) acc += part[((int64_t)s * Kp + kp) * Np + n];
+    }
+    sm[grp][o] = acc;
+    __syncthreads();
+    if (grp == 0 && t < total) {
+      float v[kDwrG];
+#pragma unroll
+      for (int q = 0; q < kDwrG; ++q) v[q] = sm[q][o];
+#pragma unroll
+      for (int st = 1; st < kDwrG; st *= 2)
+#pragma unroll
+        for (int q = 0; q < kDwrG; q += 2 * st) v[q] += v[q + st];
+      dW[t] = v[0];
+    }
+    __syncthreads();
   }
 }
 
@@ -970,7 +992,8 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
   }
     if (NT == 1) RM_CIN_DW(1) else if (NT == 2) RM_CIN_DW(2) else RM_CIN_DW(4)
 #undef RM_CIN_DW
-    hipLaunchKernelGGL(cin_dw_reduce_kernel, dim3(256), dim3(256), 0, st, part, plan, m, H, N, Np, sym, dW);
+    hipLaunchKernelGGL(cin_dw_reduce_kernel, dim3(rm_grid_cap(((int64_t)m * H * N + 63) / 64, 4096)),
+                       dim3(64 * kDwrG), 0, st, part, plan, m, H, N, Np, sym, dW);
   }
   RM_CHECK_LAUNCH("rm_cin_layer_bwd");
   return RM_OK;
