@@ -570,25 +570,45 @@ __global__ __launch_bounds__(kThreads, 1) void dense_tn_kernel(TNArgs a) {
   }
 }
 
-// dW[k][n] (+)= sum_slab ws[slab][k][n]
-__global__ void dense_tn_reduce(const float *__restrict__ ws, int slabs, int64_t KN, int N, float *dW,
-                                int64_t lddw, int accumulate, const float *__restrict__ db_ws,
-                                float *__restrict__ db) {
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < KN;
-       t += (int64_t)gridDim.x * blockDim.x) {
+// dW[k][n] (+)= sum_slab ws[slab][k][n].  A block owns 64 consecutive outputs, its 8 waves take every
+// 8th slab (a thread's chain of loads is slabs / 8 long), fixed-order tree in LDS -> deterministic.
+constexpr int kTrG = 8;
+__global__ __launch_bounds__(64 * kTrG) void dense_tn_reduce(const float *__restrict__ ws, int slabs, int64_t KN,
+                                                            int N, float *dW, int64_t lddw, int accumulate,
+                                                            const float *__restrict__ db_ws,
+                                                            float *__restrict__ db) {
+  __shared__ float sm[kTrG][64];
+  const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t total = KN + (db != nullptr ? N : 0);  // the db columns ride behind the dW elements
+  for (int64_t t0 = (int64_t)blockIdx.x * 64; t0 < total; t0 += (int64_t)gridDim.x * 64) {
+    const int64_t t = t0 + o;
     float s = 0.f;
-    for (int q = 0; q < slabs; ++q) s += ws[(int64_t)q * KN + t];
-    const int64_t k = t / N, n = t - k * N;
-    float *d = dW + k * lddw + n;
-    *d = accumulate ? *d + s : s;
-  }
-  if (db != nullptr) {
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N;
-         t += (int64_t)gridDim.x * blockDim.x) {
-      float s = 0.f;
-      for (int q = 0; q < slabs; ++q) s += db_ws[(int64_t)q * N + t];
-      db[t] = s;
+    if (t < KN) {
+#pragma unroll 4
+      for (int q = grp; q < slabs; q += kTrG) s += ws[(int64_t)q * KN + t];
+    } else if (t < total) {
+#pragma unroll 4
+      for (int q = grp; q < slabs; q += kTrG) s += db_ws[(int64_t)q * N + (t - KN)];
     }
+    sm[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && t < total) {
+      float v[kTrG];
+#pragma unroll
+      for (int q = 0; q < kTrG; ++q) v[q] = sm[q][o];
+#pragma unroll
+      for (int st = 1; st < kTrG; st *= 2)
+#pragma unroll
+        for (int q = 0; q < kTrG; q += 2 * st) v[q] += v[q + st];
+      if (t < KN) {
+        const int64_t k = t / N, n = t - k * N;
+        float *d = dW + k * lddw + n;
+        *d = accumulate ? *d + v[0] : v[0];
+      } else {
+        db[t - KN] = v[0];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -778,7 +798,7 @@ extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float
     float *ws2 = workspace + (int64_t)nblk * KNs;
     hipLaunchKernelGGL(dense_tn_fold_kernel, dim3((unsigned)rm_grid_cap((KNs + 255) / 256, 64), (unsigned)ngrp),
                        dim3(256), 0, st, workspace, nblk, kSkFold, KNs, ws2);
-    hipLaunchKernelGGL(dense_tn_reduce, dim3(rm_grid_cap((KNs + 255) / 256, 2048)), dim3(256), 0, st, ws2,
+    hipLaunchKernelGGL(dense_tn_reduce, dim3(rm_grid_cap((KNs + 63) / 64, 4096)), dim3(64 * kTrG), 0, st, ws2,
                        ngrp, KNs, N, dW, lddw, accumulate, (const float *)nullptr, (float *)nullptr);
     RM_CHECK_LAUNCH("rm_dense_wgrad(reduce)");
     return RM_OK;
@@ -827,7 +847,7 @@ extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float
     RM_CHECK_LAUNCH("rm_dense_wgrad");
   }
   const int64_t KN = (int64_t)K * N;
-  hipLaunchKernelGGL(dense_tn_reduce, dim3(rm_grid_cap((KN + 255) / 256, 2048)), dim3(256), 0, st,
+  hipLaunchKernelGGL(dense_tn_reduce, dim3(rm_grid_cap((KN + N + 63) / 64, 4096)), dim3(64 * kTrG), 0, st,
                      workspace, slabs, KN, N, dW, lddw, accumulate,
                      db ? workspace + (int64_t)slabs * KN : nullptr, db);  // (no slabs: db = 0)
   RM_CHECK_LAUNCH("rm_dense_wgrad(reduce)");

@@ -199,17 +199,23 @@ __global__ __launch_bounds__(kBlock) void outer_actgrad_sums_kernel(
   }
 }
 
-// column j of either partial array (blockIdx.y) summed over the blocks by one wave, fixed order
-__global__ void sums_stage2_kernel(const float *__restrict__ part_w, const float *__restrict__ part_b,
-                                   int nblk, int N, float *__restrict__ d_w, float *__restrict__ d_w0,
-                                   float *__restrict__ db) {
+// column j of either partial array (blockIdx.y) summed over the blocks by four waves, fixed order
+__global__ __launch_bounds__(256) void sums_stage2_kernel(const float *__restrict__ part_w,
+                                                          const float *__restrict__ part_b, int nblk, int N,
+                                                          float *__restrict__ d_w, float *__restrict__ d_w0,
+                                                          float *__restrict__ db) {
+  __shared__ float sm[4];
   const int j = blockIdx.x;
   const float *part = blockIdx.y == 0 ? part_w : part_b;
   if (blockIdx.y == 1 && j == N) return;
   float acc = 0.f;
-  for (int i = threadIdx.x; i < nblk; i += 64) acc += part[(int64_t)i * (N + 1) + j];
+#pragma unroll 4
+  for (int i = threadIdx.x; i < nblk; i += 256) acc += part[(int64_t)i * (N + 1) + j];
   acc = rm_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
   if (threadIdx.x != 0) return;
+  acc = (sm[0] + sm[1]) + (sm[2] + sm[3]);
   if (blockIdx.y == 1) {
     if (db) db[j] = acc;
   } else if (j < N) {
@@ -238,7 +244,7 @@ extern "C" int rm_outer_actgrad_sums(const float *g, const float *w, const float
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(outer_actgrad_sums_kernel, dim3(nblk), dim3(kBlock), 0, st, g, w, a, B, N, act, rpb, da,
                      pw, pb);
-  hipLaunchKernelGGL(sums_stage2_kernel, dim3(N + 1, 2), dim3(64), 0, st, pw, pb, nblk, N, d_w, d_w0, db);
+  hipLaunchKernelGGL(sums_stage2_kernel, dim3(N + 1, 2), dim3(256), 0, st, pw, pb, nblk, N, d_w, d_w0, db);
   RM_CHECK_LAUNCH("rm_outer_actgrad_sums");
   return RM_OK;
 }
