@@ -52,10 +52,6 @@ __device__ __forceinline__ float act_grad_from_out(float o, int act) {
   return 1.f;
 }
 
-__device__ __forceinline__ bool rm_aligned16_dev(const void *p) {
-  return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
-}
-
 struct ColTile {
   int nb, nt0;  // 32-col blocks in the tile; blocks of column group 0 (group 1 has nb - nt0)
 };

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kBlock) void route_count_kernel(
     }
   }
   __syncthreads();
-  if (threadIdx.x < W) cnt[threadIdx.x * gridDim.x + blockIdx.x] = sc[threadIdx.x];
+  if ((int)threadIdx.x < W) cnt[threadIdx.x * gridDim.x + blockIdx.x] = sc[threadIdx.x];
 }
 
 // exclusive scan over the w-major (w, block) grid; one block, sequential chunks
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void route_place_kernel(
   __shared__ int run[kMaxW];          // running offset of each bucket within this block
   __shared__ int wcnt[kBlock / 64][kMaxW];
   // cap > 0 (fixed-capacity layout): bucket w starts at w*cap instead of at the packed offset
-  if (threadIdx.x < W) {
+  if ((int)threadIdx.x < W) {
     const int w = threadIdx.x;
     int r = base[w * gridDim.x + blockIdx.x];
     if (cap > 0) r = r - base[w * gridDim.x] + (int)(w * cap);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void route_place_kernel(
       send_ids[p] = g / W;
     }
     __syncthreads();
-    if (threadIdx.x < W) {
+    if ((int)threadIdx.x < W) {
       int t = 0;
       for (int v = 0; v < kBlock / 64; ++v) t += wcnt[v][threadIdx.x];
       run[threadIdx.x] += t;
