@@ -359,7 +359,10 @@ int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field_off, const
                              const float *g_bias, const float *g_lin, int64_t B, int F, int D,
                              int LD, float *rows, float *m_state, float *v_state, float *gbuf,
                              int32_t *stamp, int step, int kind, float lr, float beta1, float beta2,
-                             float eps, int reset, rm_stream_t stream);
+                             float eps, int reset,
+                             const float *lin_field_mask /* [F] 0/1: fields outside the hyper-parameter
+                                linear_features (utils.py:27-30) get no linear gradient; NULL = all */,
+                             rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Row helpers (owner-side gather and re-ordering for the row-sharded table).

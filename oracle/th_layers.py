@@ -48,7 +48,12 @@ class Spec:
     (inputs.py:166).  dense_names: DenseFeat columns in dictionary order.
     """
 
-    def __init__(self, sparse_names, feat_sizes, dense_names=(), multi_names=(), value_names=()):
+    def __init__(self, sparse_names, feat_sizes, dense_names=(), multi_names=(), value_names=(),
+                 linear_names=None):
+        # linear_names: the hyper-parameter `linear_features` (utils.py:27-30) as a list - the features
+        # of the linear term IN THE GIVEN ORDER (any mix of embedding and dense features); None = all of
+        # them in the default order of utils.py:31-36
+        self.linear_names = list(linear_names) if linear_names else None
         self.sparse_names = list(sparse_names)
         self.feat_sizes = [int(v) for v in feat_sizes]
         self.dense_names = list(dense_names)
@@ -83,6 +88,22 @@ class Spec:
             at[n] = off
             off += size[n]
         return [at[n] for n in self.sparse_names], off
+
+    @property
+    def lin_layout(self):
+        """(offset of every embedding feature's one-hot block or None, offset of every dense
+        feature's column or None, total width of linear_w) under `linear_names`."""
+        if self.linear_names is None:
+            offs, dense_off = self.lin_offsets
+            return offs, [dense_off + j for j in range(self.Dn)], dense_off + self.Dn
+        size = dict(zip(self.sparse_names, self.feat_sizes))
+        at, off = {}, 0
+        for n in self.linear_names:
+            if n in at or (n not in size and n not in self.dense_names):
+                raise ValueError(f"linear_features: unknown or repeated feature {n!r}")
+            at[n] = off
+            off += size.get(n, 1)
+        return ([at.get(n) for n in self.sparse_names], [at.get(n) for n in self.dense_names], off)
 
 
 # ---------------------------------------------------------------------------
@@ -126,8 +147,7 @@ def make_params(spec, model, D, hidden=(32, 32), cin_units=(), cross_layers=0, u
         p[f"{name}_feat_embed"] = rnd((V, D))
         if use_bias:
             p[f"{name}_feat_bias"] = rnd((V, 1))
-    _, dense_off = spec.lin_offsets
-    p["linear_w"] = rnd((dense_off + spec.Dn, 1))
+    p["linear_w"] = rnd((spec.lin_layout[2], 1))
     p["linear_w0"] = rnd((1,))
     d_in = spec.F * D + spec.Dn
     dims = [d_in] + list(hidden)
@@ -208,9 +228,11 @@ def linear_layer(p, spec, idx, dense, manual_weights=None, mv=None):
     W = p["linear_w"]
     if manual_weights is not None:  # training=False (layers.py:338-345, 426-437)
         W = W + manual_weights.reshape(-1, 1).to(W.dtype)
-    offs, dense_off = spec.lin_offsets
+    offs, dense_offs, _ = spec.lin_layout
     out = p["linear_w0"].reshape(1, 1).expand(idx.shape[0], 1)
     for f, off in enumerate(offs):
+        if off is None:  # not among the linear_features
+            continue
         n = spec.sparse_names[f]
         if n in spec.multi_names:
             offsets, ids = mv[n]
@@ -224,8 +246,9 @@ def linear_layer(p, spec, idx, dense, manual_weights=None, mv=None):
             out = out + _lookup(W, off + ids) * vals.to(W.dtype).unsqueeze(1)
             continue
         out = out + _lookup(W, off + idx[:, f])
-    if spec.Dn:
-        out = out + dense @ W[dense_off : dense_off + spec.Dn]
+    for j, off in enumerate(dense_offs):
+        if off is not None:
+            out = out + dense[:, j : j + 1] * W[off]
     return out
 
 

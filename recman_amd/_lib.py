@@ -58,7 +58,7 @@ SIGNATURES = {
     "rm_pool_rows": [P, I64, c_int, c_int, P, P, P, I64, P, P],
     "rm_pool_rows_bwd": [P, I64, P, P, c_int, P, P, P, I64, I64, P, P, P, P],
     "rm_sparse_optimizer_step": [P, P, P, P, P, I64, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int,
-                                 c_float, c_float, c_float, c_float, c_int, P],
+                                 c_float, c_float, c_float, c_float, c_int, P, P],
     "rm_shard_route": [P, P, I64, c_int, c_int, P, P, P, P, P],
     "rm_shard_route_padded": [P, P, I64, c_int, c_int, I64, P, P, P, P, P, P],
     "rm_pack_grad_rows": [P, P, P, P, I64, c_int, c_int, c_int, P, P],

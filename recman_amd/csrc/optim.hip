@@ -21,7 +21,8 @@ constexpr int kBlock = 256;
 __global__ __launch_bounds__(kBlock) void sparse_accumulate_kernel(
     const int64_t *__restrict__ idx, const int64_t *__restrict__ field_off,
     const float *__restrict__ d_rows, const float *__restrict__ g_bias,
-    const float *__restrict__ g_lin, int64_t n, int F, int D, int LD, float *__restrict__ gbuf) {
+    const float *__restrict__ g_lin, const float *__restrict__ lin_mask, int64_t n, int F, int D, int LD,
+    float *__restrict__ gbuf) {
   const int W = D + 2;
   const int64_t total = n * W;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void sparse_accumulate_kernel(
     float v;
     if (k < D) v = d_rows[o * D + k];
     else if (k == D) v = g_bias ? g_bias[o / F] : 0.f;
-    else v = g_lin ? g_lin[o / F] : 0.f;
+    else v = g_lin ? g_lin[o / F] * (lin_mask ? lin_mask[o % F] : 1.f) : 0.f;  // linear_features subset
     if (v != 0.f) atomicAdd(gbuf + row * LD + k, v);
   }
 }
@@ -97,7 +98,7 @@ extern "C" int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field
                                         int64_t B, int F, int D, int LD, float *rows, float *m_state,
                                         float *v_state, float *gbuf, int32_t *stamp, int step, int kind,
                                         float lr, float beta1, float beta2, float eps, int reset,
-                                        rm_stream_t stream) {
+                                        const float *lin_field_mask, rm_stream_t stream) {
   RM_REQUIRE(B >= 0 && F > 0 && D > 0 && LD >= D + 2 && D + 2 <= 4096, "rm_sparse_optimizer_step: bad sizes");
   RM_REQUIRE(kind >= 0 && kind <= 2 && step >= 1, "rm_sparse_optimizer_step: bad kind / step");
   if (B == 0) return RM_OK;
@@ -108,7 +109,8 @@ extern "C" int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = n * (D + 2);
   hipLaunchKernelGGL(sparse_accumulate_kernel, dim3(rm_grid_cap((total + kBlock - 1) / kBlock, 256 * 16)),
-                     dim3(kBlock), 0, st, idx, field_off, d_rows, g_bias, g_lin, n, F, D, LD, gbuf);
+                     dim3(kBlock), 0, st, idx, field_off, d_rows, g_bias, g_lin, lin_field_mask, n, F, D, LD,
+                     gbuf);
   float lr_t = lr;
   if (kind == 0) {
     const double t = reset ? 1.0 : (double)step;

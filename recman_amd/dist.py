@@ -358,6 +358,8 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 raise NotImplementedError(
                     f"row-sharded table: multi-valued / value features {sorted(spec.scratch_names)} "
                     "are not supported yet (single-GPU engines handle them)")
+            if spec.linear_names is not None:
+                raise NotImplementedError("row-sharded table: linear_features subsets are not supported yet")
             self._shard_args = (rank, world, group)
             self._pending = None
             self._slot = None
@@ -373,6 +375,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             self.st = ShardedTable(R, self.D, rank, world, dev, hip_gather,
                                    HipRouter(dev, ring=self.micro_batches + 1), group, capacity_factor)
             self.table = self.st.shard  # [R_local, D+4] fused rows
+            self.lin_field_mask = self.lin_dense_mask = None
             self.linear_w_dense = torch.zeros(self.Dn, dtype=torch.float32, device=dev)
             self.field_off = torch.tensor(self.spec.offsets(), dtype=torch.int64, device=dev)
             self.lin_off = self.field_off

@@ -43,10 +43,19 @@ class FeatureSpec:
     FeatureDictionary order (inputs.py:13-15) with their feat_size (null slot
     included, inputs.py:166) and the dense feature names."""
 
-    def __init__(self, sparse_names, feat_sizes, dense_names=(), multi_names=(), value_names=()):
+    def __init__(self, sparse_names, feat_sizes, dense_names=(), multi_names=(), value_names=(),
+                 linear_names=None):
         self.sparse_names = list(sparse_names)
         self.feat_sizes = [int(v) for v in feat_sizes]
         self.dense_names = list(dense_names)
+        # the hyper-parameter linear_features (get_linear_features, utils.py:27-30): the features of
+        # the linear term in the order given; None = every feature in the default order (:31-36)
+        self.linear_names = list(linear_names) if linear_names else None
+        if self.linear_names is not None:
+            known = set(self.sparse_names) | set(self.dense_names)
+            bad = [n for n in self.linear_names if n not in known]
+            if bad or len(set(self.linear_names)) != len(self.linear_names):
+                raise ValueError(f"linear_features: unknown or repeated features {bad or self.linear_names}")
         # embedding features that are multi-valued (MultiValCsvFeat): sqrtn-pooled lookup
         self.multi_names = list(multi_names)
         # embedding features that carry a value (SparseValueFeat): value-weighted lookup
@@ -83,6 +92,24 @@ class FeatureSpec:
                  + [n for n in self.sparse_names if n in self.value_names]
                  + [n for n in self.sparse_names if n in self.multi_names])
         return [at[n] for n in order]
+
+    def lin_ref_layout(self):
+        """The reference's linear_w as a list of pieces in ITS order: ("s", first table row, size)
+        for an embedding feature's one-hot block, ("d", j) for dense column j."""
+        if self.linear_names is None:
+            return [("s", o, n) for o, n in self.lin_ref_blocks()] + [("d", j) for j in range(self.Dn)]
+        at = dict(zip(self.sparse_names, zip(self.offsets(), self.feat_sizes)))
+        dj = {n: j for j, n in enumerate(self.dense_names)}
+        return [("s",) + at[n] if n in at else ("d", dj[n]) for n in self.linear_names]
+
+    def lin_masks(self):
+        """(per-field 0/1 list, per-dense-column 0/1 list): which features the linear term uses;
+        (None, None) when it uses all of them."""
+        if self.linear_names is None:
+            return None, None
+        sel = set(self.linear_names)
+        return ([1.0 if n in sel else 0.0 for n in self.sparse_names],
+                [1.0 if n in sel else 0.0 for n in self.dense_names])
 
     @property
     def scratch_names(self):
@@ -365,6 +392,7 @@ class Engine:
                 self.params[f"{name}_feat_bias"] = self.rows[off: off + V, D: D + 1]
         self.params["linear_w_sparse"] = self.rows[:, D + 1]
         self.params["linear_w_dense"] = self.linear_w_dense
+        self._set_lin_masks()
 
     def storage(self):
         """The distinct parameter buffers (for initialisers that fill storage in place)."""
@@ -382,10 +410,10 @@ class Engine:
         R = self.spec.rows
         for k, v in params.items():
             v = torch.as_tensor(v).to(self.device, F32)
-            if k == "linear_w":  # [sum V_f + Dn, 1]: one-hot blocks first, dense columns last
-                v = v.reshape(-1)
-                self.params["linear_w_sparse"].copy_(self._lin_from_ref(v[:R]))
-                self.params["linear_w_dense"].copy_(v[R:])
+            if k == "linear_w":  # the reference's stacked one-hot blocks / dense columns
+                vs, vd = self._lin_from_ref(v.reshape(-1))
+                self.params["linear_w_sparse"].copy_(vs)
+                self.params["linear_w_dense"].copy_(vd)
                 continue
             if k not in self.params:
                 raise KeyError(f"unknown variable {k!r}")
@@ -400,32 +428,50 @@ class Engine:
                 continue
             out[k] = v.detach().clone().contiguous()
         if "linear_w_sparse" in self.params:
-            out["linear_w"] = torch.cat([self._lin_to_ref(self.params["linear_w_sparse"].detach().reshape(-1)),
-                                         self.params["linear_w_dense"].detach().reshape(-1)]).view(-1, 1)
+            out["linear_w"] = self._lin_to_ref(self.params["linear_w_sparse"].detach().reshape(-1),
+                                               self.params["linear_w_dense"].detach().reshape(-1)).view(-1, 1)
         return out
 
-    def _lin_to_ref(self, v_rows):
-        """[R] in table-row order -> the reference's linear_w block order (sparse, value, multi-valued)."""
-        if not self.spec.scratch_names:
-            return v_rows
-        return torch.cat([v_rows[o: o + n] for o, n in self.spec.lin_ref_blocks()])
+    def _set_lin_masks(self):
+        """linear_features subsets: the linear weights of the other features stay at their zero
+        initial value (W is zero-initialised, layers.py:318-328) because their gradient is masked."""
+        mf, md = self.spec.lin_masks()
+        dev = self.device
+        self.lin_field_mask = None if mf is None else torch.tensor(mf, dtype=F32, device=dev)
+        self.lin_dense_mask = None if (md is None or not md) else torch.tensor(md, dtype=F32, device=dev)
+
+    def _lin_to_ref(self, v_rows, v_dense):
+        """([R] in table-row order, [Dn]) -> the reference's linear_w: its one-hot blocks and dense
+        columns in its order (default: sparse, value, multi-valued, dense; or `linear_features`)."""
+        if self.spec.linear_names is None and not self.spec.scratch_names:
+            return torch.cat([v_rows, v_dense])
+        return torch.cat([v_rows[p[1]: p[1] + p[2]] if p[0] == "s" else v_dense[p[1]: p[1] + 1]
+                          for p in self.spec.lin_ref_layout()])
 
     def _lin_from_ref(self, v_ref):
-        if not self.spec.scratch_names:
-            return v_ref
-        out = torch.empty_like(v_ref)
+        """The inverse: (rows [R], dense [Dn]); entries of features outside `linear_features` are 0."""
+        R, Dn = self.spec.rows, self.Dn
+        if self.spec.linear_names is None and not self.spec.scratch_names:
+            return v_ref[:R], v_ref[R:]
+        vs, vd = v_ref.new_zeros(R), v_ref.new_zeros(Dn)
         at = 0
-        for o, n in self.spec.lin_ref_blocks():
-            out[o: o + n] = v_ref[at: at + n]
-            at += n
-        return out
+        for p in self.spec.lin_ref_layout():
+            if p[0] == "s":
+                vs[p[1]: p[1] + p[2]] = v_ref[at: at + p[2]]
+                at += p[2]
+            else:
+                vd[p[1]] = v_ref[at]
+                at += 1
+        if at != v_ref.numel():
+            raise ValueError(f"linear_w has {v_ref.numel()} entries, the linear features need {at}")
+        return vs, vd
 
     def to_reference_names(self, d):
         """Merges the internal linear_w_sparse / linear_w_dense entries into `linear_w`."""
         d = dict(d)
         if "linear_w_sparse" in d:
-            d["linear_w"] = torch.cat([self._lin_to_ref(d.pop("linear_w_sparse").reshape(-1)),
-                                       d.pop("linear_w_dense").reshape(-1)]).view(-1, 1)
+            d["linear_w"] = self._lin_to_ref(d.pop("linear_w_sparse").reshape(-1),
+                                             d.pop("linear_w_dense").reshape(-1)).view(-1, 1)
         return d
 
     def _alloc(self, B):
@@ -520,8 +566,9 @@ class Engine:
             mw = manual_weights.to(self.device, F32).reshape(-1)
             R = self.spec.rows
             backup = (self.params["linear_w_sparse"].clone(), self.linear_w_dense.clone())
-            self.params["linear_w_sparse"].add_(self._lin_from_ref(mw[:R]))
-            self.linear_w_dense.add_(mw[R:])
+            ms, md = self._lin_from_ref(mw)
+            self.params["linear_w_sparse"].add_(ms)
+            self.linear_w_dense.add_(md)
         try:
             branches = self._branches_fwd(idx, dense, training, masks, None)
             ops.logit_loss(branches, task=self.task, logit=self.logit, pred=self.pred)
@@ -564,6 +611,8 @@ class Engine:
             ops.linear_dense_bwd(self.dlogit, dense if self.Dn else None,
                                  self.grads["linear_w_dense"] if self.Dn else None,
                                  self.grads["linear_w0"], self.ws)
+        if self.use_linear and self.Dn and self.lin_dense_mask is not None:
+            self.grads["linear_w_dense"].mul_(self.lin_dense_mask)  # linear_features subset
         return self._add_l2(self.loss)
 
     fuse_head = True  # tests switch it off to compare against rm_logit_loss + the chain kernel
@@ -682,6 +731,10 @@ class Engine:
                               offsets, ids, offs[f], d_table, d_bias if gb is not None else None,
                               d_lin if self.use_linear else None, vals=vals)
         d_table, d_lin = d_table[:R], d_lin[:R]
+        if self.lin_field_mask is not None:  # linear_features subset
+            for f, (off, V) in enumerate(zip(offs, self.spec.feat_sizes)):
+                if self.spec.sparse_names[f] not in self.spec.linear_names:
+                    d_lin[off: off + V] = 0
         if d_bias is not None:
             d_bias = d_bias[:R]
         reg = hp.get("embedding_l2_reg", 0.0)

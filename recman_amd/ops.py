@@ -373,7 +373,8 @@ OPT_KINDS = {"adam": 0, "adagrad": 1, "gd": 2, "sgd": 2}
 
 
 def sparse_optimizer_step(idx, field_off, d_rows, rows, m_state, v_state, gbuf, stamp, step, kind, lr,
-                          g_bias=None, g_lin=None, reset=False, beta1=0.9, beta2=0.999, eps=1e-7):
+                          g_bias=None, g_lin=None, reset=False, beta1=0.9, beta2=0.999, eps=1e-7,
+                          lin_field_mask=None):
     """Lazy row-wise optimizer step on fused rows [R, LD] (see rm_sparse_optimizer_step)."""
     B, F, D = d_rows.shape
     R, LD = rows.shape
@@ -389,7 +390,8 @@ def sparse_optimizer_step(idx, field_off, d_rows, rows, m_state, v_state, gbuf, 
               None if m_state is None else m_state.data_ptr(),
               None if v_state is None else v_state.data_ptr(), gbuf.data_ptr(), stamp.data_ptr(),
               int(step), OPT_KINDS[kind], float(lr), float(beta1), float(beta2), float(eps),
-              1 if reset else 0, _stream())
+              1 if reset else 0, _chk(lin_field_mask, "lin_field_mask", F32, (F,), allow_none=True),
+              _stream())
 
 
 def _chk_csr(offsets, ids, vals):

@@ -78,6 +78,11 @@ class SparseTableOptimizer:
         self.stamp = _t.zeros(R, dtype=_t.int32, device=dev)
         self.t = 0
 
+    def _lin_on(self, f):
+        """Is embedding feature f among the linear features (hyper-parameter linear_features)?"""
+        names = self.e.spec.linear_names
+        return names is None or self.e.spec.sparse_names[f] in names
+
     def step(self, idx, reset=False):
         import torch as _t
 
@@ -90,7 +95,8 @@ class SparseTableOptimizer:
             idx[:, e.mv_fields] = -1  # handled below
         self.ops.sparse_optimizer_step(
             idx, e.field_off, e.d_rows, e.rows, self.m, self.v, self.gbuf, self.stamp, self.t,
-            self.name, self.lr, g_bias=g_bias, g_lin=g_lin, reset=reset)
+            self.name, self.lr, g_bias=g_bias, g_lin=g_lin, reset=reset,
+            lin_field_mask=getattr(e, "lin_field_mask", None))
         B = idx.shape[0]
         for f in e.mv_fields:
             offsets, ids, vals = e._mv_entry(f)
@@ -107,4 +113,5 @@ class SparseTableOptimizer:
                 ids.view(-1, 1).contiguous(), zoff, rows_g, e.rows, self.m, self.v, self.gbuf, self.stamp,
                 self.t, self.name, self.lr,
                 g_bias=(g_bias[seg] * wb).contiguous() if g_bias is not None else None,
-                g_lin=(g_lin[seg] * wl).contiguous() if g_lin is not None else None, reset=reset)
+                g_lin=(g_lin[seg] * wl).contiguous() if (g_lin is not None and self._lin_on(f)) else None,
+                reset=reset)

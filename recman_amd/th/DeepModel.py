@@ -57,7 +57,8 @@ class DeepModel(BaseEstimator, TransformerMixin):
                                [f.feat_size for f in fd.embedding_feats],
                                [f.name for f in fd.dense_feats],
                                [f.name for f in fd.multi_val_csv_feats],
-                               [f.name for f in fd.sparse_val_feats])
+                               [f.name for f in fd.sparse_val_feats],
+                               linear_names=self._linear_names())
         hp = dict(self.hparams)
         hp["strict_reference"] = self.strict_reference
         e = eng.ENGINES[self.model](spec, hp["embedding_size"], hp, task=self.task, device=self.device)
@@ -103,11 +104,26 @@ class DeepModel(BaseEstimator, TransformerMixin):
                 out[name] += (torch.from_numpy(c.vals).to(dev),)
         return out
 
+    def _linear_names(self):
+        """The hyper-parameter `linear_features` (get_linear_features, utils.py:27-30): a
+        comma-separated list of feature names = the linear term's features in that order; empty =
+        all of them.  Returns the list or None."""
+        lf = (self.hparams or {}).get("linear_features")
+        if not lf:
+            return None
+        names = [n.strip() for n in lf.split(",")] if isinstance(lf, str) else list(lf)
+        for n in names:
+            if n not in self.feat_dict:
+                raise KeyError(f"linear_features: no feature named {n!r}")  # feat_dict[name] in the reference
+        return names
+
     def _manual_weights(self):
         """Concatenated per-feature manual weights in linear-feature order
         (layers.py:338-345), or None when no feature has any."""
         fd = self.feat_dict
-        feats = fd.linear_feats  # utils.py:31-36: sparse, value, multi-valued csv, dense
+        names = self._linear_names()
+        # utils.py:27-36: the named features in the given order, or sparse, value, multi-valued csv, dense
+        feats = [fd[n] for n in names] if names else fd.linear_feats
         if not any(getattr(f, "_weights", None) for f in feats):
             return None
         w = np.concatenate([np.asarray(f.weights, dtype=np.float64).reshape(-1) for f in feats])

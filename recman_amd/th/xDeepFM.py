@@ -13,8 +13,6 @@ class xDeepFM(DeepModel):
                  batch_size=64, random_seed=2019, strict_reference=False, device="cuda"):
         hp = HyperParams().defaults()
         hp.update(hparams)
-        if hp.get(HyperParams.LinearFeatures):
-            raise NotImplementedError("linear_features subsets are not supported yet")
         DeepModel.__init__(self, feat_dict=feat_dict, hparams=hp, epoch=epoch, batch_size=batch_size,
                            random_seed=random_seed, metrics=metrics, task=task,
                            strict_reference=strict_reference, device=device)

@@ -344,3 +344,32 @@ def test_batch_feeder_yields_the_permuted_batches(hip_lib):
         seen += t - s
     assert seen == 1000
     assert sum(t - s for s, t, *_ in f.batches()) == 1000  # no permutation: the natural order
+
+
+def test_xdeepfm_linear_features_hyper_parameter(hip_lib):
+    """hparams["linear_features"] = "age,item_id,gender" (get_linear_features, utils.py:27-30): the
+    linear term uses only those features; linear_w stacks them in that order; the others' linear
+    weights stay at their zero initial value through training."""
+    import recman_amd.th as th
+
+    df = ml_frame()
+    fd = ml_features(df)
+    hp = {"embedding_size": 8, "cin_cross_layer_units": (8, 8), "deep_hidden_units": (16, 16),
+          "deep_dropout": (1, 1, 1), "learning_rate": 0.01, "linear_features": "age,item_id,gender"}
+    m = th.xDeepFM(fd, hp, metrics=(log_loss,), epoch=2, batch_size=128)
+    before = log_loss(df["label"].values, m.predict(df).astype(np.float64))
+    m.fit(df, df["label"].values)
+    after = log_loss(df["label"].values, m.predict(df).astype(np.float64))
+    assert after < before
+    sd = m._build().state_dict()
+    width = 1 + fd["item_id"].feat_size + fd["gender"].feat_size
+    assert tuple(sd["linear_w"].shape) == (width, 1)
+    assert float(sd["linear_w"].abs().max()) > 0
+    e = m._build()
+    names = e.spec.sparse_names
+    for n, off, V in zip(names, e.spec.offsets(), e.spec.feat_sizes):
+        blk = e.params["linear_w_sparse"][off: off + V]
+        assert (float(blk.abs().max()) > 0) == (n in ("item_id", "gender")), n
+    assert float(e.linear_w_dense[0].abs()) == 0.0 and float(e.linear_w_dense[1].abs()) > 0  # timestamp, age
+    with pytest.raises(KeyError):
+        th.xDeepFM(fd, dict(hp, linear_features="age,nope"))._build()

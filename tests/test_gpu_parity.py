@@ -490,3 +490,44 @@ def test_fused_mlp_head_equals_logit_loss_and_chain_kernels(hip_lib, model, kw, 
         assert torch.equal(x[:B], z[:B]), f"dh[{l}]"
     for k in a[6]:
         assert torch.equal(a[6][k], b[6][k]), k
+
+
+@pytest.mark.parametrize("model,kw,names", [
+    ("xdeepfm", dict(cin_units=(16, 8), scale=0.2), ["I1", "C3", "C0"]),
+    ("deepfm", {}, ["C1", "C4"]),
+    ("dcn", dict(cross_layers=2, scale=0.15), ["I0", "C2", "I1", "C0"]),
+])
+def test_linear_features_subset_matches_oracle(hip_lib, model, kw, names):
+    """The hyper-parameter linear_features (get_linear_features, utils.py:27-30): only the named
+    features feed the linear term, linear_w stacks them in the order given; the other features'
+    linear weights get no gradient (engine gradients, row-wise optimizer)."""
+    from recman_amd import engine as eng
+    from recman_amd.optim import SparseTableOptimizer
+
+    spec0, _, idx, dense, y, hp = make_case(model, B=41, D=8, **kw)
+    spec = T.Spec(spec0.sparse_names, spec0.feat_sizes, spec0.dense_names, linear_names=names)
+    p = T.make_params(spec, model, 8, hidden=hp["deep_hidden_units"],
+                      cin_units=hp.get("cin_cross_layer_units", ()), cross_layers=hp.get("cross_layer_num", 0),
+                      use_bias=(model == "deepfm"), seed=7, scale=kw.get("scale", 0.3))
+    loss_o, logit_o, _, grads_o = T.fwd_bwd(model, p, spec, idx, dense, y, hp)
+    espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names, linear_names=names)
+    e = eng.ENGINES[model](espec, 8, hp)
+    e.load_params({k: v for k, v in p.items() if k in e.params or k == "linear_w"})
+    loss = e.fwd_bwd(idx.cuda(), dense.cuda(), y.cuda())
+    _close(e.logit, logit_o, rtol=0, atol=1e-5, what="logit")
+    _close(loss, loss_o.reshape(1), what="loss")
+    assert tuple(e.state_dict()["linear_w"].shape) == tuple(p["linear_w"].shape)
+    _close(e.state_dict()["linear_w"], p["linear_w"], rtol=0, atol=0, what="linear_w round trip")
+    grads = e.dense_grads(idx.cuda(), reference_names=True)
+    for k in grads_o:
+        if k in grads:
+            _close(grads[k], grads_o[k], what=f"grad {k}")
+    # the row-wise optimizer leaves the other features' linear weights untouched (zero)
+    opt = SparseTableOptimizer(e, "adam", 1e-2)
+    opt.step(idx.cuda())
+    lw = e.params["linear_w_sparse"]
+    for n, off, V in zip(spec.sparse_names, espec.offsets(), spec.feat_sizes):
+        if n not in names:
+            assert float(lw[off: off + V].abs().max()) == 0.0, n
+        else:
+            assert float((lw[off: off + V] - e._lin_from_ref(p["linear_w"].reshape(-1).cuda())[0][off: off + V]).abs().max()) > 0

@@ -181,3 +181,22 @@ def test_value_feature_reduces_to_plain_lookup_and_scales():
     E3, b3 = T.feat_embedding_layer(pv, vspec, idx, True, mv={name: (idx[:, 1], 3 * ones)})
     assert torch.allclose(E3[:, 1], 3 * E1[:, 1]) and torch.equal(b3, b1)
     assert torch.equal(E3[:, 0], E1[:, 0])
+
+
+def test_linear_features_subset_layout_and_value():
+    """get_linear_features with a name list (utils.py:27-30): linear_w stacks only those features'
+    one-hot blocks / columns, in the order given."""
+    spec = T.Spec(["a", "b", "c"], [4, 3, 5], ["x", "y"], linear_names=["y", "c", "a"])
+    offs, doffs, total = spec.lin_layout
+    assert (offs, doffs, total) == ([6, None, 1], [None, 0], 10)
+    W = torch.arange(10, dtype=torch.float64).reshape(10, 1) + 1.0
+    p = {"linear_w": W, "linear_w0": torch.tensor([0.5], dtype=torch.float64)}
+    idx = torch.tensor([[2, 1, 4], [0, 2, 0]])
+    dense = torch.tensor([[10.0, 2.0], [20.0, -1.0]], dtype=torch.float64)
+    out = T.linear_layer(p, spec, idx, dense)
+    # y*W[0] + W[1 + idx_c] + W[6 + idx_a] + w0
+    want = torch.tensor([[2.0 * 1 + (1 + 1 + 4) + (6 + 1 + 2) + 0.5], [-1.0 * 1 + 2 + 7 + 0.5]],
+                        dtype=torch.float64)
+    assert torch.equal(out, want)
+    with pytest.raises(ValueError):
+        T.Spec(["a"], [4], [], linear_names=["zz"]).lin_layout
