@@ -549,6 +549,170 @@ __global__ __launch_bounds__(ROWS * 2) void cin_dx_kernel(
   }
 }
 
+// First layer (Xk IS X0): dX0[a] = sum_b dZs[a][b] x0[b] with the SYMMETRIC dZs[a][b] = dM . (W[a][b] +
+// W[b][a]) - only the pairs b >= a are formed (the k' ordering of the forward / dW pass, K' = 384
+// instead of 26 x 32 = 832 at m = 26), pair (i, j) then feeds dX0[i] += dZs x0[j] and dX0[j] += dZs x0[i]
+// (i = j: both land on the same field, 2 dZs x0[i], as d(x^2) wants).
+// Wq[k'][n] = folded filter row of pair k' (zero rows where the ordering pads).
+__global__ void cin_prep_bwd_sym_kernel(const float *__restrict__ W, int m, int H, int N, int Np,
+                                        float *__restrict__ Wq) {
+  const int total = cin_Kp_sym(m, H) * Np;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int kp = t / Np, n = t - kp * Np;
+    int i, j;
+    bool ok;
+    cin_kp_ij(kp, m, H, 1, i, j, ok);
+    float v = 0.f;
+    if (ok && n < N) {
+      v = W[(int64_t)(i * H + j) * N + n];
+      if (j > i) v += W[(int64_t)(j * H + i) * N + n];
+    }
+    Wq[t] = v;
+  }
+}
+
+// Same MFMA scheme as cin_dx_kernel (A = filter tile from LDS, B = the lane's dM row in registers), but a
+// tile's 32 k' are arbitrary (i, j) pairs, so the contraction with x0 cannot use static registers: the
+// wave parks its dZs tile in LDS [k'][row] and each lane half then walks 16 of the 32 pairs of ITS rows -
+// the i side accumulates in a register while i stays the same (pairs run j-fastest), the j side is a
+// read-modify-write of the half's own accumulator image dXa[h][field][row] (no atomics: a (half, row) has
+// one owner).  The two images are added at the end.
+template <int NT>
+__global__ __launch_bounds__(512) void cin_dx_sym_kernel(
+    const float *__restrict__ X0, const float *__restrict__ Wq, const float *__restrict__ dM, int64_t B,
+    int m, int D, float *__restrict__ dX0, int accumulate_dx0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int Np = 32 * NT;
+  constexpr int LDW = Np + 4;
+  constexpr int ROWS = 256, NTHR = 512;
+  const int He = cin_He(m), Kp = cin_Kp_sym(m, m), ntiles = Kp / 32;
+  float *X0s = smem;                         // [m][ROWS]
+  float *dXa = X0s + m * ROWS;               // [2][m][ROWS]
+  float *Wt = dXa + 2 * m * ROWS;            // [2][32][LDW]
+  float *dZt_all = Wt + 2 * 32 * LDW;        // [8 waves][32 k'][32 rows]
+  int *ijs = reinterpret_cast<int *>(dZt_all + 8 * 32 * 32);  // [Kp]: i | j << 8
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+  const int epb = ROWS / D;
+  const int64_t b0 = (int64_t)blockIdx.x * epb;
+  const int D4 = D / 4;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int t = tid; t < epb * m * D4; t += NTHR) {
+    const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+    const int64_t b = b0 + bl;
+    const float4 v = b < B ? *reinterpret_cast<const float4 *>(X0 + (b * m + i) * D + 4 * d4) : z4;
+    *reinterpret_cast<float4 *>(X0s + i * ROWS + bl * D + 4 * d4) = v;
+  }
+  for (int t = tid; t < 2 * m * ROWS; t += NTHR) dXa[t] = 0.f;
+  for (int kp = tid; kp < Kp; kp += NTHR) {
+    int i, j;
+    cin_sym_ij(kp, m, He, i, j);
+    // padding pairs (past the end, or the j = i - 1 / j = H slots of the ordering) carry a zero filter
+    // row: any in-range field will do for them
+    i = i < m ? i : m - 1;
+    j = j < m ? j : m - 1;
+    ijs[kp] = i | (j << 8);
+  }
+  const int prow = wave * 32 + c;
+  const int64_t pg = b0 * D + prow;  // global row
+  float dm[Np / 2];
+#pragma unroll
+  for (int u = 0; u < Np / 8; ++u) {
+    const float4 v = pg < B * D ? *reinterpret_cast<const float4 *>(dM + pg * Np + 8 * u + 4 * h) : z4;
+    dm[4 * u + 0] = v.x; dm[4 * u + 1] = v.y; dm[4 * u + 2] = v.z; dm[4 * u + 3] = v.w;
+  }
+  constexpr int CF4 = 32 * Np / 4;                 // float4 per filter tile
+  constexpr int F4 = (CF4 + NTHR - 1) / NTHR;      // per thread
+  static_assert(F4 <= 2, "the filter prefetch is written out for at most 2 float4 per thread");
+#pragma unroll
+  for (int q = 0; q < F4; ++q) {
+    const int f = tid + q * NTHR, row = f / (Np / 4), c4 = f - row * (Np / 4);
+    if (f < CF4)
+      *reinterpret_cast<float4 *>(Wt + row * LDW + 4 * c4) =
+          *reinterpret_cast<const float4 *>(Wq + (int64_t)row * Np + 4 * c4);
+  }
+  __syncthreads();
+
+  float *dZt = dZt_all + wave * 32 * 32;
+  float *dXh = dXa + h * m * ROWS;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    // next filter tile -> named registers, unconditionally (see cin_dx_kernel)
+    const int ktn = kt + 1 < ntiles ? kt + 1 : kt;
+    const float *wsrc = Wq + (int64_t)ktn * 32 * Np;
+    const int f0 = tid < CF4 ? tid : CF4 - 1, f1 = tid + NTHR < CF4 ? tid + NTHR : CF4 - 1;
+    const float4 pf0 = *reinterpret_cast<const float4 *>(wsrc + (int64_t)(f0 / (Np / 4)) * Np + 4 * (f0 % (Np / 4)));
+    float4 pf1 = pf0;
+    if constexpr (F4 > 1)
+      pf1 = *reinterpret_cast<const float4 *>(wsrc + (int64_t)(f1 / (Np / 4)) * Np + 4 * (f1 % (Np / 4)));
+    __builtin_amdgcn_sched_barrier(0);
+    const float *Wb = Wt + (kt & 1) * 32 * LDW;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < Np / 8; ++u) {
+      const float4 a4 = *reinterpret_cast<const float4 *>(Wb + c * LDW + 8 * u + 4 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, dm[4 * u + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, dm[4 * u + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, dm[4 * u + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, dm[4 * u + 3], acc, 0, 0, 0);
+    }
+    // acc[r] = dZs[row = prow][k' = kt*32 + (r&3) + 8*(r>>2) + 4h]  ->  dZt[k' local][row local]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dZt[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c] = acc[r];
+    // this half's 16 pairs of the tile, for row c of the wave
+    int cur_i = -1;
+    float acc_i = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+      const int kk = 16 * h + q;
+      const int ij = ijs[kt * 32 + kk];
+      const int i = ij & 255, j = ij >> 8;
+      const float dz = dZt[kk * 32 + c];
+      const float xi = X0s[i * ROWS + prow], xj = X0s[j * ROWS + prow];
+      if (i != cur_i) {  // (uniform within the half)
+        if (cur_i >= 0) dXh[cur_i * ROWS + prow] += acc_i;
+        cur_i = i;
+        acc_i = 0.f;
+      }
+      acc_i += dz * xj;
+      dXh[j * ROWS + prow] += dz * xi;
+    }
+    dXh[cur_i * ROWS + prow] += acc_i;
+    {
+      float *Wn = Wt + ((kt + 1) & 1) * 32 * LDW;
+      constexpr bool kExact = CF4 % NTHR == 0;
+      if (kExact || tid < CF4) *reinterpret_cast<float4 *>(Wn + (tid / (Np / 4)) * LDW + 4 * (tid % (Np / 4))) = pf0;
+      if constexpr (F4 > 1) {
+        const int f_ = tid + NTHR;
+        if (kExact || f_ < CF4) *reinterpret_cast<float4 *>(Wn + (f_ / (Np / 4)) * LDW + 4 * (f_ % (Np / 4))) = pf1;
+      }
+    }
+    __syncthreads();
+  }
+
+  for (int t = tid; t < epb * m * D4; t += NTHR) {
+    const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+    const int64_t b = b0 + bl;
+    if (b >= B) continue;
+    const float4 u0 = *reinterpret_cast<const float4 *>(dXa + i * ROWS + bl * D + 4 * d4);
+    const float4 u1 = *reinterpret_cast<const float4 *>(dXa + (m + i) * ROWS + bl * D + 4 * d4);
+    float4 v = make_float4(u0.x + u1.x, u0.y + u1.y, u0.z + u1.z, u0.w + u1.w);
+    float4 *dst = reinterpret_cast<float4 *>(dX0 + (b * m + i) * D + 4 * d4);
+    if (accumulate_dx0) {
+      const float4 o = *dst;
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *dst = v;
+  }
+}
+
+size_t cin_dx_sym_smem(int m, int NT) {
+  const int Np = 32 * NT;
+  return (size_t)(3 * m * 256 + 2 * 32 * (Np + 4) + 8 * 32 * 32) * sizeof(float) +
+         (size_t)cin_Kp_sym(m, m) * sizeof(int);
+}
+
 size_t cin_dx_smem(int m, int H, int NT, int rows) {
   const int Np = 32 * NT;
   return (size_t)((2 * m + cin_Hp(H)) * rows + 2 * 32 * (Np + 4)) * sizeof(float);
@@ -940,7 +1104,14 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
   hipStream_t st = (hipStream_t)stream;
   float *dbias_part = part + cin_part_floats(B, m, H, Np, D);  // [kDmBlocks][Np]
 
-  hipLaunchKernelGGL(cin_prep_bwd_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, Np, Wq);
+#ifndef RM_CIN_DX_SYM
+#define RM_CIN_DX_SYM 1
+#endif
+  // first layer: the symmetric-pair dX kernel (about half the MFMA work), when its LDS images fit
+  const bool dx_sym = RM_CIN_DX_SYM && xk_is_x0 && H == m && 256 % D == 0 && m <= 255 &&
+                      cin_dx_sym_smem(m, NT) <= 160 * 1024;
+  if (dx_sym) hipLaunchKernelGGL(cin_prep_bwd_sym_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, Np, Wq);
+  else hipLaunchKernelGGL(cin_prep_bwd_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, Np, Wq);
   {
     int epb = 64 / D;  // EPB * D = 64 dM rows per iteration (D <= 64; D = 4, 8: capped at 8 examples)
     epb = epb < 1 ? 1 : (epb > 8 ? 8 : epb);
@@ -952,7 +1123,19 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
                        cin_w_direct, pool_from, act, B, N, Np, D, epb, dM, dbias_part);
     hipLaunchKernelGGL(cin_dbias_reduce_kernel, dim3(N), dim3(256), 0, st, dbias_part, nblk, N, Np, dbias);
   }
-  {
+  if (dx_sym) {
+    const size_t smem = cin_dx_sym_smem(m, NT);
+    dim3 grid((unsigned)((B + 256 / D - 1) / (256 / D)));
+#define RM_CIN_DXS(NT_)                                                                          \
+  {                                                                                              \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dx_sym_kernel<NT_>),            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
+    hipLaunchKernelGGL((cin_dx_sym_kernel<NT_>), grid, dim3(512), smem, st, X0, Wq, dM, B, m, D,  \
+                       dX0, accumulate_dx0);                                                     \
+  }
+    if (NT == 1) RM_CIN_DXS(1) else if (NT == 2) RM_CIN_DXS(2) else RM_CIN_DXS(4)
+#undef RM_CIN_DXS
+  } else {
     const int rows = (kRC * 2 % D == 0 && 256 % D == 0 && cin_dx_smem(m, H, NT, 256) <= 160 * 1024) ? 256 : 128;
     const size_t smem = cin_dx_smem(m, H, NT, rows);
     RM_REQUIRE(smem <= 160 * 1024, "rm_cin_layer_bwd: m=%d H=%d needs %zu B of LDS (> 160 KiB)", m, H, smem);
