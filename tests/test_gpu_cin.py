@@ -78,6 +78,9 @@ def test_cin_notebook_kat_on_gpu(hip_lib):
     (9, 6, 25, 100, 32, "leaky_relu", False, True),
     (6, 4, 8, 64, 64, "relu", False, False),
     (70, 3, 3, 8, 16, "leaky_relu", True, False),   # several dX blocks and dW chunks
+    (6, 4, 4, 64, 64, "relu", True, False),         # first layer (symmetric dX) at D = 64
+    (9, 7, 7, 100, 32, "leaky_relu", True, True),   # ... odd m, D = 32, N not a multiple of 32
+    (300, 26, 26, 128, 16, "leaky_relu", True, False),  # ... many blocks, ragged last block
 ])
 def test_cin_layer_bwd(hip_lib, B, m, H, N, D, act, first, last):
     """autograd (float64) of the oracle's layer formula vs rm_cin_layer_bwd."""
