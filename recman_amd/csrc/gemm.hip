@@ -315,6 +315,12 @@ struct TNArgs {
   int slabs, kts;      // batch slabs, 128-row tiles of K
   int kts_fast;        // K tiles [0, kts_fast) lie inside A1 with 16-byte rows (float4 staging)
   int a_vec;           // A1 rows are 16-byte aligned and K1 % 4 == 0
+  // Ragged last K tile with 1 or 2 live row groups (K = 400: 16 rows, K = 429: 45): its blocks would
+  // keep one or two SIMDs busy and idle the rest for a whole slab.  With split_f = 4 / live > 1 the
+  // tile's 4 row-group slots are (live row group) x (split_f parts of every chunk's 16 k-steps), the
+  // tile gets slabs_r (< slabs) longer slabs, and each part stores its own partial slab.
+  int split_f, live_rg, slabs_r;
+  int64_t slab_rows_r;
   int64_t slab_rows;   // multiple of TRC
   float *ws;           // [slabs][K][N]
   float *db_ws;        // [slabs][N] column sums of G per slab (the bias gradient), or NULL
@@ -333,18 +339,18 @@ constexpr int TAQ = TRC * kRowsPerBlock / 4 / kThreads;          // float4 of A 
 constexpr int TGQ = (TRC * kTileCols / 4 + kThreads - 1) / kThreads;  // float4 of G per thread (7)
 
 // k-steps of one staged chunk; the B operands of step s+1 are read before the MFMAs of step s
-template <int NT>
+template <int NT, int STEPS = TRC / 2>
 __device__ __forceinline__ void tn_compute(const float *As, const float *Gs, f32x16 (&acc)[NT], int c,
-                                           int h, int rg, int colb) {
-  const float *ap = As + h * TLDA + 32 * rg + c;
-  const float *gp = Gs + h * TLDG + colb + c;
+                                           int h, int rg, int colb, int s0 = 0) {
+  const float *ap = As + (2 * s0 + h) * TLDA + 32 * rg + c;
+  const float *gp = Gs + (2 * s0 + h) * TLDG + colb + c;
   float av[2], bv[2][NT];
   av[0] = ap[0];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bv[0][nt] = gp[32 * nt];
 #pragma unroll
-  for (int s = 0; s < TRC / 2; ++s) {
-    if (s + 1 < TRC / 2) {
+  for (int s = 0; s < STEPS; ++s) {
+    if (s + 1 < STEPS) {
       av[(s + 1) & 1] = ap[(2 * s + 2) * TLDA];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bv[(s + 1) & 1][nt] = gp[(2 * s + 2) * TLDG + 32 * nt];
@@ -367,8 +373,8 @@ __device__ __forceinline__ void tn_compute(const float *As, const float *Gs, f32
 // Staged values outside [K] x [N] need no zeroing: an MFMA output row / column depends only on
 // its own A row / B column, and those outputs are never stored.  Batch rows past the end ARE
 // zeroed (peeled last chunk).
-template <int NT, bool FASTA, bool FASTG>
-__device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, int c, int h, int rg,
+template <int NT, bool FASTA, bool FASTG, int F = 1>
+__device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, int c, int h, int rg_slot,
                                         int ntw, int colb, int slab, int kt) {
   float *As = smem;                 // [TRC][TLDA]
   float *Gs = smem + TRC * TLDA;    // [TRC][TLDG]
@@ -376,8 +382,12 @@ __device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, i
   const int K = a.K1 + a.K2;
   const int ka0 = kt * kRowsPerBlock, col0 = ct * kTileCols;
   const int ncols = min(a.N - col0, kTileCols);  // real columns of this tile
-  const int64_t b_begin = (int64_t)slab * a.slab_rows;
-  int64_t b_end = b_begin + a.slab_rows;
+  // F > 1: the split ragged tile - slot -> (live row group, part of the chunk's k-steps)
+  const int rg = F > 1 ? rg_slot % a.live_rg : rg_slot;
+  const int part = F > 1 ? rg_slot / a.live_rg : 0;
+  const int64_t srows = F > 1 ? a.slab_rows_r : a.slab_rows;
+  const int64_t b_begin = (int64_t)slab * srows;
+  int64_t b_end = b_begin + srows;
   b_end = b_end < a.M ? b_end : a.M;
 
   // per-thread staging coordinates (constant over the chunks)
@@ -514,7 +524,7 @@ __device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, i
     RM_TN_PREFETCH(b_begin + nx * TRC, true)
     __builtin_amdgcn_sched_barrier(0);
     if (do_db) colsum();
-    if (rg_live) tn_compute<NT>(As, Gs, acc, c, h, rg, colb);
+    if (rg_live) tn_compute<NT, TRC / 2 / F>(As, Gs, acc, c, h, rg, colb, part * (TRC / 2 / F));
   }
   if (partial) {  // the batch's ragged end (last slab only): rows past the end staged as zeros
     RM_TN_PREFETCH(b_begin + nfull * TRC, false)
@@ -522,11 +532,11 @@ __device__ __forceinline__ void tn_wave(const TNArgs &a, float *smem, int tid, i
     RM_TN_COMMIT()
     __syncthreads();
     if (do_db) colsum();
-    if (rg_live) tn_compute<NT>(As, Gs, acc, c, h, rg, colb);
+    if (rg_live) tn_compute<NT, TRC / 2 / F>(As, Gs, acc, c, h, rg, colb, part * (TRC / 2 / F));
   }
   if (do_db && tid < ncols) a.db_ws[(int64_t)slab * a.N + col0 + tid] = csum;
   if (!rg_live) return;
-  float *out = a.ws + (int64_t)slab * K * a.N;
+  float *out = a.ws + (int64_t)(F > 1 ? slab * F + part : slab) * K * a.N;  // (a part = a partial slab)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = col0 + colb + 32 * nt + c;
@@ -552,11 +562,24 @@ __global__ __launch_bounds__(kThreads, 1) void dense_tn_kernel(TNArgs a) {
   // XCD-aware order: the K tiles of one slab run next to each other on ONE XCD (they re-read
   // the same G rows: 3 of 4 reads then hit that XCD's L2)
   int64_t L = blockIdx.x;
-  const int64_t total = (int64_t)a.slabs * a.kts;
-  if (total % 8 == 0) L = (L % 8) * (total / 8) + L / 8;
-  const int slab = (int)(L / a.kts), kt = (int)(L % a.kts);
-  const bool fa = kt < a.kts_fast;  // block-uniform: this K tile lies inside A1 with 16-byte rows
+  // the K tiles with `slabs` slabs each: all of them, or all but a split ragged last one
+  const int ktsf = a.split_f > 1 ? a.kts - 1 : a.kts;
+  const int64_t total = (int64_t)a.slabs * ktsf;
   const int ntw = cg == 0 ? tl.nt0 : tl.nb - tl.nt0, colb = cg == 0 ? 0 : 32 * tl.nt0;
+  if (L >= total) {  // the split ragged tile's blocks (block-uniform)
+    const int slab = (int)(L - total), kt = a.kts - 1;
+    if (a.split_f == 4) {
+      if (cg == 0) tn_wave<P0, false, FASTG, 4>(a, smem, tid, c, h, rg, ntw, colb, slab, kt);
+      else tn_wave<P1, false, FASTG, 4>(a, smem, tid, c, h, rg, ntw, colb, slab, kt);
+    } else {
+      if (cg == 0) tn_wave<P0, false, FASTG, 2>(a, smem, tid, c, h, rg, ntw, colb, slab, kt);
+      else tn_wave<P1, false, FASTG, 2>(a, smem, tid, c, h, rg, ntw, colb, slab, kt);
+    }
+    return;
+  }
+  if (total % 8 == 0) L = (L % 8) * (total / 8) + L / 8;
+  const int slab = (int)(L / ktsf), kt = (int)(L % ktsf);
+  const bool fa = kt < a.kts_fast;  // block-uniform: this K tile lies inside A1 with 16-byte rows
   if (cg == 0) {
     if (fa) tn_wave<P0, true, FASTG>(a, smem, tid, c, h, rg, ntw, colb, slab, kt);
     else tn_wave<P0, false, FASTG>(a, smem, tid, c, h, rg, ntw, colb, slab, kt);
@@ -572,7 +595,11 @@ constexpr int kTrG = 8;
 __global__ __launch_bounds__(64 * kTrG) void dense_tn_reduce(const float *__restrict__ ws, int slabs, int64_t KN,
                                                             int N, float *dW, int64_t lddw, int accumulate,
                                                             const float *__restrict__ db_ws,
-                                                            float *__restrict__ db) {
+                                                            float *__restrict__ db, int64_t t_hi,
+                                                            int slabs_hi, int slabs_db) {
+  // elements t >= t_hi (the rows of a split ragged K tile) have slabs_hi partial slabs instead
+  if (t_hi <= 0) { t_hi = KN; slabs_hi = slabs; }
+  if (slabs_db <= 0) slabs_db = slabs;
   __shared__ float sm[kTrG][64];
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t total = KN + (db != nullptr ? N : 0);  // the db columns ride behind the dW elements
@@ -580,11 +607,12 @@ __global__ __launch_bounds__(64 * kTrG) void dense_tn_reduce(const float *__rest
     const int64_t t = t0 + o;
     float s = 0.f;
     if (t < KN) {
+      const int sl = t < t_hi ? slabs : slabs_hi;
 #pragma unroll 4
-      for (int q = grp; q < slabs; q += kTrG) s += ws[(int64_t)q * KN + t];
+      for (int q = grp; q < sl; q += kTrG) s += ws[(int64_t)q * KN + t];
     } else if (t < total) {
 #pragma unroll 4
-      for (int q = grp; q < slabs; q += kTrG) s += db_ws[(int64_t)q * N + (t - KN)];
+      for (int q = grp; q < slabs_db; q += kTrG) s += db_ws[(int64_t)q * N + (t - KN)];
     }
     sm[grp][o] = s;
     __syncthreads();
@@ -699,6 +727,46 @@ int tn_slabs(int64_t M, int kts, int ncts) {
   return (int)s;
 }
 
+// The launch plan of the tiled TN kernel (one place for the workspace query and the launch).
+struct TnPlan {
+  int kts, nct, slabs, split_f, live, slabs_r, smax;
+  int64_t rows_f, rows_r;
+};
+TnPlan tn_plan(int K, int N, int64_t M, bool allow_split) {
+  TnPlan p;
+  p.kts = (K + kRowsPerBlock - 1) / kRowsPerBlock;
+  p.nct = ((N + 31) / 32 + kMaxNB - 1) / kMaxNB;
+  p.slabs = tn_slabs(M, p.kts, p.nct);
+  p.split_f = 1;
+  p.live = 4;
+  p.slabs_r = 0;
+  const int rem = K - (p.kts - 1) * kRowsPerBlock;
+  const int live = (rem + 31) / 32;
+#ifndef RM_TN_SPLIT
+#define RM_TN_SPLIT 1
+#endif
+  // (only with float4 staging of G: with the per-element G loader the blocks are staging-bound and the
+  // ragged tile's longer slabs became the critical path - dcn_matrix's N = 429 went 17.3 -> 18.6 ms)
+  if (RM_TN_SPLIT && allow_split && p.kts >= 2 && live <= 2) {
+    // the ragged tile's blocks run about twice as fast per batch row (a quarter / half of the MFMA
+    // work per chunk, the same staging): half as many, twice as long slabs for it
+    int64_t sf = (int64_t)(256 / p.nct) * 2 / (2 * p.kts - 1);  // (kts - 1) sf + sf / 2 <= 256 / nct
+    const int64_t cap = (M + 511) / 512;
+    sf = sf < cap ? sf : cap;
+    sf = sf / 2 * 2;
+    if (sf >= 4) {
+      p.slabs = (int)sf;
+      p.split_f = 4 / live;
+      p.live = live;
+      p.slabs_r = (int)(sf / 2);
+    }
+  }
+  p.rows_f = ((M + p.slabs - 1) / p.slabs + TRC - 1) / TRC * TRC;
+  p.rows_r = p.slabs_r ? ((M + p.slabs_r - 1) / p.slabs_r + TRC - 1) / TRC * TRC : 0;
+  p.smax = p.slabs_r * p.split_f > p.slabs ? p.slabs_r * p.split_f : p.slabs;
+  return p;
+}
+
 }  // namespace
 
 extern "C" int64_t rm_dense_filter_workspace(int K, int N) {
@@ -761,9 +829,12 @@ extern "C" int rm_dense_fwd(const float *A1, int64_t lda1, int K1, const float *
 
 extern "C" int64_t rm_dense_wgrad_workspace(int K, int N, int64_t M) {
   if (K <= 0 || N <= 0 || M <= 0) return 0;
-  const int kts = (K + kRowsPerBlock - 1) / kRowsPerBlock;
-  const int nct = ((N + 31) / 32 + kMaxNB - 1) / kMaxNB;
-  int64_t need = (int64_t)tn_slabs(M, kts, nct) * ((int64_t)K * N + N);  // + the per-slab column sums (db)
+  int64_t need = 0;
+  for (int sp = 0; sp < 2; ++sp) {  // whichever plan the call takes (the split needs aligned G rows)
+    const TnPlan pl = tn_plan(K, N, M, sp != 0);
+    const int64_t n = (int64_t)pl.smax * K * N + (int64_t)pl.slabs * N;  // + the per-slab column sums (db)
+    need = n > need ? n : need;
+  }
   if (N <= kSkN) {  // the skinny path's one partial per 128 rows (whichever path the call takes)
     const int64_t sk = (tn_skinny_blocks(M) + tn_skinny_groups(M)) * (int64_t)K * N;
     need = sk > need ? sk : need;
@@ -795,17 +866,19 @@ extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float
     hipLaunchKernelGGL(dense_tn_fold_kernel, dim3((unsigned)rm_grid_cap((KNs + 255) / 256, 64), (unsigned)ngrp),
                        dim3(256), 0, st, workspace, nblk, kSkFold, KNs, ws2);
     hipLaunchKernelGGL(dense_tn_reduce, dim3(rm_grid_cap((KNs + 63) / 64, 4096)), dim3(64 * kTrG), 0, st, ws2,
-                       ngrp, KNs, N, dW, lddw, accumulate, (const float *)nullptr, (float *)nullptr);
+                       ngrp, KNs, N, dW, lddw, accumulate, (const float *)nullptr, (float *)nullptr,
+                       (int64_t)0, 0, 0);
     RM_CHECK_LAUNCH("rm_dense_wgrad(reduce)");
     return RM_OK;
   }
-  const int kts = (K + kRowsPerBlock - 1) / kRowsPerBlock;
+  const bool g_fast_rows = ldg % 4 == 0 && rm_aligned16(G) && (N % 4 == 0);
+  const TnPlan pl = tn_plan(K, N, M > 0 ? M : 1, g_fast_rows);
+  const int kts = pl.kts, nct = pl.nct;
   const int nbt = (N + 31) / 32;
-  const int nct = (nbt + kMaxNB - 1) / kMaxNB;
-  const int slabs = M > 0 ? tn_slabs(M, kts, nct) : 0;
+  const int slabs = M > 0 ? pl.slabs : 0;
+  float *db_ws = db ? workspace + (int64_t)pl.smax * K * N : nullptr;
   if (M > 0) {
-    int64_t slab_rows = (M + slabs - 1) / slabs;
-    slab_rows = (slab_rows + TRC - 1) / TRC * TRC;
+    const int64_t slab_rows = pl.rows_f;
     const int nb0 = nbt < kMaxNB ? nbt : kMaxNB;
     const size_t smem = kTnSmemFloats * sizeof(float);
     // K tiles whose A piece lies inside A1 with 16-byte rows are staged with float4 loads, the
@@ -813,11 +886,11 @@ extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float
     const bool g_fast = ldg % 4 == 0 && rm_aligned16(G) && (N % 4 == 0);
     const bool a_al = lda1 % 4 == 0 && rm_aligned16(A1);
     const int kts_fast = a_al ? K1 / kRowsPerBlock : 0;
-    RM_REQUIRE(slab_rows * (ldg > lda1 ? ldg : lda1) < ((int64_t)1 << 30),
+    RM_REQUIRE((pl.rows_r > slab_rows ? pl.rows_r : slab_rows) * (ldg > lda1 ? ldg : lda1) < ((int64_t)1 << 30),
                "rm_dense_wgrad: rows too long for 32-bit slab offsets");
     TNArgs a{A1, A2, lda1, lda2, K1, K2, G, ldg, N, M, slabs, kts, kts_fast, (a_al && K1 % 4 == 0 && K1 >= 4) ? 1 : 0,
-             slab_rows, workspace, db ? workspace + (int64_t)slabs * K * N : nullptr};
-    const dim3 grid((unsigned)(slabs * kts), (unsigned)nct);
+             pl.split_f, pl.live, pl.slabs_r, pl.rows_r, slab_rows, workspace, db_ws};
+    const dim3 grid((unsigned)(pl.split_f > 1 ? slabs * (kts - 1) + pl.slabs_r : slabs * kts), (unsigned)nct);
 #define RM_TN(P0, P1, FAST_)                                                                      \
   {                                                                                               \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_tn_kernel<P0, P1, FAST_>),     \
@@ -844,8 +917,9 @@ extern "C" int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float
   }
   const int64_t KN = (int64_t)K * N;
   hipLaunchKernelGGL(dense_tn_reduce, dim3(rm_grid_cap((KN + N + 63) / 64, 4096)), dim3(64 * kTrG), 0, st,
-                     workspace, slabs, KN, N, dW, lddw, accumulate,
-                     db ? workspace + (int64_t)slabs * KN : nullptr, db);  // (no slabs: db = 0)
+                     workspace, slabs, KN, N, dW, lddw, accumulate, (const float *)db_ws, db,  // (no slabs: db = 0)
+                     pl.split_f > 1 ? (int64_t)(kts - 1) * kRowsPerBlock * N : (int64_t)0,
+                     M > 0 ? pl.slabs_r * pl.split_f : 0, slabs);
   RM_CHECK_LAUNCH("rm_dense_wgrad(reduce)");
   return RM_OK;
 }

@@ -107,7 +107,10 @@ def test_dense_fwd_other_epilogues(hip_lib, M, K1, K2, N):
 @pytest.mark.parametrize("M,K1,K2,N", SHAPES + [(5000, 416, 13, 400), (3, 8, 0, 8),
                                                 # skinny G (N <= 8): the weighted-column-sum path
                                                 (5000, 416, 13, 7), (129, 32, 0, 1), (4100, 64, 3, 8),
-                                                (300, 30, 2, 5)])   # K1 % 4 != 0: tiled path
+                                                (300, 30, 2, 5),    # K1 % 4 != 0: tiled path
+                                                # ragged last K tile split over the block's SIMDs
+                                                (5000, 400, 0, 400), (4100, 272, 0, 96), (9000, 429, 0, 200),
+                                                (3000, 160, 13, 64)])
 def test_dense_wgrad(hip_lib, M, K1, K2, N):
     from recman_amd import ops
 
