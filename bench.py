@@ -209,7 +209,10 @@ def main():
     spec = eng.FeatureSpec([f"C{i + 1}" for i in range(w["F"])], [V] * w["F"],
                            [f"I{j + 1}" for j in range(w["Dn"])])
     hp = dict(w["hp"], embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=0.0, cin_l2_reg=0.0,
-              cross_layer_l2_reg=0.0)
+              cross_layer_l2_reg=0.0,
+              # uniform ids: a row is touched about once per batch -> streamed (non-temporal) row loads;
+              # --zipf: hot rows want the caches
+              table_row_reuse="cache" if a.zipf > 0 else "stream")
     sharded = world > 1 or a.force_sharded
     if sharded:
         from recman_amd import dist as rdist
@@ -351,6 +354,7 @@ def main():
                    "rows_per_field": V,
                    "dense_fields": w["Dn"], "emb_dim": w["D"], "hp": {k: v for k, v in w["hp"].items()},
                    "indices": "uniform" if a.zipf == 0 else f"zipf({a.zipf})",
+                   "table_row_loads": "cached" if a.zipf > 0 else "non-temporal (ids with little reuse per batch)",
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
                    "host_enqueue_ms_per_step": round(enqueue / a.steps * 1e3, 4),
                    "prewarm_s": a.prewarm,

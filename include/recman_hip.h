@@ -75,13 +75,18 @@ int rm_device_cus(void);
  *   lin_logit[B]      sum_f lin_w[lin_off[f]+idx] + dense . lin_w[dense block] + lin_w0
  * D must be a multiple of 4 and <= 256; table/E 16-byte aligned.
  */
+/* flags: RM_EMBED_STREAM_ROWS = load the table rows non-temporally (fused-row layout only).  For ids that
+ * touch a row about once per batch (uniformly hashed ids over a table far larger than the caches) the
+ * row lines then do not evict E from L2 / the Infinity Cache, which the next kernels read; ids with
+ * heavy reuse (Zipf) want the plain, cached loads. */
+enum { RM_EMBED_STREAM_ROWS = 1 };
 int rm_embed_fwd(const int64_t *idx, const float *table, int64_t table_ld,
                  const int64_t *field_off, const float *bias_table, int64_t bias_ld,
                  const float *lin_w, int64_t lin_ld, const int64_t *lin_off,
                  const float *lin_w_dense, const float *lin_w0, const float *dense, int Dn,
                  const float *mask_b, const float *mask_e, int64_t B, int F, int D,
                  float *E, float *fm_sum, float *fm_logit, float *lin_logit,
-                 rm_stream_t stream);
+                 int flags /* RM_EMBED_* */, rm_stream_t stream);
 
 /* Backward of the embedding + FM block w.r.t. the gathered rows: the IndexedSlices
  * values TF's autodiff produces for tf.nn.embedding_lookup (one row per (b,f)

@@ -539,7 +539,11 @@ class Engine:
             mask_b=fm_masks[0] if want_fm else None, mask_e=fm_masks[1] if want_fm else None,
             E=self.E, fm_sum=self.fm_sum if want_fm else None,
             fm_logit=self.fm_logit if want_fm else None,
-            lin_logit=self.lin_logit if self.use_linear else None)
+            lin_logit=self.lin_logit if self.use_linear else None,
+            # hp["table_row_reuse"] = "stream" (default): ids touch a row about once per batch
+            # (hashed ids over a table far beyond the caches) -> non-temporal row loads keep E in the
+            # caches for the MLP / CIN kernels; "cache": heavy id reuse (Zipf-like), plain loads
+            stream_rows=self.hp.get("table_row_reuse", "stream") == "stream")
 
     def _mv_entry(self, f):
         """(offsets, ids, vals) of scratch-row field f from the mv dict: a multi-valued feature

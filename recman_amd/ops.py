@@ -35,8 +35,9 @@ def _chk(t, name, dtype, shape=None, allow_none=False):
 def embed_fwd(idx, table, field_off, *, bias_table=None, bias_ld=1, lin_w=None, lin_ld=1,
               lin_off=None, lin_w_dense=None, lin_w0=None, dense=None, mask_b=None, mask_e=None,
               E=None, fm_sum=None, fm_logit=None, lin_logit=None, table_ld=None, D=None,
-              bias_col=None, lin_col=None):
+              bias_col=None, lin_col=None, stream_rows=False):
     """Gather + FM + linear forward (see rm_embed_fwd in include/recman_hip.h).
+    stream_rows: RM_EMBED_STREAM_ROWS - non-temporal row loads (ids with little reuse per batch).
     `table` is [R, table_ld]; D defaults to table.shape[1].  bias_col / lin_col: the FM
     bias / sparse linear weight live in that column of the table row itself (fused rows)."""
     B, F = idx.shape
@@ -62,7 +63,7 @@ def embed_fwd(idx, table, field_off, *, bias_table=None, bias_ld=1, lin_w=None, 
         _chk(E, "E", F32, (B, F, D), allow_none=True),
         _chk(fm_sum, "fm_sum", F32, (B, D), allow_none=True),
         _chk(fm_logit, "fm_logit", F32, (B,), allow_none=True),
-        _chk(lin_logit, "lin_logit", F32, (B,), allow_none=True), _stream())
+        _chk(lin_logit, "lin_logit", F32, (B,), allow_none=True), 1 if stream_rows else 0, _stream())
 
 
 def embed_bwd(d_rows, *, E=None, fm_sum=None, dE_up=None, g_fm=None, mask_b=None, mask_e=None,
