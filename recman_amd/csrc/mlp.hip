@@ -31,6 +31,20 @@ __device__ __forceinline__ float actg(float o, int act) {
   return 1.f;
 }
 
+#ifndef RM_MLP_NT
+#define RM_MLP_NT 3  // bit 0: non-temporal d_rows stores in mlp_bwd, bit 1: non-temporal x loads in mlp_bwd (last use of E in the MLP; together -1.3 % on the DeepFM step, each alone nothing: profiles/r01_p11)
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4_stream(float *p, const float4 &v) {
+  f4v t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));
+}
+__device__ __forceinline__ float4 load4_stream(const float *p) {
+  const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+
 struct MlpW {
   const float *W[kMaxNL];  // W[0] [K,H0], W[l] [H_{l-1}, H_l]
   const float *b[kMaxNL];
@@ -396,7 +410,11 @@ __device__ __forceinline__ void load_ktile(float4 (&v)[4], const float *__restri
     for (int q = 0; q < 4; ++q) {
       int64_t b = ex0 + (lane >> 3) + 8 * q;
       b = b < B ? b : B - 1;
+#if RM_MLP_NT & 2
+      v[q] = load4_stream(xe + b * FD + k);
+#else
       v[q] = *reinterpret_cast<const float4 *>(xe + b * FD + k);
+#endif
     }
     return;
   }
@@ -668,7 +686,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
             float4 o = *reinterpret_cast<const float4 *>(xb + row * kLDT + 4 * piece);
             const float4 s4 = *reinterpret_cast<const float4 *>(gS + row * D + (k % D));
             o.x += s4.x; o.y += s4.y; o.z += s4.z; o.w += s4.w;
+#if RM_MLP_NT & 1
+            if (br < B && k < FD) store4_stream(d_rows + br * FD + k, o);
+#else
             if (br < B && k < FD) *reinterpret_cast<float4 *>(d_rows + br * FD + k) = o;
+#endif
           }
         } else {
 #pragma unroll 1  // (register-bound kernel: the unrolled form with its global loads spilled 56 VGPRs)
