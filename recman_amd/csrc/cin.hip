@@ -105,7 +105,7 @@ __global__ void cin_prep_fwd_kernel(const float *__restrict__ W, int m, int H, i
 // MT = 1 (8 waves, 2 per SIMD) lets one wave's s_waitcnt / barrier time be covered by its
 // SIMD partner: rocprofv3 showed 26 % of wave-cycles parked in waits at 1 wave per SIMD.
 #ifndef RM_CIN_EXP
-#define RM_CIN_EXP 0  // ablation builds only (profiles/r01_p11): 1 = no per-chunk barrier, 2 = no output stores (cin_fwd)
+#define RM_CIN_EXP 0  // ablation builds only (profiles/r01_p11): 1 = no per-chunk barrier, 2 = no output stores, 4 = non-temporal output stores (cin_fwd; none of them moves layer 1)
 #endif
 template <int NT, int MT>
 __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
@@ -256,7 +256,14 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
         v.z = act_apply(acc[mt][nt][4 * g + 2] + bn, act);
         v.w = act_apply(acc[mt][nt][4 * g + 3] + bn, act);
         if (b < B && n < N) {
-#if !(RM_CIN_EXP & 2)
+#if RM_CIN_EXP & 4
+          {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            f4v t4;
+            t4.x = v.x; t4.y = v.y; t4.z = v.z; t4.w = v.w;
+            __builtin_nontemporal_store(t4, reinterpret_cast<f4v *>(out + (b * N + n) * D + d));
+          }
+#elif !(RM_CIN_EXP & 2)
           *reinterpret_cast<float4 *>(out + (b * N + n) * D + d) = v;
 #endif
           if (want_pool && n >= pool_from) atomicAdd(pool_s + bl * Np + n, v.x + v.y + v.z + v.w);
