@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--table-row-reuse", default="", choices=["", "stream", "cache"],
+                    help="gather kernel's row loads: stream = non-temporal (default for uniform ids), "
+                         "cache = plain (default with --zipf)")
     ap.add_argument("--prewarm", type=float, default=0.25,
                     help="seconds of untimed steps BEFORE the W warmup steps (GPU clock ramp); 0 = none")
     ap.add_argument("--workload", default="deepfm", choices=sorted(WORKLOADS))
@@ -212,7 +215,7 @@ def main():
               cross_layer_l2_reg=0.0,
               # uniform ids: a row is touched about once per batch -> streamed (non-temporal) row loads;
               # --zipf: hot rows want the caches
-              table_row_reuse="cache" if a.zipf > 0 else "stream")
+              table_row_reuse=a.table_row_reuse or ("cache" if a.zipf > 0 else "stream"))
     sharded = world > 1 or a.force_sharded
     if sharded:
         from recman_amd import dist as rdist
@@ -354,7 +357,8 @@ def main():
                    "rows_per_field": V,
                    "dense_fields": w["Dn"], "emb_dim": w["D"], "hp": {k: v for k, v in w["hp"].items()},
                    "indices": "uniform" if a.zipf == 0 else f"zipf({a.zipf})",
-                   "table_row_loads": "cached" if a.zipf > 0 else "non-temporal (ids with little reuse per batch)",
+                   "table_row_loads": ("cached" if hp["table_row_reuse"] == "cache"
+                                       else "non-temporal (ids with little reuse per batch)"),
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
                    "host_enqueue_ms_per_step": round(enqueue / a.steps * 1e3, 4),
                    "prewarm_s": a.prewarm,
