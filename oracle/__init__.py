@@ -19,7 +19,8 @@ TensorFlow, which is not installed here and cannot be fetched, so the oracle
 cannot be checked against a run of the reference.  What pins it instead:
 
 * the CIN walk-through of ``recman/notes/xDeepFM.ipynb`` cell 6 (inputs in the
-  notebook, outputs hand-derived: the notebook stores none) - tests/test_oracle_kat.py;
+  notebook, outputs hand-derived: the notebook stores none) - tests/test_oracle.py
+  (test_cin_notebook_kat, test_cin_z_layout_is_i_major);
 * two independent restatements (numpy float64 and torch float32) that must
   agree, closed-form identities (FM pairwise-dot, cross network on integer
   data) and finite-difference gradient checks;

@@ -34,9 +34,24 @@ def hipcc():
     return exe
 
 
-def build(force=False, verbose=True, extra_flags=()):
-    if not force and not _stale():
+def clean_experiments(verbose=True):
+    """Removes experiment builds (librecman_*.so other than the product library) from csrc/: they
+    would travel to the GPU box with every gpurun push.  Experiment builds belong under build/."""
+    for p in glob.glob(os.path.join(CSRC, "librecman_*.so")):
+        if os.path.abspath(p) != os.path.abspath(LIB):
+            if verbose:
+                print(f"[build] removing stray experiment build {p}", flush=True)
+            os.remove(p)
+
+
+def build(force=False, verbose=True, extra_flags=(), out=None):
+    """out: another output path (an experiment build, e.g. build/librecman_x.so, loaded through
+    RECMAN_HIP_LIB; its objects go next to it) - the product library is `LIB`."""
+    clean_experiments(verbose)
+    if out is None and not force and not _stale():
         return LIB
+    if out is not None:
+        return _build_variant(out, extra_flags, verbose)
     objs = []
     procs = []
     for src in sources():
@@ -57,6 +72,29 @@ def build(force=False, verbose=True, extra_flags=()):
     return LIB
 
 
+def _build_variant(out, extra_flags, verbose):
+    out = os.path.abspath(out)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    tag = os.path.splitext(os.path.basename(out))[0]
+    objs, procs = [], []
+    for src in sources():
+        obj = os.path.join(os.path.dirname(out), f"{tag}_{os.path.basename(src)[:-4]}.o")
+        cmd = [hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-c", src, "-o", obj,
+               "-Wall", "-Wno-unused-function", *extra_flags]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    subprocess.check_call([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out])
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    # python -m recman_amd.build [--force] [--out build/librecman_x.so -DFLAG ...]
+    argv = sys.argv[1:]
+    out = argv[argv.index("--out") + 1] if "--out" in argv else None
+    flags = [a for a in argv if a.startswith("-D")]
+    print(build(force="--force" in argv, out=out, extra_flags=flags))

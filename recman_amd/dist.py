@@ -492,8 +492,8 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             """Fixed-capacity layout only.  Captures the three compute stretches of every
             micro-batch - route | owner-side gather | embed..loss..backward..pack - as hipGraphs
             over static buffers; fwd_bwd then replays them with the RCCL calls issued eagerly in
-            between (a replayed graph that CONTAINS the all_to_all faulted on this stack, see
-            DESIGN.md).  A step costs 3 graph launches + 3 collectives per micro-batch on the host
+            between (the whole step as ONE graph with the RCCL calls inside is bench.py's opt-in
+            --graph-sharded: it could only be exercised at world size 1).  A step costs 3 graph launches + 3 collectives per micro-batch on the host
             instead of ~25 kernel launches.  idx / dense / y become the static input buffers:
             later calls with other tensors of the same shape are copied into them."""
             from types import SimpleNamespace

@@ -6,9 +6,9 @@ are views of it), a workspace sized once per batch size, and enqueues a fixed
 sequence of HIP kernels (recman_amd/ops.py -> librecman_hip.so) on the current
 stream - which makes a whole step capturable in a hipGraph (`capture=True`).
 
-The MLP ("DNN", layers.py:576-609) GEMMs go to rocBLAS/hipBLASLt through
-torch.mm: SURVEY.md section 7 step 6 - a library GEMM, not one of the hand-written
-kernels the north star names.
+The MLP ("DNN", layers.py:576-609) runs on hand-written f32-MFMA kernels as well:
+csrc/mlp.hip (all layers fused, hidden widths <= 32) or csrc/gemm.hip (one launch per
+GEMM with fused epilogues, any width); no library GEMM is left on the path.
 
 Variable names are the reference's (layers.py:96,106,318,324,533,541,548,558,564,
 572,663,673,687,693) so state_dict() round-trips with its checkpoints' keys.

@@ -362,7 +362,24 @@ class DataInputs(dict):
         self.idx = np.concatenate(cols, axis=1) if sparse else np.zeros((n, 0), np.int64)
         self.dense = (np.concatenate([self[f.name] for f in dense], axis=1).astype(np.float32)
                       if dense else np.zeros((n, 0), np.float32))
+        self.check_ranges(feat_dict)
         return self
+
+    def check_ranges(self, feat_dict):
+        """Every id must address a row of ITS feature: 0 <= id < feat_size.  The kernels compute
+        field_off[f] + id without a bound (an undersized SparseFeat(name, feat_size) would read -
+        and, in the optimizer, write - the next feature's rows or past the table); the reference
+        fails loudly at the same spot (tf.nn.embedding_lookup raises InvalidArgument,
+        layers.py:117-128).  One pass over arrays that are encoded once per fit()."""
+        for j, f in enumerate(feat_dict.embedding_feats):
+            ids = self.mv[f.name].ids if f.name in self.mv else self.idx[:, j]
+            if ids.size == 0:
+                continue
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= f.feat_size:
+                raise ValueError(
+                    f"feature {f.name!r}: encoded id {lo if lo < 0 else hi} outside [0, {f.feat_size}) - "
+                    f"feat_size={f.feat_size - 1} is smaller than the fitted vocabulary")
 
     @property
     def y(self):

@@ -170,3 +170,36 @@ def test_sparse_value_feat_encodes_pairs():
     assert unseen.ids.tolist() == [0] and unseen.vals.tolist() == [1.5]
     fd["tagw"].set_weights({"a": 3.0})
     assert fd["tagw"].weights.tolist() == [0.0, 3.0, 0.0, 0.0]
+
+
+def test_ids_outside_feat_size_raise():
+    """An undersized feat_size must fail on the host (the reference's tf.nn.embedding_lookup raises
+    InvalidArgument): the kernels address field_off[f] + id without a bound."""
+    from recman_amd.th.inputs import MultiValCsvFeat
+
+    df = pd.DataFrame({"s": ["a", "b", "c", "d"], "t": ["x", "x", "y", "y"]})
+    fd = FeatureDictionary()
+    fd["s"] = SparseFeat("s", 2)   # 4 fitted classes need feat_size >= 4
+    fd["t"] = SparseFeat("t", 2)
+    fd.initialize(df)
+    with pytest.raises(ValueError, match="feature 's'"):
+        DataInputs().load(fd, df)
+    fd["s"] = SparseFeat("s", 4)
+    fd.initialize(df)
+    assert DataInputs().load(fd, df).idx[:, 0].tolist() == [1, 2, 3, 4]
+    # an encoder-less feature handing in raw ids (negative / too large) and CSR tag ids
+    raw = SparseFeat("r", 3, encoder=None)
+    raw.encoder = None
+    fd2 = FeatureDictionary()
+    fd2["r"] = raw
+    with pytest.raises(ValueError, match="feature 'r'"):
+        DataInputs().load(fd2, pd.DataFrame({"r": [0, 1, -1]}))
+    with pytest.raises(ValueError, match="feature 'r'"):
+        DataInputs().load(fd2, pd.DataFrame({"r": [0, 4, 1]}))
+    assert DataInputs().load(fd2, pd.DataFrame({"r": [0, 3, 1]})).idx.reshape(-1).tolist() == [0, 3, 1]
+    mv = MultiValCsvFeat("g", tags=("p", "q"))
+    mv.tag_hash_table["bad"] = 7   # a corrupted tag table: id beyond feat_size
+    fd3 = FeatureDictionary()
+    fd3["g"] = mv
+    with pytest.raises(ValueError, match="feature 'g'"):
+        DataInputs().load(fd3, pd.DataFrame({"g": ["p|bad"]}))
