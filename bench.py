@@ -4,10 +4,27 @@ of every parameter, optimizer step excluded) on synthetic Criteo-shaped batches.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload deepfm|xdeepfm|dcn]
 
-N = 1 runs in this process; N > 1 is launched by the driver as
-`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (one rank
-per GPU, RCCL), the embedding table row-sharded over the ranks (recman_amd/dist.py),
-per-GPU batch fixed (weak scaling).  Rank 0 prints ONE JSON line.
+N = 1 runs in this process.  N > 1: one rank per GPU over RCCL, the embedding table
+row-sharded over the ranks (recman_amd/dist.py), per-GPU batch fixed (weak scaling).
+The ranks are started either by the driver (`python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`: WORLD_SIZE is set) or, when WORLD_SIZE is
+unset, by this script itself: BEFORE any GPU call it starts `torch.distributed.run`
+as a child process, relays rank 0's JSON line and exits with the child's code.
+Rank 0 prints ONE JSON line.
+
+The default run (N = 1, no --workload) measures BASELINE configs[1] (DeepFM) as the
+contract line - `value`, `roofline`, `cpu_baseline` - and adds, in the same line,
+`workloads.xdeepfm` (configs[2], CIN on the f32 MFMA roofline) and `workloads.dcn`
+(configs[3], dense GEMM on MFMA + the fused cross kernels on HBM), each with its own
+`ms_per_step`, `value`, `roofline(s)` and `cpu_baseline`, plus `zipf` (the DeepFM step
+with Zipf(1.05) ids).  `--workload X` (or --only) measures that workload alone.
+
+`roofline.traffic`: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and
+WRITE_SIZE each in its own `--pmc ... --kernel-trace` run, FETCH_SIZE doubled as
+MI355X_MICROARCH.md prescribes for gfx950) of THIS build, collected live by two child
+processes (`bench.py --pmc-child`, the roofline kernels only) started before this
+process touches the GPU; `traffic_live` says whether that worked - otherwise the value
+comes from the committed profile named in `traffic_source`, or is null.
 
 Workloads (BASELINE.json `configs`), seed 2019, dropout keep 1,
 embedding_l2_reg 0, weights N(0, 0.01), indices uniform over each field's vocabulary:
@@ -18,9 +35,15 @@ embedding_l2_reg 0, weights N(0, 0.01), indices uniform over each field's vocabu
   dcn_matrix        (extra)    : the same with matrix cross layers x0 o (W x_l + b) + x_l
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -30,6 +53,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
+METRIC = "examples/sec fwd+bwd, Criteo-shape batch 65536; % HBM and MFMA roofline"
 
 WORKLOADS = {
     "deepfm": dict(model="deepfm", B=65536, D=16, F=26, V=1_000_001, Dn=13,
@@ -49,9 +73,12 @@ WORKLOADS = {
                        hp=dict(deep_hidden_units=(400, 400), deep_activation="relu", cross_layer_num=6,
                                cross_type="matrix")),
 }
+CONFIG_NO = {"deepfm": 1, "xdeepfm": 2, "dcn": 3, "xdeepfm_100m": 4}
+# committed PMC profiles of earlier builds: the fallback when the live PMC passes are unavailable
+TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "traffic.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -61,12 +88,24 @@ def parse():
                          "cache = plain (default with --zipf)")
     ap.add_argument("--prewarm", type=float, default=0.25,
                     help="seconds of untimed steps BEFORE the W warmup steps (GPU clock ramp); 0 = none")
-    ap.add_argument("--workload", default="deepfm", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="measure this workload alone (default: deepfm as the contract line + the "
+                         "xdeepfm / dcn / zipf sub-records)")
+    ap.add_argument("--only", action="store_true",
+                    help="no sub-records: the named (or default deepfm) workload alone")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (tests)")
     ap.add_argument("--vocab", type=int, default=0, help="override rows per field (tests)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="skip the separately-reported optimizer step")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not start the rocprofv3 --pmc child passes (roofline.traffic then comes from "
+                         "the committed profile, tagged traffic_live=false)")
+    ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # comma list of workloads
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent for indices (0 = uniform)")
+    ap.add_argument("--cpu-budget", type=float, default=0.0,
+                    help="seconds of CPU-baseline work per workload (default 20 for the contract line, "
+                         "12 for the sub-records)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded engine even at world size 1 (rehearsal)")
     ap.add_argument("--no-graph-segments", action="store_true",
@@ -83,9 +122,49 @@ def parse():
                     help="row-sharded exchange layout: fixed capacity (equal splits, no host sync, one "
                          "hipGraph per step; falls back when a batch overflows) or dynamic split sizes; "
                          "auto = fixed for uniform indices, dynamic for --zipf")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------- self-launch (N > 1)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n, argv, port=None, python=None):
+    """The torch.distributed.run command line that starts n ranks of this script."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()),
+            os.path.abspath(__file__), *argv]
+
+
+def self_launch(n, argv):
+    """--gpus N > 1 without WORLD_SIZE: start the N ranks as CHILD processes (never exec, and before
+    this process has made any GPU call), relay rank 0's JSON line, return the child's exit code."""
+    cmd = launch_command(n, argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line = None
+    for out in p.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("[bench] the ranks exited 0 without a JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+# ---------------------------------------------------------------------- inputs
 def synth_inputs(w, B, V, device, seed, zipf=0.0):
     g = torch.Generator(device=device).manual_seed(seed)
     if zipf > 0:
@@ -108,17 +187,6 @@ def init_engine(engine, seed):
         for s in range(0, flat.numel(), 1 << 26):
             e = min(flat.numel(), s + (1 << 26))
             flat[s:e] = torch.randn(e - s, generator=g, device=engine.device) * 0.01
-
-
-def algorithmic_bytes_embed_fwd(B, F, D, Dn, fm, lin):
-    """SURVEY.md section 8d, per launch of rm_embed_fwd: idx + gathered rows (+ bias
-    and linear entries) read, E (+ S, logits) written."""
-    per = F * 8 + F * 4 * D + F * 4 * D  # idx, rows read, E written
-    if fm:
-        per += F * 4 + 4 * D + 4  # bias entries, S, fm_logit
-    if lin:
-        per += F * 4 + Dn * 4 + 4
-    return B * per
 
 
 def cpu_baseline(w, hp, idx, dense, y, engine, budget_s=20.0):
@@ -180,33 +248,122 @@ def cpu_baseline(w, hp, idx, dense, y, engine, budget_s=20.0):
                        + (f", CIN in chunks of {chunk_max}" if chunk_max < sample else "")), logit, sample
 
 
-def main():
-    a = parse()
-    w = dict(WORKLOADS[a.workload])
-    B = a.batch or w["B"]
-    V = a.vocab or w["V"]
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    # RECMAN_REHEARSE_ONE_GPU=1: every rank on GPU 0 with gloo (host-staged) collectives - a
-    # rehearsal of the multi-rank control flow on a one-GPU box, not a measurement
-    rehearse = os.environ.get("RECMAN_REHEARSE_ONE_GPU", "0") == "1"
-    if rehearse:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1 or "RANK" in os.environ:
-        import torch.distributed as dist
+# ---------------------------------------------------------------------- PMC traffic (child passes)
+PMC_LAUNCHES = 3  # launches of each roofline kernel a --pmc-child makes at the end of its run
 
-        if rehearse:
-            dist.init_process_group("gloo")
+
+def under_profiler():
+    env = os.environ
+    return ("rocprof" in env.get("LD_PRELOAD", "") or "ROCP_TOOL_LIBRARIES" in env
+            or "ROCPROFILER_REGISTER_FORCE_LOAD" in env or "ROCPROF_OUTPUT_PATH" in env)
+
+
+def pmc_passes(workloads, timeout_s=240):
+    """Runs `rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --pmc-child <workloads>` once
+    per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass) and returns
+    {workload: {kernel symbol: {"FETCH_SIZE": kb, "WRITE_SIZE": kb}}} averaged over the PMC_LAUNCHES
+    launches the child makes of each roofline kernel between two marker kernels; {} (+ a reason) when
+    rocprofv3 is unavailable or fails.
+    Must run BEFORE this process makes a GPU call (the children use the GPU alone)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or under_profiler():
+        return {}, "rocprofv3 not available (or this run is itself profiled)"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="recman_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            plan = os.path.join(tmp, f"plan_{counter}.json")
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   shutil.which("python3") or sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", ",".join(workloads), "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(env, RECMAN_PMC_PLAN=plan), timeout=timeout_s,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if r.returncode != 0 or not os.path.exists(plan):
+                return {}, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-300:]}"
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                rows += list(csv.DictReader(open(f)))
+            err = reduce_counter(rows, json.load(open(plan)), counter, out)
+            if err:
+                return {}, err
+        return out, None
+    except Exception as e:  # a diagnostic extra: never let it break the contract line
+        return {}, f"PMC passes failed: {type(e).__name__}: {str(e)[:200]}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+MARKER = "rm_profile_marker_kernel"
+
+
+def reduce_counter(rows, plan, counter, out):
+    """rows: the dicts of a rocprofv3 counter_collection.csv; plan: [(workload, kernel symbol), ...] in
+    the order the child ran its probes, each bracketed by two rm_profile_marker launches.  Stores the
+    average Counter_Value of the probe's launches in out[workload][symbol][counter].  Returns an
+    error text or None."""
+    rows = sorted((x for x in rows if x.get("Counter_Name") == counter), key=lambda x: int(x.get("Dispatch_Id", 0)))
+    marks = [i for i, x in enumerate(rows) if MARKER in x["Kernel_Name"]]
+    if len(marks) != 2 * len(plan):
+        return f"PMC pass ({counter}): {len(marks)} marker dispatches for {len(plan)} probes"
+    for k, (wname, symbol) in enumerate(plan):
+        seg = rows[marks[2 * k] + 1: marks[2 * k + 1]]
+        vals = [float(x["Counter_Value"]) for x in seg if symbol in x["Kernel_Name"]]
+        if len(vals) != PMC_LAUNCHES:
+            return f"PMC pass ({counter}): {len(vals)} launches of {symbol} between its markers, expected {PMC_LAUNCHES}"
+        out.setdefault(wname, {}).setdefault(symbol, {})[counter] = sum(vals) / len(vals)
+    return None
+
+
+def pmc_child(a):
+    """The profiled child: per workload one engine, one warm step, then PMC_LAUNCHES launches of each
+    roofline kernel (the parent reads the counters of exactly those dispatches)."""
+    from recman_amd import ops
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    plan = []
+    for name in a.pmc_child.split(","):
+        w = WORKLOADS[name]
+        engine, idx, dense, y, _ = make_engine(a, w, w["B"], w["V"], dev, 0, 1, False)
+        engine.fwd_bwd(idx, dense, y)
+        torch.cuda.synchronize()
+        for p in engine.roofline_probes(idx, dense, y):
+            ops.profile_marker(len(plan))
+            for _ in range(PMC_LAUNCHES):
+                p["fn"]()
+            ops.profile_marker(len(plan))
+            torch.cuda.synchronize()
+            plan.append((name, p["symbol"]))
+        del engine, idx, dense, y
+        torch.cuda.empty_cache()
+    with open(os.environ["RECMAN_PMC_PLAN"], "w") as f:
+        json.dump(plan, f)
+
+
+def attach_traffic(roofs, wname, live, fallback):
+    """Adds traffic (HBM bytes per launch: FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes) to each roofline."""
+    for r in roofs:
+        c = (live.get(wname) or {}).get(r["symbol"])
+        if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            r["traffic"] = round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, 0)
+            r["traffic_live"] = True
+            r["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this run "
+                                   f"(avg of {PMC_LAUNCHES} launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            fb = (fallback.get(wname) or {}).get(r["symbol"])
+            r["traffic"] = fb["bytes"] if fb else None
+            r["traffic_live"] = False
+            if fb:
+                r["traffic_source"] = fb["source"]
+        if r["traffic"] and r["bound"] == "hbm":
+            # the same launch priced on the bytes the counters saw instead of the algorithmic ones
+            r["frac_traffic"] = round(r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
 
+
+# ---------------------------------------------------------------------- one workload
+def make_engine(a, w, B, V, dev, rank, world, sharded, zipf=0.0):
     from recman_amd import engine as eng
 
     spec = eng.FeatureSpec([f"C{i + 1}" for i in range(w["F"])], [V] * w["F"],
@@ -215,19 +372,24 @@ def main():
               cross_layer_l2_reg=0.0,
               # uniform ids: a row is touched about once per batch -> streamed (non-temporal) row loads;
               # --zipf: hot rows want the caches
-              table_row_reuse=a.table_row_reuse or ("cache" if a.zipf > 0 else "stream"))
-    sharded = world > 1 or a.force_sharded
+              table_row_reuse=a.table_row_reuse or ("cache" if zipf > 0 else "stream"))
     if sharded:
         from recman_amd import dist as rdist
 
-        fixed = a.exchange == "fixed" or (a.exchange == "auto" and a.zipf == 0)
+        fixed = a.exchange == "fixed" or (a.exchange == "auto" and zipf == 0)
         micro = a.micro_batches or (2 if world > 1 else 1)
         engine = rdist.make_sharded_engine(w["model"], spec, w["D"], hp, dev, rank, world,
                                            capacity_factor=1.0 if fixed else None, micro_batches=micro)
     else:
         engine = eng.ENGINES[w["model"]](spec, w["D"], hp, device=dev)
     init_engine(engine, 2019)
-    idx, dense, y = synth_inputs(w, B, V, dev, 2019 + rank, a.zipf)
+    idx, dense, y = synth_inputs(w, B, V, dev, 2019 + rank, zipf)
+    return engine, idx, dense, y, hp
+
+
+def time_steps(a, engine, idx, dense, y, sharded, world, dist, rehearse, dev, steps, warmup):
+    """W warmup + K timed steps of engine.fwd_bwd -> (ms per step, host enqueue ms, graph kind, fixed)."""
+    # (the captured graph / replay closure are dropped on return: they pin the capture's memory pool)
 
     def step():
         return engine.fwd_bwd(idx, dense, y)
@@ -307,11 +469,11 @@ def main():
             for _ in range(20):
                 run()
             torch.cuda.synchronize()
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         run()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         run()
     enqueue = time.perf_counter() - t0  # host time to enqueue the steps (launch-bound when ~= elapsed)
     barrier()
@@ -322,97 +484,188 @@ def main():
         t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    ms = elapsed / a.steps * 1e3
-    value = world * B * a.steps / elapsed
+    kind = "segments between the collectives" if segments else graph is not None
+    return elapsed / steps * 1e3, enqueue / steps * 1e3, kind, fixed
 
-    # ---- roofline of the dominant hand-written kernel, HIP events on its stream ----
+
+def step_hbm(w, B, ms):
+    """algorithmic bytes of the embedding+FM forward AND backward per batch
+    (idx, rows, E, S, g, dE, gradient rows) over the whole step time."""
+    F, D = w["F"], w["D"]
+    fwd = B * F * (8 + 4 * D + 4) + B * 4 + B * F * 4 * D
+    bwd = B * F * (8 + 4 * D + 4 * D + 4 * D + 4) + B * 4
+    gbs = (fwd + bwd) / (ms * 1e-3) / 1e9
+    return {"algorithmic_bytes": fwd + bwd, "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "what": "embed+FM fwd+bwd algorithmic bytes of SURVEY.md 8d over the WHOLE step's time"}
+
+
+def measure(a, wname, dev, rank, world, dist, rehearse, sharded, live_traffic, fallback, steps, warmup,
+            cpu_budget, zipf=0.0, want_cpu=True, want_opt=True):
+    """One workload at the current world size -> its record (dict)."""
+    w = dict(WORKLOADS[wname])
+    B = a.batch or w["B"]
+    V = a.vocab or w["V"]
+    engine, idx, dense, y, hp = make_engine(a, w, B, V, dev, rank, world, sharded, zipf)
+    ms, enq_ms, graph_kind, fixed = time_steps(a, engine, idx, dense, y, sharded, world, dist, rehearse, dev,
+                                               steps, warmup)
+    value = world * B / (ms * 1e-3)
+
+    # ---- rooflines of the hand-written hot kernels, HIP events on the stream they run on ----
     # (sharded: only for the models whose dominant kernel is the gather; rank 0, local kernel only)
-    roof = None
-    if not sharded:
-        roof = engine.roofline_probe(idx, dense, y, iters=max(10, min(a.steps, 50)))
-    elif rank == 0 and w["model"] == "deepfm":
-        roof = engine.roofline_probe(idx, dense, y, iters=max(10, min(a.steps, 50)))
-    if roof is not None and not sharded and a.workload == "deepfm" and B == 65536 and V == 1_000_001 and a.zipf == 0:
-        # HBM bytes per launch of the gather kernel from rocprofv3 PMC passes of this same command
-        # (FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes on gfx950, + WRITE_SIZE):
-        # profiles/r01_p5_deepfm_fused.md
-        roof["traffic"] = 375.0e6
-        roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, profiles/r01_p5_deepfm_fused.md"
-    if (roof is not None and not sharded and B == w["B"] and V == 1_000_001 and a.zipf == 0
-            and a.workload in ("xdeepfm", "dcn")):
-        # HBM bytes per launch of the dominant MFMA kernel (same PMC recipe): profiles/r01_p10_traffic.md
-        roof["traffic"] = {"xdeepfm": 475.0e6 + 591.0e6, "dcn": 249.0e6 + 217.0e6}[a.workload]
-        roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2) / --pmc WRITE_SIZE, profiles/r01_p10_traffic.md"
+    roofs = []
+    if not sharded or (rank == 0 and w["model"] == "deepfm"):
+        roofs = engine.roofline_probe_all(idx, dense, y, iters=max(10, min(steps, 50)))
+        full = not sharded and B == w["B"] and V == w["V"] and zipf == 0
+        attach_traffic(roofs, wname, live_traffic if full else {}, fallback if full else {})
+    for r in roofs:
+        r.pop("fn", None)
 
-    out = {
-        "metric": "examples/sec fwd+bwd, Criteo-shape batch 65536; % HBM and MFMA roofline",
-        "value": round(value, 1), "unit": "examples/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (f"{a.workload} (BASELINE configs[{1 + ['deepfm', 'xdeepfm', 'dcn'].index(a.workload)}])"
-                                if a.workload in ("deepfm", "xdeepfm", "dcn") else
-                                "xdeepfm_100m (BASELINE configs[4])" if a.workload == "xdeepfm_100m" else
-                                f"{a.workload} (extra workload, not a BASELINE config)"),
+    rec = {
+        "value": round(value, 1), "unit": "examples/s", "ms_per_step": round(ms, 4),
+        "config": {"workload": (f"{wname} (BASELINE configs[{CONFIG_NO[wname]}])" if wname in CONFIG_NO
+                                else f"{wname} (extra workload, not a BASELINE config)"),
                    "batch_per_gpu": B, "batch_all_gpus": B * world, "sparse_fields": w["F"],
                    "rows_per_field": V,
                    "dense_fields": w["Dn"], "emb_dim": w["D"], "hp": {k: v for k, v in w["hp"].items()},
-                   "indices": "uniform" if a.zipf == 0 else f"zipf({a.zipf})",
+                   "indices": "uniform" if zipf == 0 else f"zipf({zipf})",
                    "table_row_loads": ("cached" if hp["table_row_reuse"] == "cache"
                                        else "non-temporal (ids with little reuse per batch)"),
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
-                   "host_enqueue_ms_per_step": round(enqueue / a.steps * 1e3, 4),
-                   "prewarm_s": a.prewarm,
-                   "hipgraph": ("segments between the collectives" if segments else graph is not None),
+                   "host_enqueue_ms_per_step": round(enq_ms, 4),
+                   "prewarm_s": a.prewarm, "hipgraph": graph_kind,
                    "table": (f"row-sharded mod {world}, fused [D+4] rows, all_to_all over xGMI, "
                              + ("fixed-capacity exchange (equal splits, no host sync)" if fixed
                                 else "dynamic split sizes (one host sync per batch)")
                              + f", {engine.micro_batches} micro-batch(es) per step") if sharded
                    else "single GPU"},
-        "roofline": roof,
+        "roofline": roofs[0] if roofs else None,
     }
-    if rank == 0 and not sharded:
-        # reported separately (the headline metric is fwd+bwd only): the lazy row-wise Adam step
-        # on the table rows this batch touched + dense Adam on the dense parameters
+    if len(roofs) > 1:
+        rec["rooflines"] = roofs
+    if w["model"] == "deepfm" and not sharded:
+        rec["step_hbm"] = step_hbm(w, B, ms)
+    if rank == 0 and want_opt and not a.no_optimizer:
+        # reported separately (the headline metric is fwd+bwd only): the row-wise step on the table
+        # rows this batch touched + dense Adam on the dense parameters
         try:
-            from recman_amd.optim import Optimizer, SparseTableOptimizer
-
-            sopt, dopt = SparseTableOptimizer(engine, "adam", 1e-3), Optimizer("adam", 1e-3)
-            for _ in range(3):
-                sopt.step(idx)
-                dopt.step(engine.params, engine.grads)
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            for _ in range(10):
-                sopt.step(idx)
-                dopt.step(engine.params, engine.grads)
-            ev1.record()
-            torch.cuda.synchronize()
-            out["optimizer_step"] = {"ms": round(ev0.elapsed_time(ev1) / 10, 4),
-                                     "what": "lazy row-wise Adam on touched table rows (rm_sparse_optimizer_step) "
-                                             "+ dense Adam on dense parameters; NOT part of value"}
-            del sopt, dopt
+            rec["optimizer_step"] = engine.optimizer_probe(idx) if not sharded else None
         except Exception as e:  # never let the extra break the contract line
-            out["optimizer_step"] = {"ms": None, "error": str(e)[:200]}
-    if rank == 0 and not sharded and not a.no_cpu_baseline:
-        base, logit_cpu, sample = cpu_baseline(w, hp, idx, dense, y, engine)
-        out["cpu_baseline"] = base
+            rec["optimizer_step"] = {"ms": None, "error": f"{type(e).__name__}: {str(e)[:200]}"}
+    if sharded and want_opt and not a.no_optimizer and hasattr(engine, "optimizer_probe_sharded"):
+        # every rank takes part (the dense all_reduce precedes the dense step); rank 0 reports
+        try:
+            o = engine.optimizer_probe_sharded(idx, dense, y)
+            if rank == 0:
+                rec["optimizer_step"] = o
+        except Exception as e:
+            rec["optimizer_step"] = {"ms": None, "error": f"{type(e).__name__}: {str(e)[:200]}"}
+    if rank == 0 and not sharded and want_cpu and not a.no_cpu_baseline:
+        base, logit_cpu, sample = cpu_baseline(w, hp, idx, dense, y, engine, cpu_budget)
+        rec["cpu_baseline"] = base
         engine.forward(idx[:sample].contiguous(), dense[:sample].contiguous(), training=True)
         err = float((engine.logit[:sample].cpu() - logit_cpu).abs().max())
-        out["parity_check"] = {"max_abs_logit_err_vs_cpu_oracle": err, "examples": sample,
+        rec["parity_check"] = {"max_abs_logit_err_vs_cpu_oracle": err, "examples": sample,
                                "tolerance": 1e-5}
+    # (a hipGraph that holds RCCL kernels, --graph-sharded, keeps the communicator busy: the graphs go
+    # before destroy_process_group())
+    if sharded:
+        engine._segs = None
+    del engine, idx, dense, y
+    import gc
+
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main():
+    a = parse()
+    if a.pmc_child:
+        return pmc_child(a)
+    world_env = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and world_env is None:
+        # not under torch.distributed.run: start the ranks ourselves, before any GPU call
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", 0))
+    world = int(world_env or 1)
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start one rank per GPU")
+    wname = a.workload or "deepfm"
+    sharded = world > 1 or a.force_sharded
+    extras = (a.workload is None and not a.only and world == 1 and not a.force_sharded
+              and not a.batch and not a.vocab and a.zipf == 0)
+
+    # ---- HBM traffic of the roofline kernels: rocprofv3 --pmc child passes, BEFORE any GPU call here ----
+    live, pmc_note = {}, "not requested"
+    full_size = not a.batch and not a.vocab and a.zipf == 0
+    if rank == 0 and world == 1 and not sharded and not a.no_pmc and full_size:
+        t0 = time.perf_counter()
+        live, pmc_note = pmc_passes(["deepfm", "xdeepfm", "dcn"] if extras else [wname])
+        pmc_note = pmc_note or f"ok ({time.perf_counter() - t0:.0f} s)"
+        if not live:
+            print(f"[bench] live PMC traffic unavailable: {pmc_note}", file=sys.stderr)
+    fallback = json.load(open(TRAFFIC_FALLBACK)) if os.path.exists(TRAFFIC_FALLBACK) else {}
+
+    # RECMAN_REHEARSE_ONE_GPU=1: every rank on GPU 0 with gloo (host-staged) collectives - a
+    # rehearsal of the multi-rank control flow on a one-GPU box, not a measurement
+    rehearse = os.environ.get("RECMAN_REHEARSE_ONE_GPU", "0") == "1"
+    if rehearse:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    backend = None
+    if world > 1 or "RANK" in os.environ:
+        import torch.distributed as dist
+
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        backend = dist.get_backend()
+        assert dist.get_world_size() == world
+
+    rec = measure(a, wname, dev, rank, world, dist, rehearse, sharded, live, fallback, a.steps, a.warmup,
+                  a.cpu_budget or 20.0, zipf=a.zipf)
+    out = {
+        "metric": METRIC, "value": rec.pop("value"), "unit": rec.pop("unit"), "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": rec.pop("ms_per_step"),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "world_size": (dist.get_world_size() if dist is not None else 1),
+        "backend": ({"nccl": "nccl (RCCL over xGMI)", "gloo": "gloo (one-GPU rehearsal, host-staged)"}.get(
+            backend, backend) if backend else "none (single process)"),
+    }
+    out.update(rec)
+    if extras:
+        sub_steps, sub_warm = max(5, min(a.steps, 20)), max(2, min(a.warmup, 5))
+        out["zipf"] = _sub(measure(a, "deepfm", dev, rank, world, dist, rehearse, False, {}, {}, a.steps,
+                                   a.warmup, 0.0, zipf=1.05, want_cpu=False, want_opt=False),
+                           note="the DeepFM workload with Zipf(1.05) ids (cached row loads); SURVEY.md 8d asks "
+                                "for both index distributions")
+        out["workloads"] = {}
+        for name in ("xdeepfm", "dcn"):
+            out["workloads"][name] = _sub(measure(a, name, dev, rank, world, dist, rehearse, False, live,
+                                                  fallback, sub_steps, sub_warm, a.cpu_budget or 12.0),
+                                          steps=sub_steps, warmup=sub_warm)
+    if rank == 0 and world == 1:
+        out["pmc_passes"] = pmc_note
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
-        # graphs first: a hipGraph that holds RCCL kernels (--graph-sharded) keeps the communicator
-        # busy and destroy_process_group() waited on it forever
-        run = graph = None
-        if sharded:
-            engine._segs = None
         import gc
 
         gc.collect()
         torch.cuda.synchronize()
         dist.destroy_process_group()
+
+
+def _sub(rec, **extra):
+    rec = dict(rec)
+    rec.update(extra)
+    return rec
 
 
 if __name__ == "__main__":

@@ -46,6 +46,11 @@ int rm_version(void);
 const char *rm_last_error(void);
 /* number of compute units of the current device (grid sizing for callers) */
 int rm_device_cus(void);
+/* Enqueues an empty one-wave kernel named rm_profile_marker_kernel: brackets a stretch of launches so
+ * that a rocprofv3 kernel / counter trace can be cut at it (bench.py's PMC child passes).  No memory
+ * is touched.  (New: the reference has no profiler hooks beyond tf.summary.trace_on,
+ * recman/tf/core/TensorBoardLogger.py:58-69.) */
+int rm_profile_marker(int tag, rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Embedding gather (+ FM, + sparse/dense linear term), forward.

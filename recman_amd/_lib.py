@@ -32,6 +32,7 @@ class MlpTail(ctypes.Structure):
 SIGNATURES = {
     "rm_version": [],
     "rm_device_cus": [],
+    "rm_profile_marker": [c_int, P],
     "rm_embed_fwd": [P, P, I64, P, P, I64, P, I64, P, P, P, P, c_int, P, P, I64, c_int, c_int,
                      P, P, P, P, c_int, P],
     "rm_embed_bwd": [P, P, P, P, P, P, I64, c_int, c_int, P, P, P],

@@ -638,7 +638,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                     dst.copy_(src)
             return self._run_segments()
 
-        def _dominant_kernel(self, idx, dense):
+        def roofline_probes(self, idx, dense, y):
             """roofline_probe on the sharded engine: the LOCAL gather + FM + linear kernel over the
             rows received in the last exchange (no collective inside, any rank may call it)."""
             from . import ops
@@ -663,8 +663,9 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                     fm_logit=self.fm_logit[:b] if fm else None,
                     lin_logit=self.lin_logit[:b] if self.use_linear else None)
 
-            return ("embed_fwd_kernel on the exchanged rows (rm_embed_fwd: gather + FM + linear, "
-                    f"{b} examples per launch)", fn, self._embed_fwd_bytes(b, fm), "hbm")
+            return [dict(name="embed_fwd_kernel on the exchanged rows (rm_embed_fwd: gather + FM + linear, "
+                              f"{b} examples per launch)", symbol="embed_fwd_kernel", fn=fn,
+                         work=self._embed_fwd_bytes(b, fm), bound="hbm")]
 
         def overflowed(self):
             """True when a fixed-capacity batch did not fit (host sync; clears the flag): every

@@ -653,29 +653,74 @@ class Engine:
         return total
 
     # ------------------------------------------------------------ measurement
-    def roofline_probe(self, idx, dense, y, iters=20):
-        """Times the dominant hand-written kernel of this model with HIP events on the
-        stream it is launched on and prices it against its roofline."""
+    def roofline_probes(self, idx, dense, y):
+        """The hand-written hot kernels of this model as [{name, symbol, fn, work, bound}], the
+        dominant one first: `fn` launches the kernel once on the current stream, `work` is its
+        algorithmic bytes (bound "hbm") or flops (bound "mfma") per launch, `symbol`
+        the kernel's name in a rocprofv3 trace."""
         self._alloc(idx.shape[0])
-        name, fn, work, bound = self._dominant_kernel(idx, dense)
+        fm = self._has_fm()
+        return [dict(name="embed_fwd_fused_kernel (rm_embed_fwd: gather + FM + linear)",
+                     symbol="embed_fwd_fused_kernel", fn=lambda: self._embed(idx, dense, fm, None),
+                     work=self._embed_fwd_bytes(idx.shape[0], fm), bound="hbm")]
+
+    def roofline_probe_all(self, idx, dense, y, iters=20):
+        """Times every roofline_probes() kernel with HIP events on the stream it is launched on and
+        prices it against its roofline."""
+        out = []
+        for p in self.roofline_probes(idx, dense, y):
+            fn = p["fn"]
+            for _ in range(3):
+                fn()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(iters)]
+            for a, b in ev:
+                a.record()
+                fn()
+                b.record()
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in ev) / iters
+            if p["bound"] == "hbm":
+                achieved, peak, unit = p["work"] / (ms * 1e-3) / 1e9, 8000.0, "GB/s"
+            else:
+                achieved, peak, unit = p["work"] / (ms * 1e-3) / 1e12, 157.3, "TFLOP/s"
+            out.append({"kernel": p["name"], "symbol": p["symbol"], "bound": p["bound"],
+                        "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                        "frac": round(achieved / peak, 4), "traffic": None,
+                        "avg_launch_us": round(ms * 1e3, 2), "algorithmic_per_launch": p["work"],
+                        "timing": f"hipEvent pairs, {iters} launches"})
+        return out
+
+    def roofline_probe(self, idx, dense, y, iters=20):
+        """The dominant kernel's roofline record (roofline_probe_all()[0])."""
+        return self.roofline_probe_all(idx, dense, y, iters)[0]
+
+    def optimizer_probe(self, idx, iters=10):
+        """Times the separately-reported optimizer step on the gradients of the last fwd_bwd: the
+        row-wise step on the touched table rows + dense Adam on the dense parameters."""
+        from .optim import Optimizer, SparseTableOptimizer
+
+        sopt, dopt = SparseTableOptimizer(self, "adam", 1e-3), Optimizer("adam", 1e-3)
         for _ in range(3):
-            fn()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(iters)]
-        for a, b in ev:
-            a.record()
-            fn()
-            b.record()
+            sopt.step(idx)
+            dopt.step(self.params, self.grads)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        for _ in range(iters):
+            sopt.step(idx)
+        ev[1].record()
+        for _ in range(iters):
+            dopt.step(self.params, self.grads)
+        ev[2].record()
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in ev) / iters
-        if bound == "hbm":
-            achieved, peak, unit = work / (ms * 1e-3) / 1e9, 8000.0, "GB/s"
-        else:
-            achieved, peak, unit = work / (ms * 1e-3) / 1e12, 157.3, "TFLOP/s"
-        return {"kernel": name, "bound": bound, "achieved": round(achieved, 2), "peak": peak,
-                "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
-                "avg_launch_us": round(ms * 1e3, 2),
-                "algorithmic_per_launch": work, "timing": f"hipEvent pairs, {iters} launches"}
+        ms_s, ms_d = ev[0].elapsed_time(ev[1]) / iters, ev[1].elapsed_time(ev[2]) / iters
+        out = {"ms": round(ms_s + ms_d, 4), "sparse_rows_ms": round(ms_s, 4), "dense_params_ms": round(ms_d, 4),
+               "what": "row-wise lazy Adam on the touched table rows (rm_sparse_optimizer_step) "
+                       "+ dense Adam on the dense parameters; NOT part of value"}
+        roof = getattr(sopt, "roofline", None)
+        if roof is not None:
+            out["roofline"] = roof(idx, ms_s)
+        return out
 
     def _embed_fwd_bytes(self, B, fm):
         F, D, Dn = self.F, self.D, self.Dn
@@ -685,12 +730,6 @@ class Engine:
         if self.use_linear:
             per += F * 4 + Dn * 4 + 4  # linear entries, dense columns, lin_logit
         return B * per
-
-    def _dominant_kernel(self, idx, dense):
-        fm = self._has_fm()
-        return ("embed_fwd_kernel (rm_embed_fwd: gather + FM + linear)",
-                lambda: self._embed(idx, dense, fm, None), self._embed_fwd_bytes(idx.shape[0], fm),
-                "hbm")
 
     # ----------------------------------------------- dense views of the sparse grads
     def dense_grads(self, idx, reference_names=False):
@@ -969,24 +1008,39 @@ class DCNEngine(Engine):
                               gr["cross_w_out"].view(-1))
         self._cross_l2_grads()
 
-    def _dominant_kernel(self, idx, dense):
-        # the MLP GEMMs dominate the DCN step: layer 0 of the wide DNN, x = [xe | xd] -> H0
-        # (bias + activation fused), on the f32 MFMA roofline
+    def roofline_probes(self, idx, dense, y):
+        # the MLP GEMMs dominate the DCN step: layer 0 of the wide DNN, x = [xe | xd] -> H0 (bias +
+        # activation fused), on the f32 MFMA roofline; the fused cross kernels on the HBM roofline
         if self.mlp.fused_ok:
-            return super()._dominant_kernel(idx, dense)
+            return super().roofline_probes(idx, dense, y)
         B = idx.shape[0]
-        self._embed(idx, dense, False, None)
+        self._alloc(B)
+        if getattr(self, "_probe_ready", None) != B:
+            self.fwd_bwd(idx, dense, y)  # fills E, the layer scalars s, dlogit, dxe_dnn
+            self._probe_ready = B
         xe, xd = self.E.view(-1, self.FD), (dense if self.Dn else None)
-        self.mlp.forward(xe, xd)
         W, b = self.params["dnn_layer_0_weights"], self.params["dnn_layer_0_bias"]
-        m = self.mlp
-
-        def fn():
-            ops.dense_fwd(xe, xd, W, m.a[0], m._fws, bias=b, act=m.act)
-
+        m, p, L, d = self.mlp, self.params, self.L, self.FD + self.Dn
         K, N = W.shape
-        return (f"dense_nn_kernel (rm_dense_fwd, DNN layer 0: [{B},{K}] x [{K},{N}] + bias + {m.act})", fn,
-                2.0 * B * K * N, "mfma")
+        probes = [dict(name=f"dense_nn_kernel (rm_dense_fwd, DNN layer 0: [{B},{K}] x [{K},{N}] + bias + {m.act})",
+                       symbol="dense_nn_kernel",
+                       fn=lambda: ops.dense_fwd(xe, xd, W, m.a[0], m._fws, bias=b, act=m.act),
+                       work=2.0 * B * K * N, bound="mfma")]
+        if not self.matrix:
+            probes.append(dict(
+                name=f"cross_fwd_kernel (rm_cross_fwd, {L} layers fused: x0 [{B},{d}] read once -> logit, s_l)",
+                symbol="cross_fwd_kernel",
+                fn=lambda: ops.cross_fwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1),
+                                         self.cross_logit, self.cross_s),
+                work=B * (d * 4 + 4 + 4 * L), bound="hbm"))
+            probes.append(dict(
+                name=f"cross_bwd_kernel (rm_cross_bwd: x0 + the DNN's dx read once, dx0 written once)",
+                symbol="cross_bwd_kernel",
+                fn=lambda: ops.cross_bwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1),
+                                         self.dlogit, self.cross_s, self.d_rows.view(-1, self.FD), None,
+                                         self.coef, dx_in_e=self.dxe_dnn),
+                work=B * (d * 4 + 2 * self.FD * 4 + 4 * (2 * L + 2) + 4 * L + 4), bound="hbm"))
+        return probes
 
     def _cross_l2_grads(self):
         p, gr = self.params, self.grads
@@ -1155,9 +1209,10 @@ class XDeepFMEngine(Engine):
             total = total + sum(reg * 0.5 * w.square().sum() for w in ws)
         return total
 
-    def _dominant_kernel(self, idx, dense):
+    def roofline_probes(self, idx, dense, y):
         # the heaviest CIN forward layer on the f32 MFMA roofline
         B, m, D = idx.shape[0], self.F, self.D
+        self._alloc(B)
         i = max(range(len(self.units)), key=lambda k: self.Hs[k] * self.units[k])
         H, n = self.Hs[i], self.units[i]
         xk = self.E if i == 0 else self.maps[i - 1]
@@ -1170,8 +1225,8 @@ class XDeepFMEngine(Engine):
                               self.cin_act, self.maps[i], self.cin_fws, pooled=self.pooled,
                               pool_col0=self.pool_col0[i], pool_from=self.pool_from[i])
 
-        return (f"cin_fwd_kernel<4> (rm_cin_layer_fwd, layer {i}: m={m} H={H} N={n})", fn,
-                2.0 * B * D * m * H * n, "mfma")
+        return [dict(name=f"cin_fwd_kernel (rm_cin_layer_fwd, layer {i}: m={m} H={H} N={n})",
+                     symbol="cin_fwd_kernel", fn=fn, work=2.0 * B * D * m * H * n, bound="mfma")]
 
 
 ENGINES = {"deepfm": DeepFMEngine, "dcn": DCNEngine, "xdeepfm": XDeepFMEngine}

@@ -32,6 +32,11 @@ def _chk(t, name, dtype, shape=None, allow_none=False):
     return t.data_ptr()
 
 
+def profile_marker(tag=0):
+    """An empty marker kernel on the current stream (cuts a rocprofv3 trace, rm_profile_marker)."""
+    _lib.call("rm_profile_marker", int(tag), _stream())
+
+
 def embed_fwd(idx, table, field_off, *, bias_table=None, bias_ld=1, lin_w=None, lin_ld=1,
               lin_off=None, lin_w_dense=None, lin_w0=None, dense=None, mask_b=None, mask_e=None,
               E=None, fm_sum=None, fm_logit=None, lin_logit=None, table_ld=None, D=None,
