@@ -232,24 +232,29 @@ int rm_rowdot(const float *X, const float *w, const float *w0, int64_t B, int P,
  *   x_{l+1} = x0 * (x_l . w_l) + b_l + x_l,  logit = x_L . w_out
  * x0 = [xe | xd]: xe [B,FD] is the flattened embedding block E, xd [B,Dn] the dense
  * columns (DNNCombiner, layers.py:494-501) - never concatenated in memory.
- *   w, b [L,d], w_out [d], d = FD + Dn, FD % 4 == 0, d <= 512, L <= 8.
+ *   w, b [L,d], w_out [d], d = FD + Dn, FD % 4 == 0, 0 < FD <= 512, L <= 8.
+ * Computed in closed form (exact algebra): x_l = c_l x0 + Bp_l with Bp_l = sum_{j<l} b_j, so
+ *   s_l = x_l.w_l = c_l p_l + beta_l,  p_l = x0.w_l,  beta_l = Bp_l.w_l,  c_{l+1} = c_l + s_l,
+ *   logit = c_L p_out + beta_out  (p_out = x0.w_out): L+1 dot products per row + a scalar recurrence.
+ *   p_out [B, p_ld] (p_ld >= L+1; NULL ok): the row's dot products (p_0..p_{L-1}, x0.w_out), saved
+ *   for the backward, which needs nothing else of x0.
  */
 int rm_cross_fwd(const float *xe, const float *xd, int FD, int Dn, const float *w,
                  const float *b, const float *w_out, int L, int64_t B, float *logit,
-                 float *s_out /* [B,L] layer scalars x_l.w_l, saved for the backward; NULL ok */,
-                 rm_stream_t stream);
+                 float *p_out, int p_ld, rm_stream_t stream);
 
-/* Backward: given g [B] = dLoss/dlogit and s [B,L] from the forward,
- *   d_xe [B,FD] (+= dx_in_e when given), d_xd [B,Dn] (+= dx_in_d when given):
- *       gradient w.r.t. x0, optionally summed with another branch's gradient
+/* Backward: given g [B] = dLoss/dlogit and p [B, p_ld] from the forward,
+ *   d_xe [B,FD] (+ dx_in_e when given): gradient w.r.t. the embedding block of x0
+ *       = g c_L w_out + sum_l t_l c_l w_l, optionally summed with another branch's gradient
+ *       (t_l = g p_out + sum_{j>l} t_j p_j).  x0 itself is not read; the dense columns are input
+ *       data and get no gradient (the reference differentiates variables only, xDeepFM.py:126).
  *   coef [B, 2L+2]: per-example scalars from which the parameter gradients follow
  *       by one skinny GEMM (see recman_amd/engine.py and DESIGN.md):
  *       columns 0..L-1 = t_l*c_l, L = g*c_L, L+1..2L = t_l, 2L+1 = g
  */
-int rm_cross_bwd(const float *xe, const float *xd, int FD, int Dn, const float *w,
-                 const float *b, const float *w_out, int L, int64_t B, const float *g,
-                 const float *s, const float *dx_in_e, const float *dx_in_d, float *d_xe,
-                 float *d_xd, float *coef, rm_stream_t stream);
+int rm_cross_bwd(int FD, int Dn, const float *w, const float *b, const float *w_out, int L,
+                 int64_t B, const float *g, const float *p, int p_ld, const float *dx_in_e,
+                 float *d_xe, float *coef, rm_stream_t stream);
 
 /* Finishes the CrossNet parameter gradients from P = x0^T @ coef[:, :L+1] ([d, L+1],
  * row-major) and colsum = sum_b coef[:, L+1:] ([L+1]):

@@ -49,8 +49,8 @@ SIGNATURES = {
     "rm_outer_actgrad": [P, P, P, I64, c_int, c_int, P, P],
     "rm_outer_actgrad_sums": [P, P, P, I64, c_int, c_int, P, P, P, P, P, P],
     "rm_rowdot": [P, P, P, I64, c_int, P, P],
-    "rm_cross_fwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P],
-    "rm_cross_bwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, P, P, P, P, P, P],
+    "rm_cross_fwd": [P, P, c_int, c_int, P, P, P, c_int, I64, P, P, c_int, P],
+    "rm_cross_bwd": [c_int, c_int, P, P, P, c_int, I64, P, P, c_int, P, P, P, P],
     "rm_cross_param_grads": [P, P, P, P, P, c_int, c_int, P, P, P, P],
     "rm_cin_layer_fwd": [P, P, I64, P, P, c_int, I64, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                          c_int, P, P],

@@ -906,7 +906,7 @@ class DCNEngine(Engine):
         dev = self.device
         L = self.L
         self.cross_logit = torch.empty(B, dtype=F32, device=dev)
-        self.cross_s = torch.empty(B, L, dtype=F32, device=dev)
+        self.cross_p = torch.empty(B, ops.cross_p_ld(L), dtype=F32, device=dev)  # x0.w_l, x0.w_out
         self.coef = torch.empty(B, 2 * L + 2, dtype=F32, device=dev)
         self._coef_sum = torch.empty(2 * L + 2, dtype=F32, device=dev)
         self._ones_b = torch.ones(B, dtype=F32, device=dev)
@@ -977,7 +977,7 @@ class DCNEngine(Engine):
             self._cross_matrix_fwd(xe, xd)
         else:
             ops.cross_fwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1),
-                          self.cross_logit, self.cross_s)
+                          self.cross_logit, self.cross_p)
         branches = [(self.dnn_logit, self.dnn_coef), (self.cross_logit, 1.0)]
         if self.use_linear:
             branches.append((self.lin_logit, 1.0))
@@ -994,9 +994,8 @@ class DCNEngine(Engine):
             return
         # cross backward adds the DNN's dx and writes straight into the row-gradient
         # buffer: with no FM term d_rows IS dLoss/dE (no separate embed_bwd launch)
-        ops.cross_bwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1), g,
-                      self.cross_s, self.d_rows.view(-1, self.FD), None, self.coef,
-                      dx_in_e=self.dxe_dnn)
+        ops.cross_bwd(p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1), g,
+                      self.cross_p, self.d_rows.view(-1, self.FD), self.coef, dx_in_e=self.dxe_dnn)
         L = self.L
         # P = x0^T coef[:, :L+1]: a batch-reduction GEMM with x0 = [xe | xd] read in place, and the
         # column sums of coef in one pass (rm_linear_dense_bwd with unit weights)
@@ -1028,18 +1027,18 @@ class DCNEngine(Engine):
                        work=2.0 * B * K * N, bound="mfma")]
         if not self.matrix:
             probes.append(dict(
-                name=f"cross_fwd_kernel (rm_cross_fwd, {L} layers fused: x0 [{B},{d}] read once -> logit, s_l)",
+                name=f"cross_fwd_kernel (rm_cross_fwd, {L} layers fused: x0 [{B},{d}] read once -> logit, p)",
                 symbol="cross_fwd_kernel",
                 fn=lambda: ops.cross_fwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1),
-                                         self.cross_logit, self.cross_s),
-                work=B * (d * 4 + 4 + 4 * L), bound="hbm"))
+                                         self.cross_logit, self.cross_p),
+                work=B * (d * 4 + 4 + 4 * (L + 1)), bound="hbm"))
             probes.append(dict(
-                name=f"cross_bwd_kernel (rm_cross_bwd: x0 + the DNN's dx read once, dx0 written once)",
+                name="cross_bwd_kernel (rm_cross_bwd: the DNN's dx [B,FD] + the p row read, dx0 written once)",
                 symbol="cross_bwd_kernel",
-                fn=lambda: ops.cross_bwd(xe, xd, p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1),
-                                         self.dlogit, self.cross_s, self.d_rows.view(-1, self.FD), None,
+                fn=lambda: ops.cross_bwd(p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1),
+                                         self.dlogit, self.cross_p, self.d_rows.view(-1, self.FD),
                                          self.coef, dx_in_e=self.dxe_dnn),
-                work=B * (d * 4 + 2 * self.FD * 4 + 4 * (2 * L + 2) + 4 * L + 4), bound="hbm"))
+                work=B * (2 * self.FD * 4 + 4 * (2 * L + 2) + 4 * (L + 1) + 4), bound="hbm"))
         return probes
 
     def _cross_l2_grads(self):

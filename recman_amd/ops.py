@@ -137,30 +137,36 @@ def logit_loss(branches, *, y=None, y_f=None, task="classification", logit=None,
         _chk(workspace, "workspace", F32, allow_none=True), _stream())
 
 
-def cross_fwd(xe, xd, w, b, w_out, logit, s_out=None):
+def cross_p_ld(L):
+    """Row length of the saved dot products p [B, p_ld] (L+1 values, padded to a multiple of 4)."""
+    return (L + 4) // 4 * 4
+
+
+def cross_fwd(xe, xd, w, b, w_out, logit, p_out=None):
+    """CrossNet forward (rm_cross_fwd).  p_out [B, cross_p_ld(L)]: the row's dot products
+    (x0.w_l, x0.w_out), all the backward needs."""
     B, FD = xe.shape
     Dn = 0 if xd is None else xd.shape[1]
     L, d = w.shape
     if d != FD + Dn:
         raise ValueError(f"cross_fwd: w has d={d}, inputs have {FD}+{Dn}")
+    p_ld = 0 if p_out is None else p_out.shape[1]
     _lib.call(
         "rm_cross_fwd", _chk(xe, "xe", F32), _chk(xd, "xd", F32, (B, Dn), allow_none=True), FD, Dn,
         _chk(w, "w", F32), _chk(b, "b", F32, (L, d)), _chk(w_out, "w_out", F32, (d,)), L, B,
-        _chk(logit, "logit", F32, (B,)), _chk(s_out, "s_out", F32, (B, L), allow_none=True),
+        _chk(logit, "logit", F32, (B,)), _chk(p_out, "p_out", F32, (B, p_ld), allow_none=True), p_ld,
         _stream())
 
 
-def cross_bwd(xe, xd, w, b, w_out, g, s, d_xe, d_xd, coef, dx_in_e=None, dx_in_d=None):
-    B, FD = xe.shape
-    Dn = 0 if xd is None else xd.shape[1]
+def cross_bwd(w, b, w_out, g, p, d_xe, coef, dx_in_e=None):
+    """CrossNet backward (rm_cross_bwd): d_xe [B,FD] (+ dx_in_e), coef [B,2L+2]."""
+    B, FD = d_xe.shape
     L, d = w.shape
     _lib.call(
-        "rm_cross_bwd", _chk(xe, "xe", F32), _chk(xd, "xd", F32, (B, Dn), allow_none=True), FD, Dn,
-        _chk(w, "w", F32), _chk(b, "b", F32, (L, d)), _chk(w_out, "w_out", F32, (d,)), L, B,
-        _chk(g, "g", F32, (B,)), _chk(s, "s", F32, (B, L)),
-        _chk(dx_in_e, "dx_in_e", F32, (B, FD), allow_none=True),
-        _chk(dx_in_d, "dx_in_d", F32, (B, Dn), allow_none=True), _chk(d_xe, "d_xe", F32, (B, FD)),
-        _chk(d_xd, "d_xd", F32, (B, Dn), allow_none=True),
+        "rm_cross_bwd", FD, d - FD, _chk(w, "w", F32), _chk(b, "b", F32, (L, d)),
+        _chk(w_out, "w_out", F32, (d,)), L, B, _chk(g, "g", F32, (B,)),
+        _chk(p, "p", F32, (B, p.shape[1])), p.shape[1],
+        _chk(dx_in_e, "dx_in_e", F32, (B, FD), allow_none=True), _chk(d_xe, "d_xe", F32, (B, FD)),
         _chk(coef, "coef", F32, (B, 2 * L + 2)), _stream())
 
 
