@@ -360,24 +360,46 @@ int rm_pool_rows_bwd(const float *d_rows, int64_t dr_stride, const float *g_bias
                      int64_t row0, float *d_table, float *d_bias, float *d_lin, rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * Row-wise (lazy) optimizer step on the fused table rows, straight from the IndexedSlices
- * form the backward produces.  Replaces optimizer.minimize(...) of xDeepFM.py:121-126 /
- * create_optimizer (utils.py:201-213) for the embedding-side variables: Keras Adam
- * (kind 0: beta1/beta2, epsilon outside the sqrt), Adagrad (kind 1, accumulator starts at
- * 0.1) or SGD (kind 2).  Only rows occurring in idx are touched; duplicates are summed.
- *   rows, m_state, v_state, gbuf [R, LD] (gbuf must be all-zero on entry, is on exit),
- *   stamp [R] int32 (any values != step), step >= 1 and different from the previous call,
- *   g_bias / g_lin [B]: per-example gradient of the bias (column D) / linear (column D+1)
- *   entries or NULL; reset != 0 ignores the stored moments (the reference builds a new
- *   optimizer for every batch).  * Occurrences with idx < 0 are skipped. */
+ * Optimizer steps.  Replace optimizer.minimize(...) of xDeepFM.py:121-126 / create_optimizer
+ * (utils.py:201-213): Keras Adam (kind 0: beta1/beta2, epsilon outside the sqrt), Adagrad (kind 1,
+ * accumulator starts at 0.1) or SGD (kind 2).  reset != 0 ignores the stored moments (the reference
+ * builds a new optimizer for every batch); step >= 1 is the Adam bias-correction step.
+ *
+ * rm_sparse_optimizer_step: ROW-WISE and LAZY step on table rows, straight from the IndexedSlices
+ * form the backward produces (LazyAdam - Keras' sparse Adam decays the moments of EVERY row; the two
+ * coincide under `reset` and when every row is touched each step; see csrc/optim.hip).  Only rows
+ * occurring in idx are touched; duplicate occurrences are summed in occurrence order (a stable sort,
+ * no float atomics: bit-reproducible).  Occurrences with idx < 0 are skipped.
+ *   rows [R, ld]: parameter rows [D embedding | bias | lin | m_bias | m_lin | v_bias | v_lin | pad pad ..],
+ *                 ld >= D + 8, ld % 4 == 0 (the four moment entries live in the row's padding), 8 <= D <= 64
+ *   mom  [R, 2D]: moments of the embedding entries, interleaved per float4 slice
+ *                 [m[0:4] v[0:4] | m[4:8] v[4:8] | ..] (Adagrad uses the v halves; SGD: may be NULL)
+ *   d_rows [B,F,D], g_bias / g_lin [B] (per-example gradient of column D / D+1, or NULL),
+ *   lin_field_mask [F] or NULL (linear_features subsets)
+ *   workspace: rm_sparse_optimizer_workspace(B * F) BYTES.
+ * rm_sparse_optimizer_prepare: the id-only part of a step (keys + stable sort by table row) on its own,
+ *   so that it can be issued before / beside the forward+backward pass; the following step call on the
+ *   same ids passes prepared = 1 and the same workspace (ids: idx [n/F, F] + field_off, or row_ids [n]).
+ * rm_sparse_optimizer_step_rows: the same step from gradient rows that already carry their table row
+ *   (the row-sharded table's owner side): row_ids [n] (< 0: skip), grad_rows [n, gw] with columns
+ *   [0, D) embedding gradient, D bias gradient, D+1 linear gradient.
+ * rm_dense_optimizer_step: the same update rule on a flat parameter buffer (dense parameters). */
+int64_t rm_sparse_optimizer_workspace(int64_t n);
+int rm_sparse_optimizer_prepare(const int64_t *idx, const int64_t *field_off, const int64_t *row_ids,
+                                int64_t n, int F, int64_t R, void *workspace, int64_t ws_bytes,
+                                rm_stream_t stream);
 int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field_off, const float *d_rows,
                              const float *g_bias, const float *g_lin, int64_t B, int F, int D,
-                             int LD, float *rows, float *m_state, float *v_state, float *gbuf,
-                             int32_t *stamp, int step, int kind, float lr, float beta1, float beta2,
-                             float eps, int reset,
-                             const float *lin_field_mask /* [F] 0/1: fields outside the hyper-parameter
-                                linear_features (utils.py:27-30) get no linear gradient; NULL = all */,
+                             int64_t R, float *rows, int64_t ld, float *mom, int step, int kind,
+                             float lr, float beta1, float beta2, float eps, int reset,
+                             const float *lin_field_mask, int prepared, void *workspace, int64_t ws_bytes,
                              rm_stream_t stream);
+int rm_sparse_optimizer_step_rows(const int64_t *row_ids, const float *grad_rows, int64_t gw, int64_t n,
+                                  int D, int64_t R, float *rows, int64_t ld, float *mom, int step, int kind,
+                                  float lr, float beta1, float beta2, float eps, int reset, int prepared,
+                                  void *workspace, int64_t ws_bytes, rm_stream_t stream);
+int rm_dense_optimizer_step(float *p, const float *g, float *m, float *v, int64_t n, int step, int kind,
+                            float lr, float beta1, float beta2, float eps, int reset, rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Row helpers (owner-side gather and re-ordering for the row-sharded table).

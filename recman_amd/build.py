@@ -44,14 +44,18 @@ def clean_experiments(verbose=True):
             os.remove(p)
 
 
-def build(force=False, verbose=True, extra_flags=(), out=None):
+def build(force=False, verbose=True, extra_flags=(), out=None, only=None):
     """out: another output path (an experiment build, e.g. build/librecman_x.so, loaded through
-    RECMAN_HIP_LIB; its objects go next to it) - the product library is `LIB`."""
+    RECMAN_HIP_LIB; its objects go next to it) - the product library is `LIB`.  only: with `out`,
+    the source stems (e.g. ["cross"]) that are recompiled with extra_flags; every other
+    translation unit is taken from the product build's objects."""
     clean_experiments(verbose)
     if out is None and not force and not _stale():
         return LIB
     if out is not None:
-        return _build_variant(out, extra_flags, verbose)
+        if only:
+            build(force=False, verbose=verbose)  # the product objects must be current
+        return _build_variant(out, extra_flags, verbose, only)
     objs = []
     procs = []
     for src in sources():
@@ -72,12 +76,15 @@ def build(force=False, verbose=True, extra_flags=(), out=None):
     return LIB
 
 
-def _build_variant(out, extra_flags, verbose):
+def _build_variant(out, extra_flags, verbose, only=None):
     out = os.path.abspath(out)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     tag = os.path.splitext(os.path.basename(out))[0]
     objs, procs = [], []
     for src in sources():
+        if only and os.path.basename(src)[:-4] not in only:
+            objs.append(src[:-4] + ".o")
+            continue
         obj = os.path.join(os.path.dirname(out), f"{tag}_{os.path.basename(src)[:-4]}.o")
         cmd = [hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-c", src, "-o", obj,
                "-Wall", "-Wno-unused-function", *extra_flags]
@@ -93,8 +100,9 @@ def _build_variant(out, extra_flags, verbose):
 
 
 if __name__ == "__main__":
-    # python -m recman_amd.build [--force] [--out build/librecman_x.so -DFLAG ...]
+    # python -m recman_amd.build [--force] [--out build/librecman_x.so [--only cross,embed] -DFLAG ...]
     argv = sys.argv[1:]
     out = argv[argv.index("--out") + 1] if "--out" in argv else None
     flags = [a for a in argv if a.startswith("-D")]
-    print(build(force="--force" in argv, out=out, extra_flags=flags))
+    only = argv[argv.index("--only") + 1].split(",") if "--only" in argv else None
+    print(build(force="--force" in argv, out=out, extra_flags=flags, only=only))

@@ -111,21 +111,22 @@ __device__ __forceinline__ void stage_params(float *sm, const float *__restrict_
   const int total = (2 * L + 1) * P;
   for (int base = 0; base < total; base += kBlock * PER) {
     float v[PER];
+    bool ok[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int i = base + q * kBlock + threadIdx.x;
       const int r = i / P, e = i - r * P;
-      int src = -1;
-      if (e < 256 * NS) { if (e < FD) src = e; }
-      else if (e - 256 * NS < Dn) src = FD + e - 256 * NS;
-      v[q] = 0.f;
-      if (i < total && src >= 0)
-        v[q] = r < L ? w[(int64_t)r * d + src] : (r == L ? w_out[src] : b[(int64_t)(r - L - 1) * d + src]);
+      const int src = e < 256 * NS ? e : FD + e - 256 * NS;
+      ok[q] = i < total && (e < 256 * NS ? e < FD : e - 256 * NS < Dn);
+      // one unconditional load from a clamped address per element (a branch per source array made
+      // every element its own divergent region); zeroed by the select below
+      const float *row = r < L ? w + (int64_t)r * d : (r == L ? w_out : b + (int64_t)(r - L - 1) * d);
+      v[q] = (i < total ? row : w)[ok[q] ? src : 0];
     }
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int i = base + q * kBlock + threadIdx.x;
-      if (i < total) sm[i] = v[q];
+      if (i < total) sm[i] = ok[q] ? v[q] : 0.f;
     }
   }
 }

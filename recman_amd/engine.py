@@ -697,30 +697,48 @@ class Engine:
 
     def optimizer_probe(self, idx, iters=10):
         """Times the separately-reported optimizer step on the gradients of the last fwd_bwd: the
-        row-wise step on the touched table rows + dense Adam on the dense parameters."""
-        from .optim import Optimizer, SparseTableOptimizer
+        row-wise step on the touched table rows + the dense parameters in one launch; checks that two
+        identical steps from the same state give bit-identical tables."""
+        from .optim import FusedDenseOptimizer, SparseTableOptimizer
 
-        sopt, dopt = SparseTableOptimizer(self, "adam", 1e-3), Optimizer("adam", 1e-3)
+        sopt, dopt = SparseTableOptimizer(self, "adam", 1e-3), FusedDenseOptimizer(self, "adam", 1e-3)
+        # determinism: the same step twice from the same state (rows + moments restored in between)
+        rows0, mom0 = self.rows.clone(), sopt.mom.clone()
+        sopt.step(idx)
+        rows1, mom1 = self.rows.clone(), sopt.mom.clone()
+        self.rows.copy_(rows0)
+        sopt.mom.copy_(mom0)
+        sopt.t = 0
+        sopt.step(idx)
+        same = bool(torch.equal(self.rows, rows1) and torch.equal(sopt.mom, mom1))
+        del rows0, mom0, rows1, mom1
         for _ in range(3):
             sopt.step(idx)
-            dopt.step(self.params, self.grads)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            dopt.step()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
         for _ in range(iters):
             sopt.step(idx)
         ev[1].record()
         for _ in range(iters):
-            dopt.step(self.params, self.grads)
+            dopt.step()
         ev[2].record()
+        for _ in range(iters):
+            sopt.prepare(idx)
+        ev[3].record()
         torch.cuda.synchronize()
+        sopt._prepared = None
         ms_s, ms_d = ev[0].elapsed_time(ev[1]) / iters, ev[1].elapsed_time(ev[2]) / iters
-        out = {"ms": round(ms_s + ms_d, 4), "sparse_rows_ms": round(ms_s, 4), "dense_params_ms": round(ms_d, 4),
-               "what": "row-wise lazy Adam on the touched table rows (rm_sparse_optimizer_step) "
-                       "+ dense Adam on the dense parameters; NOT part of value"}
-        roof = getattr(sopt, "roofline", None)
-        if roof is not None:
-            out["roofline"] = roof(idx, ms_s)
-        return out
+        ms_p = ev[2].elapsed_time(ev[3]) / iters
+        return {"ms": round(ms_s + ms_d, 4), "sparse_rows_ms": round(ms_s, 4), "dense_params_ms": round(ms_d, 4),
+                "sort_ms": round(ms_p, 4), "apply_ms": round(ms_s - ms_p, 4),
+                "bit_identical_rerun": same,
+                "what": "row-wise lazy Adam on the touched table rows (rm_sparse_optimizer_step: stable sort by "
+                        "row, duplicates summed in occurrence order, no float atomics) + Adam on the dense "
+                        "parameters in one launch (rm_dense_optimizer_step), timed back to back; sort_ms is the "
+                        "id-only part (rm_sparse_optimizer_prepare) that fit() issues on a side stream beside "
+                        "fwd+bwd; NOT part of value",
+                "roofline": sopt.roofline(idx, ms_s)}
 
     def _embed_fwd_bytes(self, B, fm):
         F, D, Dn = self.F, self.D, self.Dn

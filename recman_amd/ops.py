@@ -384,26 +384,77 @@ def pack_grad_rows(d_rows, g_bias, g_lin, pos, out):
 OPT_KINDS = {"adam": 0, "adagrad": 1, "gd": 2, "sgd": 2}
 
 
-def sparse_optimizer_step(idx, field_off, d_rows, rows, m_state, v_state, gbuf, stamp, step, kind, lr,
+def sparse_optimizer_workspace(n):
+    """Bytes of workspace rm_sparse_optimizer_step needs for n occurrences."""
+    need = int(_lib.lib().rm_sparse_optimizer_workspace(int(n)))
+    if need < 0:
+        raise ValueError(f"sparse_optimizer_workspace: bad occurrence count {n}")
+    return need
+
+
+def _opt_ws(workspace, n):
+    if workspace.dtype != torch.uint8 or not workspace.is_cuda or workspace.numel() < sparse_optimizer_workspace(n):
+        raise ValueError("sparse optimizer: workspace must be a uint8 device tensor of "
+                         "sparse_optimizer_workspace(n) bytes")
+    return workspace.data_ptr(), workspace.numel()
+
+
+def sparse_optimizer_prepare(workspace, R, idx=None, field_off=None, row_ids=None):
+    """The id-only part of a row-wise step (keys + stable sort) on the current stream
+    (rm_sparse_optimizer_prepare); follow it with sparse_optimizer_step(..., prepared=True)."""
+    if row_ids is not None:
+        n, F = row_ids.numel(), 1
+    else:
+        n, F = idx.numel(), idx.shape[1]
+    wp, wn = _opt_ws(workspace, n)
+    _lib.call("rm_sparse_optimizer_prepare", _chk(idx, "idx", I64, allow_none=True),
+              _chk(field_off, "field_off", I64, allow_none=True), _chk(row_ids, "row_ids", I64, allow_none=True),
+              n, F, int(R), wp, wn, _stream())
+
+
+def sparse_optimizer_step(idx, field_off, d_rows, rows, mom, workspace, step, kind, lr, D=None,
                           g_bias=None, g_lin=None, reset=False, beta1=0.9, beta2=0.999, eps=1e-7,
-                          lin_field_mask=None):
-    """Lazy row-wise optimizer step on fused rows [R, LD] (see rm_sparse_optimizer_step)."""
-    B, F, D = d_rows.shape
-    R, LD = rows.shape
-    for nm, t in (("m_state", m_state), ("v_state", v_state), ("gbuf", gbuf)):
-        if t is not None:
-            _chk(t, nm, F32, (R, LD))
-    if stamp.dtype != torch.int32 or stamp.numel() != R:
-        raise ValueError("sparse_optimizer_step: stamp must be int32 [R]")
+                          lin_field_mask=None, prepared=False):
+    """Lazy row-wise optimizer step on table rows [R, ld] (see rm_sparse_optimizer_step): rows =
+    [D emb | bias | lin | m_b | m_l | v_b | v_l | pad], mom [R, 2D] = [m | v] of the embedding."""
+    B, F, Dg = d_rows.shape
+    D = Dg if D is None else D
+    R, ld = rows.shape
+    if mom is not None:
+        _chk(mom, "mom", F32, (R, 2 * D))
+    wp, wn = _opt_ws(workspace, B * F)
     _lib.call("rm_sparse_optimizer_step", _chk(idx, "idx", I64, (B, F)),
-              _chk(field_off, "field_off", I64, (F,)), _chk(d_rows, "d_rows", F32),
+              _chk(field_off, "field_off", I64, (F,)), _chk(d_rows, "d_rows", F32, (B, F, D)),
               _chk(g_bias, "g_bias", F32, (B,), allow_none=True),
-              _chk(g_lin, "g_lin", F32, (B,), allow_none=True), B, F, D, LD, _chk(rows, "rows", F32),
-              None if m_state is None else m_state.data_ptr(),
-              None if v_state is None else v_state.data_ptr(), gbuf.data_ptr(), stamp.data_ptr(),
+              _chk(g_lin, "g_lin", F32, (B,), allow_none=True), B, F, D, R, _chk(rows, "rows", F32), ld,
+              None if mom is None else mom.data_ptr(), int(step), OPT_KINDS[kind], float(lr), float(beta1),
+              float(beta2), float(eps), 1 if reset else 0,
+              _chk(lin_field_mask, "lin_field_mask", F32, (F,), allow_none=True), 1 if prepared else 0,
+              wp, wn, _stream())
+
+
+def sparse_optimizer_step_rows(row_ids, grad_rows, D, rows, mom, workspace, step, kind, lr, reset=False,
+                               beta1=0.9, beta2=0.999, eps=1e-7, prepared=False):
+    """The same step from gradient rows that carry their (local) table row: row_ids [n] (< 0: skip),
+    grad_rows [n, gw] = [dE | g_bias | g_lin | ...] (rm_sparse_optimizer_step_rows)."""
+    n, gw = grad_rows.shape
+    R, ld = rows.shape
+    if mom is not None:
+        _chk(mom, "mom", F32, (R, 2 * D))
+    wp, wn = _opt_ws(workspace, n)
+    _lib.call("rm_sparse_optimizer_step_rows", _chk(row_ids, "row_ids", I64, (n,)),
+              _chk(grad_rows, "grad_rows", F32), gw, n, D, R, _chk(rows, "rows", F32), ld,
+              None if mom is None else mom.data_ptr(), int(step), OPT_KINDS[kind], float(lr), float(beta1),
+              float(beta2), float(eps), 1 if reset else 0, 1 if prepared else 0, wp, wn, _stream())
+
+
+def dense_optimizer_step(p, g, m, v, step, kind, lr, reset=False, beta1=0.9, beta2=0.999, eps=1e-7):
+    """One launch over a flat parameter buffer (rm_dense_optimizer_step)."""
+    n = p.numel()
+    _lib.call("rm_dense_optimizer_step", _chk(p, "p", F32, (n,)), _chk(g, "g", F32, (n,)),
+              _chk(m, "m", F32, (n,), allow_none=True), _chk(v, "v", F32, (n,), allow_none=True), n,
               int(step), OPT_KINDS[kind], float(lr), float(beta1), float(beta2), float(eps),
-              1 if reset else 0, _chk(lin_field_mask, "lin_field_mask", F32, (F,), allow_none=True),
-              _stream())
+              1 if reset else 0, _stream())
 
 
 def _chk_csr(offsets, ids, vals):

@@ -21,7 +21,7 @@ from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_random_state
 
 from .. import engine as eng
-from ..optim import Optimizer, SparseTableOptimizer
+from ..optim import FusedDenseOptimizer, Optimizer, SparseTableOptimizer
 from .inputs import DataInputs, FeatureDictionary
 
 log = logging.getLogger(__name__)
@@ -69,9 +69,13 @@ class DeepModel(BaseEstimator, TransformerMixin):
         no_l2 = not hp.get("embedding_l2_reg", 0.0) and not hp.get("linear_l2_reg", 0.0)
         want = hp.get("sparse_optimizer", e.rows.numel() > (1 << 24))
         self._sparse_opt = None
-        if want and no_l2 and hp.get("optimizer", "adam") in ("adam", "adagrad", "gd", "sgd"):
+        fits = e.rows.shape[1] >= e.D + 8 and 8 <= e.D <= 64  # room for the bias / linear moments in the row
+        if want and no_l2 and fits and hp.get("optimizer", "adam") in ("adam", "adagrad", "gd", "sgd"):
             self._sparse_opt = SparseTableOptimizer(e, hp.get("optimizer", "adam"),
                                                     hp.get("learning_rate", 1e-3))
+            # ... and the dense parameters in one launch (the dict-walking Optimizer stays the path
+            # for densified table gradients: small tables, l2 terms, FM bias dropout)
+            self._dense_fused = FusedDenseOptimizer(e, hp.get("optimizer", "adam"), hp.get("learning_rate", 1e-3))
         return e
 
     @property
@@ -196,13 +200,24 @@ class DeepModel(BaseEstimator, TransformerMixin):
         e = self._build()
         if idx.shape[0] == 0:
             return None
+        side = None
+        if self._sparse_opt is not None and not e.spec.scratch_names:
+            # the id-only third of the row-wise step (keys + sort by row) runs on a side stream beside the
+            # forward+backward pass
+            self._sparse_opt._workspace(idx.numel())  # (allocated on the main stream)
+            side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream(device=e.device)
+            side.wait_stream(torch.cuda.current_stream(e.device))
+            with torch.cuda.stream(side):
+                self._sparse_opt.prepare(idx)
         loss = e.fwd_bwd(idx, dense, yt, masks=self._dropout_masks(idx.shape[0]), mv=mv)
+        if side is not None:
+            torch.cuda.current_stream(e.device).wait_stream(side)
         if self.strict_reference:
             self._opt.reset()  # a NEW optimizer every batch (xDeepFM.py:121-126)
         fm_masked = getattr(e, "d_bias", None) is not None  # FM bias dropout: per-occurrence grads
         if self._sparse_opt is not None and not fm_masked:
             self._sparse_opt.step(idx, reset=self.strict_reference)
-            self._opt.step(e.params, e.grads)  # dense parameters only
+            self._dense_fused.step(reset=self.strict_reference)  # dense parameters only
         else:
             self._opt.step(e.params, e.dense_grads(idx))
         return loss
