@@ -86,6 +86,9 @@ def parse(argv=None):
     ap.add_argument("--table-row-reuse", default="", choices=["", "stream", "cache"],
                     help="gather kernel's row loads: stream = non-temporal (default for uniform ids), "
                          "cache = plain (default with --zipf)")
+    ap.add_argument("--d-rows-reuse", default="cache", choices=["cache", "stream"],
+                    help="the backward's row-gradient stores: cache (default - what fit() runs: the optimizer step "
+                         "gathers them right after) or stream (non-temporal: a bare fwd+bwd is ~1 %% faster)")
     ap.add_argument("--prewarm", type=float, default=0.25,
                     help="seconds of untimed steps BEFORE the W warmup steps (GPU clock ramp); 0 = none")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
@@ -372,7 +375,8 @@ def make_engine(a, w, B, V, dev, rank, world, sharded, zipf=0.0):
               cross_layer_l2_reg=0.0,
               # uniform ids: a row is touched about once per batch -> streamed (non-temporal) row loads;
               # --zipf: hot rows want the caches
-              table_row_reuse=a.table_row_reuse or ("cache" if zipf > 0 else "stream"))
+              table_row_reuse=a.table_row_reuse or ("cache" if zipf > 0 else "stream"),
+              d_rows_reuse=a.d_rows_reuse)
     if sharded:
         from recman_amd import dist as rdist
 
@@ -531,6 +535,8 @@ def measure(a, wname, dev, rank, world, dist, rehearse, sharded, live_traffic, f
                    "indices": "uniform" if zipf == 0 else f"zipf({zipf})",
                    "table_row_loads": ("cached" if hp["table_row_reuse"] == "cache"
                                        else "non-temporal (ids with little reuse per batch)"),
+                   "row_gradient_stores": ("cached (as in fit(): the optimizer step gathers them next)"
+                                           if hp["d_rows_reuse"] == "cache" else "non-temporal"),
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
                    "host_enqueue_ms_per_step": round(enq_ms, 4),
                    "prewarm_s": a.prewarm, "hipgraph": graph_kind,

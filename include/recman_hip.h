@@ -159,6 +159,8 @@ int rm_logit_loss(const float *logit_a, float coef_a, const float *logit_b, floa
  *   bias when the same g drives it (layers.py:330-347; saves the rm_linear_dense_bwd pass).
  *   Deterministic (no float atomics).
  *   workspace: rm_mlp_bwd_workspace(FD, Dn) floats.
+ *   flags: RM_MLP_STREAM_DROWS = store d_rows non-temporally - only when NOTHING re-reads it soon (a
+ *   bare fwd+bwd); in training the optimizer step gathers it right after: leave it 0.
  *
  * Fused training head (rm_mlp_tail, optional - NULL gives the plain calls above).  When the DNN is
  *   the LAST branch of the model's forward (DeepFM, xDeepFM), everything between its output and its
@@ -187,6 +189,7 @@ typedef struct rm_mlp_tail {
   float *dh[3];         /* dh[l] [B,32] for l < NL (the same buffers rm_mlp_bwd gets as dh) */
 } rm_mlp_tail;
 
+#define RM_MLP_STREAM_DROWS 1
 int rm_mlp_supported(int FD, int Dn, int NL, const int *H);
 int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
                const float *const *W, const float *const *bias, const float *w_out,
@@ -198,7 +201,7 @@ int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const i
                const float *const *h, const float *fm_sum, int D, float *d_rows,
                float *const *dh, float *const *dW, float *const *db, float *d_w_out,
                float *d_w0_out, float *d_xd_wsum, float *d_g_sum, float *workspace,
-               const rm_mlp_tail *tail, rm_stream_t stream);
+               const rm_mlp_tail *tail, int flags, rm_stream_t stream);
 
 /* Epilogues of the library-GEMM DNN path (wide hidden layers, layers.py:593-601):
  * rm_bias_act: x[b,j] = act(x[b,j] + bias[j]) in place (bias may be NULL);

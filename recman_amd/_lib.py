@@ -43,7 +43,7 @@ SIGNATURES = {
     "rm_mlp_supported": [c_int, c_int, c_int, P],
     "rm_mlp_fwd": [P, P, c_int, c_int, c_int, P, P, P, P, P, c_int, I64, P, P, P, P],
     "rm_mlp_bwd": [P, P, c_int, c_int, c_int, P, P, P, c_int, I64, P, P, P, c_int, P, P, P, P, P, P,
-                   P, P, P, P, P],
+                   P, P, P, P, c_int, P],
     "rm_bias_act": [P, P, I64, c_int, c_int, P],
     "rm_act_bwd": [P, P, I64, c_int, c_int, P],
     "rm_outer_actgrad": [P, P, P, I64, c_int, c_int, P, P],

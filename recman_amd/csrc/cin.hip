@@ -233,12 +233,11 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
   }
 
   // ---- epilogue: bias + activation, [B,N,D] store, pooled sums through LDS ----
-  float *pool_s = Ws;  // [epb][Np] (<= 32 KB, fits the two filter buffers when epb <= 64)
+  // pool_s [rows / 4][Np]: every (4-row group, filter) partial has its OWN cell (plain stores), and the
+  // D / 4 partials of an (example, filter) are then added in row order: bit-reproducible.  (The first
+  // version added them with a float atomicAdd into one cell per example - four adders in hardware order.)
+  float *pool_s = Ws;  // 64 x Np floats <= 32 KB: fits the two filter buffers
   const bool want_pool = pooled != nullptr;
-  if (want_pool) {
-    for (int t = tid; t < epb * Np; t += NTHR) pool_s[t] = 0.f;
-    __syncthreads();
-  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
 #elif !(RM_CIN_EXP & 2)
           *reinterpret_cast<float4 *>(out + (b * N + n) * D + d) = v;
 #endif
-          if (want_pool && n >= pool_from) atomicAdd(pool_s + bl * Np + n, v.x + v.y + v.z + v.w);
+          if (want_pool && n >= pool_from) pool_s[(p >> 2) * Np + n] = (v.x + v.y) + (v.z + v.w);
         }
       }
     }
@@ -277,7 +276,12 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
     for (int t = tid; t < epb * ncols; t += NTHR) {
       const int bl = t / ncols, cidx = t - bl * ncols;
       const int64_t b = b0 + bl;
-      if (b < B) pooled[b * pool_stride + pool_col0 + cidx] = pool_s[bl * Np + pool_from + cidx];
+      if (b < B) {
+        const int q0 = bl * (D >> 2);
+        float t4 = pool_s[q0 * Np + pool_from + cidx];
+        for (int q = 1; q < (D >> 2); ++q) t4 += pool_s[(q0 + q) * Np + pool_from + cidx];
+        pooled[b * pool_stride + pool_col0 + cidx] = t4;
+      }
     }
   }
 }

@@ -32,7 +32,7 @@ __device__ __forceinline__ float actg(float o, int act) {
 }
 
 #ifndef RM_MLP_NT
-#define RM_MLP_NT 3  // bit 0: non-temporal d_rows stores in mlp_bwd, bit 1: non-temporal x loads in mlp_bwd (last use of E in the MLP; together -1.3 % on the DeepFM step, each alone nothing: profiles/r01_p11)
+#define RM_MLP_NT 2  // bit 1: non-temporal x loads in mlp_bwd (last use of E in the MLP).  (Bit 0, non-temporal d_rows stores, is now the CALLER's flag RM_MLP_STREAM_DROWS: -1.3 % on a bare fwd+bwd step together with bit 1, but the optimizer step that follows in training gathers d_rows again and paid +0.05 ms for it: profiles/r01_p11)
 #endif
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store4_stream(float *p, const float4 &v) {
@@ -529,6 +529,7 @@ __global__ __launch_bounds__(256) void mlp_dh_chain_kernel(
   }
 }
 
+template <bool NT_OUT>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(
     const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn,
     const float *__restrict__ W0, int H0, int64_t B, const float *__restrict__ g,
@@ -686,11 +687,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
             float4 o = *reinterpret_cast<const float4 *>(xb + row * kLDT + 4 * piece);
             const float4 s4 = *reinterpret_cast<const float4 *>(gS + row * D + (k % D));
             o.x += s4.x; o.y += s4.y; o.z += s4.z; o.w += s4.w;
-#if RM_MLP_NT & 1
-            if (br < B && k < FD) store4_stream(d_rows + br * FD + k, o);
-#else
-            if (br < B && k < FD) *reinterpret_cast<float4 *>(d_rows + br * FD + k) = o;
-#endif
+            if (NT_OUT) {
+              if (br < B && k < FD) store4_stream(d_rows + br * FD + k, o);
+            } else {
+              if (br < B && k < FD) *reinterpret_cast<float4 *>(d_rows + br * FD + k) = o;
+            }
           }
         } else {
 #pragma unroll 1  // (register-bound kernel: the unrolled form with its global loads spilled 56 VGPRs)
@@ -998,7 +999,7 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
                           const float *g, const float *const *h, const float *fm_sum, int D,
                           float *d_rows, float *const *dh, float *const *dW, float *const *db,
                           float *d_w_out, float *d_w0_out, float *d_xd_wsum, float *d_g_sum,
-                          float *workspace, const rm_mlp_tail *tail, rm_stream_t stream) {
+                          float *workspace, const rm_mlp_tail *tail, int flags, rm_stream_t stream) {
   int rc = mlp_check("rm_mlp_bwd", FD, Dn, NL, H);
   if (rc != RM_OK) return rc;
   if (B == 0) return RM_OK;
@@ -1066,10 +1067,17 @@ extern "C" int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int 
     // 3. dX (+ FM term) -> d_rows and the dW0 slabs, from x and dh0.  (After the small gradients:
     // those read h_l / dh_l, which the forward's epilogue wrote a moment ago - still in L2 / the
     // Infinity Cache now, gone from them after this kernel's 220 MB.)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(nblk), dim3(512), smem, st, xe, xd, FD, Dn, W[0], H[0], B, g,
-                       (const float *)dh[0], fm_sum, D, d_rows, part, s_lds);
+    if (flags & RM_MLP_STREAM_DROWS) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(nblk), dim3(512), smem, st, xe, xd, FD, Dn, W[0], H[0], B, g,
+                         (const float *)dh[0], fm_sum, D, d_rows, part, s_lds);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3(nblk), dim3(512), smem, st, xe, xd, FD, Dn, W[0], H[0], B, g,
+                         (const float *)dh[0], fm_sum, D, d_rows, part, s_lds);
+    }
     const int n_dw0 = Kp * 32 / 64, n_sg = (kSgStride + 63) / 64;
     const bool with_loss = tail && tail->loss;
     hipLaunchKernelGGL(mlp_finish_kernel, dim3(n_dw0 + n_sg + (with_loss ? 1 : 0)), dim3(64 * kFinG), 0, st, part,

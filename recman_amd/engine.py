@@ -145,6 +145,10 @@ class MLP:
         # (csrc/gemm.hip: bias / activation / activation-gradient fused, x = [xe | xd] in place)
         self.fused_ok = bool(FD % 4 == 0 and ops.mlp_supported(FD, Dn, self.hidden))
         self.fused = False
+        # hp["d_rows_reuse"] = "stream": the row gradients leave the caches (non-temporal stores) - only
+        # for a bare forward+backward; the default keeps them cached for the optimizer step that
+        # gathers them right after (fit(), and the benchmark: it times what training runs)
+        self.stream_d_rows = False
 
     def _alloc(self, B, device):
         if self._B == B:
@@ -242,7 +246,8 @@ class MLP:
                         d_w_out=gr[f"{pre}dnn_w"].view(-1), d_w0_out=gr[f"{pre}dnn_w0"],
                         d_xd_wsum=lin_grads[0] if (lin_grads and 1 <= self.Dn <= 32) else None,
                         d_g_sum=lin_grads[1] if (lin_grads and 1 <= self.Dn <= 32) else None,
-                        tail=self.tail if self.head_done else None)
+                        tail=self.tail if self.head_done else None,
+                        stream_d_rows=getattr(self, "stream_d_rows", False))
             self.lin_done = bool(lin_grads and 1 <= self.Dn <= 32)
             return fm_sum is not None
         # d(pre-activation of the last layer) = (g w_out^T) o mask o act'(a): one elementwise pass
@@ -839,6 +844,7 @@ class DeepFMEngine(Engine):
         if self.use_deep:
             self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
                            hp.get("deep_activation", "relu"), self.device)
+            self.mlp.stream_d_rows = hp.get("d_rows_reuse", "cache") == "stream"
 
     def _has_fm(self):
         return self.use_fm
@@ -911,6 +917,7 @@ class DCNEngine(Engine):
         dev = self.device
         self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
                        hp.get("deep_activation", "relu"), dev)
+        self.mlp.stream_d_rows = hp.get("d_rows_reuse", "cache") == "stream"
         self.cross_type = hp.get("cross_type", "vector")
         if self.cross_type not in ("vector", "matrix"):
             raise ValueError(f"cross_type {self.cross_type!r}: 'vector' or 'matrix'")
@@ -1099,6 +1106,7 @@ class XDeepFMEngine(Engine):
             assert len(keep) == len(self.units) + 1  # layers.py:657 (checked only when it matters)
         self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
                        hp.get("deep_activation", "leaky_relu"), dev)
+        self.mlp.stream_d_rows = hp.get("d_rows_reuse", "cache") == "stream"
         m = self.F
         self.Hs, self.pool_from, self.pool_col0 = [m], [], []
         final = 0

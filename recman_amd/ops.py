@@ -320,9 +320,10 @@ def mlp_fwd(xe, xd, Ws, bs, w_out, w0_out, act, h_out, logit, tail=None):
 
 
 def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None, db=None,
-            d_w_out=None, d_w0_out=None, d_xd_wsum=None, d_g_sum=None, tail=None):
+            d_w_out=None, d_w0_out=None, d_xd_wsum=None, d_g_sum=None, tail=None, stream_d_rows=False):
     """tail: the struct the forward ran with - dh is already there (no chain launch) and the
-    finishing kernel also reduces the loss."""
+    finishing kernel also reduces the loss.  stream_d_rows: RM_MLP_STREAM_DROWS (non-temporal d_rows
+    stores: only when no optimizer step re-reads them)."""
     B, FD = xe.shape
     Dn = 0 if xd is None else xd.shape[1]
     H = [W.shape[1] for W in Ws]
@@ -343,7 +344,7 @@ def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None
               _chk(d_w0_out, "d_w0_out", F32, (1,), allow_none=True),
               _chk(d_xd_wsum, "d_xd_wsum", F32, (Dn,), allow_none=True),
               _chk(d_g_sum, "d_g_sum", F32, (1,), allow_none=True),
-              _chk(workspace, "workspace", F32), _tail_ref(tail), _stream())
+              _chk(workspace, "workspace", F32), _tail_ref(tail), 1 if stream_d_rows else 0, _stream())
 
 
 def shard_route(idx, field_off, world, pos, send_ids, counts, workspace):

@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same
-seeded inputs.  Tolerances: logits 1e-5 absolute (north star), gradients 1e-5
-relative to the gradient's max magnitude + 1e-6 absolute; indices bit-exact."""
+seeded inputs.  Tolerances: logits 1e-5 absolute (north star); gradients PER ELEMENT:
+|got - want| <= 2e-5 * max(|want|, 0.1 * max|want| of the tensor) - relative to the element itself
+down to a tenth of the tensor's largest entry, with no absolute floor (a gradient tensor whose entries
+are all ~1e-4 is held to ~2e-9, not to 1e-6 as the round-1 check did); indices bit-exact."""
 import numpy as np
 import pytest
 import torch
@@ -20,6 +22,21 @@ def _close(got, want, rtol=1e-5, atol=1e-6, what=""):
     scale = max(1.0, float(want.abs().max()))
     err = float((got - want).abs().max())
     assert err <= atol + rtol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e})"
+
+
+def _close_grad(got, want, rtol=2e-5, what=""):
+    """Per-element relative check of a gradient (see the module docstring)."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    scale = float(want.abs().max())
+    if scale == 0.0:
+        assert float(got.abs().max()) == 0.0, f"{what}: expected an all-zero gradient"
+        return
+    tol = rtol * torch.clamp(want.abs(), min=0.1 * scale)
+    bad = (got - want).abs() > tol
+    if bool(bad.any()):
+        i = int(((got - want).abs() / tol).argmax())
+        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.numel()} entries off; worst got "
+                             f"{got.reshape(-1)[i]:.9e} want {want.reshape(-1)[i]:.9e} (tensor max {scale:.3e})")
 
 
 def _engine(model, spec, D, hp, p):
@@ -44,7 +61,7 @@ def _check_model(model, hip_lib, D=8, B=37, **kw):
     grads = e.dense_grads(idx_d, reference_names=True)
     for k in grads_o:
         if k in grads:
-            _close(grads[k], grads_o[k], what=f"grad {k}")
+            _close_grad(grads[k], grads_o[k], what=f"grad {k}")
         else:  # a variable this configuration does not use (e.g. DNN weights with use_deep=False)
             assert float(grads_o[k].abs().max()) <= 1e-3 * 1.0001 * float(p[k].abs().max()), k
     assert set(grads) <= set(grads_o), set(grads) - set(grads_o)
@@ -128,7 +145,7 @@ def test_mlp_dropout_masks_injected(hip_lib):
     _close(e.logit, logit_o, rtol=0, atol=1e-5, what="logit")
     grads = e.dense_grads(idx.cuda(), reference_names=True)
     for k in grads_o:
-        _close(grads[k], grads_o[k], what=f"grad {k}")
+        _close_grad(grads[k], grads_o[k], what=f"grad {k}")
 
 
 def test_regression_task(hip_lib):
@@ -147,7 +164,7 @@ def test_regression_task(hip_lib):
     _close(loss, loss_o.detach().reshape(1), what="mse loss")
     grads = e.dense_grads(idx.cuda(), reference_names=True)
     for k, v in leaves.items():
-        _close(grads[k], v.grad, what=f"grad {k}")
+        _close_grad(grads[k], v.grad, what=f"grad {k}")
 
 
 def test_loss_clip_region_gradient_is_zero(hip_lib):
@@ -279,7 +296,7 @@ def test_multi_valued_feature_fwd_bwd_matches_oracle(hip_lib, model, kw):
     grads = e.dense_grads(idx.cuda(), reference_names=True)
     for k in grads_o:
         if k in grads:
-            _close(grads[k], grads_o[k], what=f"grad {k}")
+            _close_grad(grads[k], grads_o[k], what=f"grad {k}")
     logit_i, _ = e.forward(idx.cuda(), dense.cuda(), training=False, mv=mv_d)
     _close(logit_i, logit_o, rtol=0, atol=1e-5, what="inference logit")
 
@@ -317,7 +334,7 @@ def test_value_feature_fwd_bwd_matches_oracle(hip_lib, model, kw):
     grads = e.dense_grads(idx.cuda(), reference_names=True)
     for k in grads_o:
         if k in grads:
-            _close(grads[k], grads_o[k], what=f"grad {k}")
+            _close_grad(grads[k], grads_o[k], what=f"grad {k}")
     with pytest.raises(ValueError):  # a value feature without its values
         e.forward(idx.cuda(), dense.cuda(), mv={vname: (torch.arange(B + 1).cuda(), vids.cuda()),
                                                  mname: (offsets.cuda(), ids.cuda())})
@@ -346,7 +363,7 @@ def test_dcn_matrix_cross_fwd_bwd_matches_oracle(hip_lib, B, L, use_linear):
     grads = e.dense_grads(idx.cuda(), reference_names=True)
     for k in grads_o:
         if k in grads:
-            _close(grads[k], grads_o[k], what=f"grad {k}")
+            _close_grad(grads[k], grads_o[k], what=f"grad {k}")
     assert {"cross_w", "cross_b", "cross_w_out"} <= set(grads)
     logit_i, _ = e.forward(idx.cuda(), dense.cuda(), training=False)
     _close(logit_i, logit_o, rtol=0, atol=1e-5, what="inference logit")
@@ -445,7 +462,7 @@ def test_cin_dropout_masks_injected(hip_lib, keep):
     _close(loss, loss_o.reshape(1), what="loss")
     grads = e.dense_grads(idx.cuda(), reference_names=True)
     for k in grads_o:
-        _close(grads[k], grads_o[k], what=f"grad {k}")
+        _close_grad(grads[k], grads_o[k], what=f"grad {k}")
     # inference ignores the dropout
     logit_i, _ = e.forward(idx.cuda(), dense.cuda(), training=False)
     want = T.xdeepfm_logit(p, spec, idx, dense, hp, training=False).reshape(-1)
@@ -521,7 +538,7 @@ def test_linear_features_subset_matches_oracle(hip_lib, model, kw, names):
     grads = e.dense_grads(idx.cuda(), reference_names=True)
     for k in grads_o:
         if k in grads:
-            _close(grads[k], grads_o[k], what=f"grad {k}")
+            _close_grad(grads[k], grads_o[k], what=f"grad {k}")
     # the row-wise optimizer leaves the other features' linear weights untouched (zero)
     opt = SparseTableOptimizer(e, "adam", 1e-2)
     opt.step(idx.cuda())
