@@ -93,6 +93,15 @@ int rm_embed_fwd(const int64_t *idx, const float *table, int64_t table_ld,
                  float *E, float *fm_sum, float *fm_logit, float *lin_logit,
                  int flags /* RM_EMBED_* */, rm_stream_t stream);
 
+/* The linear term on its own: (Sparse)LinearCombiner + (Sparse)LinearLayer.__call__ (layers.py:281-347,
+ * 368-439; one_hot utils.py:51-67) in gather form, for callers that compose the reference's layer
+ * callables one by one (recman_amd/th/layers.py; the engines take it from rm_embed_fwd):
+ *   out[b] = sum_f w[lin_off[f] + idx[b,f]] + sum_j dense[b,j] * w_dense[j] + w0[0]
+ * w0 may be NULL.  Its backward is rm_scatter_add_rows (g_row form) + rm_linear_dense_bwd. */
+int rm_linear_fwd(const int64_t *idx, const int64_t *lin_off, const float *w, const float *dense,
+                  const float *w_dense, const float *w0, int64_t B, int F, int Dn, float *out,
+                  rm_stream_t stream);
+
 /* Backward of the embedding + FM block w.r.t. the gathered rows: the IndexedSlices
  * values TF's autodiff produces for tf.nn.embedding_lookup (one row per (b,f)
  * occurrence, duplicates NOT merged; the indices are `idx` itself).

@@ -35,6 +35,7 @@ SIGNATURES = {
     "rm_profile_marker": [c_int, P],
     "rm_embed_fwd": [P, P, I64, P, P, I64, P, I64, P, P, P, P, c_int, P, P, I64, c_int, c_int,
                      P, P, P, P, c_int, P],
+    "rm_linear_fwd": [P, P, P, P, P, P, I64, c_int, c_int, P, P],
     "rm_embed_bwd": [P, P, P, P, P, P, I64, c_int, c_int, P, P, P],
     "rm_scatter_add_rows": [P, P, P, P, I64, c_int, c_int, I64, P, P],
     "rm_linear_dense_bwd": [P, P, I64, c_int, P, P, P, P],

@@ -216,6 +216,22 @@ __global__ __launch_bounds__(kBlock) void embed_fwd_fused_kernel(
   }
 }
 
+// Linear term alone (the layer-callable surface, recman_amd/th/layers.py; the engines get it from the
+// fused gather kernel above): out[b] = sum_f w[lin_off[f] + idx[b,f]] + sum_j dense[b,j] w_dense[j] + w0.
+// A thread per example (F + Dn loads): a convenience kernel, not a hot one.
+__global__ __launch_bounds__(kBlock) void linear_fwd_kernel(
+    const int64_t *__restrict__ idx, const int64_t *__restrict__ lin_off, const float *__restrict__ w,
+    const float *__restrict__ dense, const float *__restrict__ w_dense, const float *__restrict__ w0,
+    int64_t B, int F, int Dn, float *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
+    float acc = w0 != nullptr ? w0[0] : 0.f;
+    for (int f = 0; f < F; ++f) acc += w[lin_off[f] + idx[b * F + f]];
+    for (int j = 0; j < Dn; ++j) acc += dense[b * Dn + j] * w_dense[j];
+    out[b] = acc;
+  }
+}
+
 // Backward: purely elementwise over the [B, F*D/4] float4 grid once S is saved.
 template <bool MASK>
 __global__ __launch_bounds__(kBlock) void embed_bwd_kernel(
@@ -479,6 +495,19 @@ extern "C" int rm_embed_fwd(const int64_t *idx, const float *table, int64_t tabl
   }
 #undef RM_EMBED_CASE
   RM_CHECK_LAUNCH("rm_embed_fwd");
+  return RM_OK;
+}
+
+extern "C" int rm_linear_fwd(const int64_t *idx, const int64_t *lin_off, const float *w, const float *dense,
+                             const float *w_dense, const float *w0, int64_t B, int F, int Dn, float *out,
+                             rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && F >= 0 && Dn >= 0 && F + Dn > 0, "rm_linear_fwd: bad sizes");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(out && (F == 0 || (idx && lin_off && w)) && (Dn == 0 || (dense && w_dense)),
+             "rm_linear_fwd: NULL argument");
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(rm_grid_cap((B + kBlock - 1) / kBlock, 256 * 8)), dim3(kBlock), 0,
+                     (hipStream_t)stream, idx, lin_off, w, dense, w_dense, w0, B, F, Dn, out);
+  RM_CHECK_LAUNCH("rm_linear_fwd");
   return RM_OK;
 }
 

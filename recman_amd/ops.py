@@ -71,6 +71,18 @@ def embed_fwd(idx, table, field_off, *, bias_table=None, bias_ld=1, lin_w=None, 
         _chk(lin_logit, "lin_logit", F32, (B,), allow_none=True), 1 if stream_rows else 0, _stream())
 
 
+def linear_fwd(idx, lin_off, w, dense, w_dense, w0, out):
+    """out[b] = sum_f w[lin_off[f] + idx[b,f]] + dense[b,:] . w_dense + w0 (rm_linear_fwd)."""
+    B = out.shape[0]
+    F = 0 if idx is None else idx.shape[1]
+    Dn = 0 if dense is None else dense.shape[1]
+    _lib.call("rm_linear_fwd", _chk(idx, "idx", I64, (B, F), allow_none=True),
+              _chk(lin_off, "lin_off", I64, (F,), allow_none=True), _chk(w, "w", F32, allow_none=True),
+              _chk(dense, "dense", F32, (B, Dn), allow_none=True),
+              _chk(w_dense, "w_dense", F32, (Dn,), allow_none=True),
+              _chk(w0, "w0", F32, (1,), allow_none=True), B, F, Dn, _chk(out, "out", F32, (B,)), _stream())
+
+
 def embed_bwd(d_rows, *, E=None, fm_sum=None, dE_up=None, g_fm=None, mask_b=None, mask_e=None,
               d_bias=None):
     B, F, D = d_rows.shape

@@ -10,6 +10,7 @@ from .inputs import (DataInputs, DenseFeat, FeatureDictionary, MultiValCsvFeat, 
                      SparseFeat, SparseValueFeat)
 from .xDeepFM import xDeepFM
 from . import hparams
+from . import layers
 
 __all__ = ["BestModelFinder", "DCN", "DeepFM", "DeepModel", "xDeepFM", "DataInputs", "DenseFeat", "FeatureDictionary",
-           "MultiValCsvFeat", "ResilientLabelEncoder", "SparseFeat", "SparseValueFeat", "hparams"]
+           "MultiValCsvFeat", "ResilientLabelEncoder", "SparseFeat", "SparseValueFeat", "hparams", "layers"]
