@@ -434,16 +434,18 @@ int rm_shard_route_padded(const int64_t *idx, const int64_t *field_off, int64_t 
                           int64_t cap, int64_t *pos, int64_t *send_ids, int64_t *counts,
                           int32_t *overflow, int32_t *workspace, rm_stream_t stream);
 
-/* out[pos[o], :] = [d_rows[o, 0..D) | g_bias[b] | g_lin[b] | 0 ..] (width floats per row): the
- * per-occurrence gradient rows of the fused table rows, written straight in bucketed order
- * (the send buffer of the backward all_to_all).  g_bias / g_lin [B] may be NULL (0). */
+/* out[pos[o], :] = [d_rows[o, 0..D) | g_bias[b] | g_lin[b] * lin_field_mask[f] | 0 ..] (width floats per
+ * row): the per-occurrence gradient rows of the fused table rows, written straight in bucketed order
+ * (the send buffer of the backward all_to_all).  g_bias / g_lin [B] may be NULL (0); lin_field_mask
+ * [F] or NULL: the linear_features subset (get_linear_features, utils.py:27-30). */
 int rm_pack_grad_rows(const float *d_rows, const float *g_bias, const float *g_lin,
-                      const int64_t *pos, int64_t B, int F, int D, int width, float *out,
-                      rm_stream_t stream);
+                      const float *lin_field_mask, const int64_t *pos, int64_t B, int F, int D, int width,
+                      float *out, rm_stream_t stream);
 
-/* rows_out[i,:] = table[rows[i],:] for i < n (owner-side gather of the requested
- * local rows; width floats per row, width % 4 == 0); rows[i] < 0 gives a zero row. */
-int rm_gather_rows(const float *table, const int64_t *rows, int64_t n, int width,
+/* rows_out[i, 0..width) = table[rows[i], 0..width) for i < n (owner-side gather of the requested
+ * local rows; table rows are table_ld floats apart - the shard keeps optimizer state behind the
+ * exchanged columns -, width % 4 == 0, table_ld % 4 == 0); rows[i] < 0 gives a zero row. */
+int rm_gather_rows(const float *table, int64_t table_ld, const int64_t *rows, int64_t n, int width,
                    float *rows_out, rm_stream_t stream);
 
 /* dst[i,:] = src[slot[i],:] (un-route: received rows back into (b,f) order) when

@@ -67,8 +67,8 @@ SIGNATURES = {
     "rm_dense_optimizer_step": [P, P, P, P, I64, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P],
     "rm_shard_route": [P, P, I64, c_int, c_int, P, P, P, P, P],
     "rm_shard_route_padded": [P, P, I64, c_int, c_int, I64, P, P, P, P, P, P],
-    "rm_pack_grad_rows": [P, P, P, P, I64, c_int, c_int, c_int, P, P],
-    "rm_gather_rows": [P, P, I64, c_int, P, P],
+    "rm_pack_grad_rows": [P, P, P, P, P, I64, c_int, c_int, c_int, P, P],
+    "rm_gather_rows": [P, I64, P, I64, c_int, P, P],
     "rm_permute_rows": [P, P, I64, c_int, c_int, P, P],
     "rm_dense_fwd": [P, I64, c_int, P, I64, c_int, P, I64, c_int, c_int, P, c_int, c_int, P, I64, P, I64,
                      I64, P, I64, P, I64, P, P],

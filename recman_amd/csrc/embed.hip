@@ -361,7 +361,7 @@ __global__ void colsum_w_stage2(const float *__restrict__ partial, int nblk, int
 }
 
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(
-    const float4 *__restrict__ table, const int64_t *__restrict__ rows, int64_t n, int G,
+    const float4 *__restrict__ table, int64_t ld4, const int64_t *__restrict__ rows, int64_t n, int G,
     float4 *__restrict__ out) {
   const int64_t total = n * G;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(
     const int64_t i = t / G;
     const int sub = (int)(t - i * G);
     const int64_t r = rows[i];  // r < 0: an empty slot of the fixed-capacity exchange -> zero row
-    out[t] = r >= 0 ? table[r * G + sub] : make_float4(0.f, 0.f, 0.f, 0.f);
+    out[t] = r >= 0 ? table[r * ld4 + sub] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -581,9 +581,10 @@ extern "C" int rm_linear_dense_bwd(const float *g, const float *dense, int64_t B
   return RM_OK;
 }
 
-extern "C" int rm_gather_rows(const float *table, const int64_t *rows, int64_t n, int width,
+extern "C" int rm_gather_rows(const float *table, int64_t table_ld, const int64_t *rows, int64_t n, int width,
                               float *rows_out, rm_stream_t stream) {
-  RM_REQUIRE(n >= 0 && width > 0 && width % 4 == 0, "rm_gather_rows: bad sizes");
+  RM_REQUIRE(n >= 0 && width > 0 && width % 4 == 0 && table_ld >= width && table_ld % 4 == 0,
+             "rm_gather_rows: bad sizes (width and table_ld multiples of 4, table_ld >= width)");
   if (n == 0) return RM_OK;
   RM_REQUIRE(table && rows && rows_out && rm_aligned16(table) && rm_aligned16(rows_out),
              "rm_gather_rows: NULL or unaligned argument");
@@ -591,7 +592,7 @@ extern "C" int rm_gather_rows(const float *table, const int64_t *rows, int64_t n
   const int64_t total = n * G;
   dim3 grid(rm_grid_cap((total + kBlock - 1) / kBlock, 256 * 16));
   hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream,
-                     (const float4 *)table, rows, n, G, (float4 *)rows_out);
+                     (const float4 *)table, table_ld / 4, rows, n, G, (float4 *)rows_out);
   RM_CHECK_LAUNCH("rm_gather_rows");
   return RM_OK;
 }

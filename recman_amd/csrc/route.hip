@@ -143,8 +143,8 @@ __global__ __launch_bounds__(kBlock) void route_place_kernel(
 // bucketed[pos[o]][0..D) = d_rows[o][:], [D] = g_bias ? g_bias[b] : 0, [D+1] = g_lin ? g_lin[b] : 0
 __global__ __launch_bounds__(kBlock) void pack_grad_rows_kernel(
     const float4 *__restrict__ d_rows, const float *__restrict__ g_bias,
-    const float *__restrict__ g_lin, const int64_t *__restrict__ pos, int64_t n, int F, int GD,
-    int GW, float4 *__restrict__ out) {
+    const float *__restrict__ g_lin, const float *__restrict__ lin_mask, const int64_t *__restrict__ pos,
+    int64_t n, int F, int GD, int GW, float4 *__restrict__ out) {
   const int64_t total = n * GW;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(kBlock) void pack_grad_rows_kernel(
       v = d_rows[o * GD + sub];
     } else if (sub == GD) {
       const int64_t b = o / F;
-      v = make_float4(g_bias ? g_bias[b] : 0.f, g_lin ? g_lin[b] : 0.f, 0.f, 0.f);
+      const float lm = lin_mask ? lin_mask[o - b * F] : 1.f;  // linear_features subsets: per field
+      v = make_float4(g_bias ? g_bias[b] : 0.f, g_lin ? g_lin[b] * lm : 0.f, 0.f, 0.f);
     } else {
       v = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -204,8 +205,8 @@ extern "C" int rm_shard_route_padded(const int64_t *idx, const int64_t *field_of
 }
 
 extern "C" int rm_pack_grad_rows(const float *d_rows, const float *g_bias, const float *g_lin,
-                                 const int64_t *pos, int64_t B, int F, int D, int width, float *out,
-                                 rm_stream_t stream) {
+                                 const float *lin_field_mask, const int64_t *pos, int64_t B, int F, int D,
+                                 int width, float *out, rm_stream_t stream) {
   RM_REQUIRE(B >= 0 && F > 0 && D > 0 && D % 4 == 0 && width >= D + 4 && width % 4 == 0,
              "rm_pack_grad_rows: bad sizes (width >= D + 4, multiples of 4)");
   if (B == 0) return RM_OK;
@@ -214,8 +215,8 @@ extern "C" int rm_pack_grad_rows(const float *d_rows, const float *g_bias, const
   const int64_t n = B * F;
   const int64_t total = n * (width / 4);
   hipLaunchKernelGGL(pack_grad_rows_kernel, dim3(rm_grid_cap((total + kBlock - 1) / kBlock, 256 * 16)),
-                     dim3(kBlock), 0, (hipStream_t)stream, (const float4 *)d_rows, g_bias, g_lin, pos, n,
-                     F, D / 4, width / 4, (float4 *)out);
+                     dim3(kBlock), 0, (hipStream_t)stream, (const float4 *)d_rows, g_bias, g_lin, lin_field_mask,
+                     pos, n, F, D / 4, width / 4, (float4 *)out);
   RM_CHECK_LAUNCH("rm_pack_grad_rows");
   return RM_OK;
 }

@@ -41,7 +41,10 @@ import torch.distributed as dist
 
 import os
 
-PAD = 4  # bias, linear weight, 2 floats of padding: fused row width D + 4 (16-byte multiple)
+PAD = 4  # bias, linear weight, 2 floats of padding: EXCHANGED row width D + 4 (16-byte multiple)
+STATE = 4  # behind them, in the shard only: the bias / linear entries' optimizer moments (m_b m_l v_b v_l)
+# shard row [D + 8] = [D embedding | bias | lin | m_b | m_l | v_b | v_l | pad pad] - the layout
+# rm_sparse_optimizer_step_rows updates in place; only the first D + 4 floats ever travel
 # RECMAN_FORCE_COLLECTIVES=1: issue the all_to_all / all_reduce calls even at world size 1
 # (rehearses the RCCL path on a single GPU)
 FORCE = os.environ.get("RECMAN_FORCE_COLLECTIVES", "0") == "1"
@@ -171,10 +174,30 @@ class ShardedTable:
 
     def __init__(self, R, D, rank, world, device, gather_fn, route_fn, group=None, capacity_factor=None):
         self.R, self.D, self.W = R, D, D + PAD
+        self.LD = D + PAD + STATE
         self.rank, self.world, self.group = rank, world, group
         self.capacity_factor = capacity_factor  # None: dynamic split sizes
-        self.shard = torch.zeros(shard_rows(R, rank, world), self.W, dtype=torch.float32, device=device)
+        self.shard = torch.zeros(shard_rows(R, rank, world), self.LD, dtype=torch.float32, device=device)
         self.gather_fn, self.route_fn = gather_fn, route_fn
+
+    def init_reference(self, offsets, sizes, seed=2019):
+        """Initial values with the reference's distribution for THIS rank's rows: row r of feature f ~
+        truncated normal(0, sqrt(2 / (V_f + D))) (FeatEmbedding._upsert_variables, layers.py:95-110;
+        glorot_normal utils.py:180-183), bias and linear entries zero.  Drawn per rank (seed + rank): TF's
+        stream cannot be reproduced anyway, and the table never exists in one piece."""
+        dev = self.shard.device
+        g = torch.Generator(device=dev).manual_seed(int(seed) + 7919 * self.rank)
+        n = self.shard.shape[0]
+        glob = torch.arange(n, device=dev, dtype=torch.int64) * self.world + self.rank
+        offs = torch.tensor(list(offsets), device=dev, dtype=torch.int64)
+        feat = torch.searchsorted(offs, glob, right=True) - 1
+        std = torch.sqrt(2.0 / (torch.tensor(list(sizes), device=dev, dtype=torch.float32)[feat] + self.D))
+        self.shard.zero_()
+        for s0 in range(0, n, 1 << 22):  # in chunks: the shard is 12.5 M rows at BASELINE configs[4]
+            s1 = min(n, s0 + (1 << 22))
+            z = torch.empty(s1 - s0, self.D, device=dev)
+            torch.nn.init.trunc_normal_(z, 0.0, 1.0, -2.0, 2.0, generator=g)
+            self.shard[s0:s1, : self.D] = z * std[s0:s1, None]
 
     def load_global(self, table, bias=None, lin=None):
         """Fills the shard from full-size arrays (tests / small tables): row r -> rank r % W."""
@@ -226,7 +249,7 @@ class ShardedTable:
         the caller enqueues before lookup_finish(ex) runs while the rows travel."""
         ex = RowExchange(idx, field_off, self.world, self.route_fn, self.group, self.capacity(idx.numel()))
         served = torch.empty(len(ex.recv_ids), self.W, dtype=torch.float32, device=self.shard.device)
-        self.gather_fn(self.shard, ex.recv_ids, served)
+        self.gather_fn(self.shard[:, : self.W], ex.recv_ids, served)  # (the state columns stay home)
         ex.served = served  # keeps the send buffer alive until the exchange is done
         ex.rows, ex.rows_work = ex.fetch(served, async_op=True)
         return ex
@@ -250,6 +273,9 @@ class ShardedTable:
         """bucketed_grads [n, D+4] (row pos[o] = gradient of occurrence o) -> (local row ids,
         gradient rows) for this shard: IndexedSlices, duplicates not merged."""
         return ex.recv_ids, ex.push(bucketed_grads)
+
+
+_DENSE_L2 = ("deep_l2_reg", "cin_l2_reg", "cross_layer_l2_reg")
 
 
 def flatten_grads(grads):
@@ -358,14 +384,18 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 raise NotImplementedError(
                     f"row-sharded table: multi-valued / value features {sorted(spec.scratch_names)} "
                     "are not supported yet (single-GPU engines handle them)")
-            if spec.linear_names is not None:
-                raise NotImplementedError("row-sharded table: linear_features subsets are not supported yet")
+            for k in ("embedding_l2_reg", "linear_l2_reg"):
+                if hp.get(k, 0.0):
+                    # a dense l2 term on the table makes EVERY row's gradient non-zero (layers.py:188-193):
+                    # 25.6 GB per step at BASELINE configs[4] - the row-wise owner-side step cannot honour it
+                    raise NotImplementedError(f"row-sharded table: {k} must be 0 (a dense table gradient)")
             self._shard_args = (rank, world, group)
             self._pending = None
             self._slot = None
             self._segs = None
             self.micro_batches = int(micro_batches)
             super().__init__(spec, D, hp, device=device)
+            self._hp_full = dict(self.hp)
             self._flat_grads = flatten_grads(self.grads)
             self._acc = torch.zeros_like(self._flat_grads)
 
@@ -374,8 +404,8 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             R = self.spec.rows
             self.st = ShardedTable(R, self.D, rank, world, dev, hip_gather,
                                    HipRouter(dev, ring=self.micro_batches + 1), group, capacity_factor)
-            self.table = self.st.shard  # [R_local, D+4] fused rows
-            self.lin_field_mask = self.lin_dense_mask = None
+            self.table = self.st.shard  # [R_local, D+8]: fused rows [D | bias | lin | 2 pad] + 4 state columns
+            self._set_lin_masks()       # linear_features subsets: masked per field in the gradient rows
             self.linear_w_dense = torch.zeros(self.Dn, dtype=torch.float32, device=dev)
             self.field_off = torch.tensor(self.spec.offsets(), dtype=torch.int64, device=dev)
             self.lin_off = self.field_off
@@ -430,36 +460,42 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             loss = base.fwd_bwd(self, idx, dense, y, masks)
             # gradient rows [dE | g_fm | g_lin | 0 0], written straight in bucketed order -> owners
             ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
-                               self.dlogit if self.use_linear else None, self.ex.pos, grad_rows)
+                               self.dlogit if self.use_linear else None, self.ex.pos, grad_rows,
+                               lin_field_mask=self.lin_field_mask)
             out, work = self.ex.push(grad_rows, async_op=True)
             return loss, self.ex.recv_ids, out, work
 
-        def fwd_bwd(self, idx, dense, y, masks=None):
-            """One step.  micro_batches = M > 1 splits the batch into M equal micro-batches and
+        def fwd_bwd(self, idx, dense, y, masks=None, weight=None):
+            """One step.  weight: this rank's share of the global batch (default 1 / world: equal
+            per-rank batches; fit() passes B_local / B_global for a ragged last batch).
+            micro_batches = M > 1 splits the batch into M equal micro-batches and
             software-pipelines them: while micro-batch c computes, the rows of c+1 and the gradient
             rows of c-1 travel over xGMI (RCCL runs them on its own stream).  The gradients are the
             full-batch means either way: shard_grad_ids / shard_grad_rows (lists of M IndexedSlices
             pieces when M > 1) and self.grads."""
             M = self.micro_batches
             B = idx.shape[0]
-            if self._segs is not None and masks is None:
+            if self._segs is not None and masks is None and weight is None:
                 return self._replay_segments(idx, dense, y)
             self._alloc(B if M <= 1 else B // M)
-            l2 = any(self.hp.get(k, 0.0) for k in ("deep_l2_reg", "cin_l2_reg", "cross_layer_l2_reg",
-                                                   "embedding_l2_reg", "linear_l2_reg"))
-            if l2 and (world > 1 or M > 1):
-                raise NotImplementedError("l2 terms with a row-sharded table over several ranks / "
-                                          "micro-batches (they would be added once per rank and micro-batch)")
             # every gradient is the gradient of the GLOBAL batch mean: each rank's (micro-)batch
-            # carries 1/(world*M), the owners sum the rows they receive, the dense all_reduce sums
-            self.grad_scale = 1.0 / (world * M)
+            # carries its share `weight` / M (1 / world for equal per-rank batches), the owners sum the
+            # rows they receive, the dense all_reduce sums.  The l2 terms of the dense parameters are
+            # added ONCE: each (micro-)batch adds reg * weight / M of them (hp scaled for the call), and the
+            # shares add up to reg over ranks and micro-batches.
+            w_rank = (1.0 / world) if weight is None else float(weight)
+            self.grad_scale = w_rank / M
+            self.hp = dict(self._hp_full, **{k: self._hp_full.get(k, 0.0) * self.grad_scale for k in _DENSE_L2})
             if M <= 1:
-                loss, ids, rows, work = self._one(idx, dense, y, masks, self.grad_rows)
+                try:
+                    loss, ids, rows, work = self._one(idx, dense, y, masks, self.grad_rows)
+                finally:
+                    self.hp = self._hp_full
                 if work is not None:
                     work.wait()
                 self.shard_grad_ids, self.shard_grad_rows = ids, rows
                 allreduce_dense(self.grads, world, group, self._flat_grads, average=False)
-                return loss
+                return loss + self._l2_once()
             if B % M or masks is not None:
                 raise ValueError("micro-batching needs a batch divisible by micro_batches and no dropout masks")
             b = B // M
@@ -470,7 +506,11 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 self._pending = started
                 # start the NEXT micro-batch's exchange before this one's compute is enqueued
                 started = self.st.lookup_start(parts[c + 1][0], self.field_off) if c + 1 < M else None
-                loss, ids, rows, work = self._one(*parts[c], None, self.grad_rows_m[c])
+                try:
+                    loss, ids, rows, work = self._one(*parts[c], None, self.grad_rows_m[c])
+                except BaseException:
+                    self.hp = self._hp_full
+                    raise
                 outs.append((ids, rows, work))
                 if c == 0:
                     self._acc.copy_(self._flat_grads)
@@ -482,10 +522,24 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             for _, _, work in outs:
                 if work is not None:
                     work.wait()
+            self.hp = self._hp_full
             self.shard_grad_ids = [o[0] for o in outs]
             self.shard_grad_rows = [o[1] for o in outs]
             allreduce_dense(self.grads, world, group, self._flat_grads, average=False)
-            return total.div_(M)
+            return total.div_(M) + self._l2_once()
+
+        def _add_l2(self, loss):
+            return loss  # (the data loss only: the dense parameters' l2 value is added once per step)
+
+        def _l2_once(self):
+            """The l2 VALUE of the dense parameters with the full coefficients (identical on every rank)."""
+            if not any(self._hp_full.get(k, 0.0) for k in _DENSE_L2):
+                return 0.0
+            keep, self.hp = self.hp, self._hp_full  # (restored: capture_segments runs with the scaled copy)
+            try:
+                return base._add_l2_model(self, torch.zeros(1, dtype=torch.float32, device=self.device))
+            finally:
+                self.hp = keep
 
         # ---- hipGraph segments (fixed-capacity layout): the compute BETWEEN the collectives ----
         def capture_segments(self, idx, dense, y):
@@ -516,6 +570,8 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             router.ensure(b * F, world, cap)
             coll = world > 1 or (FORCE and dist.is_initialized())
             self.grad_scale = 1.0 / (world * M)
+            # (the dense parameters' l2 shares are baked into the captured kernels: see fwd_bwd)
+            self.hp = dict(self._hp_full, **{k: self._hp_full.get(k, 0.0) * self.grad_scale for k in _DENSE_L2})
             self._seg_loss = torch.zeros(1, dtype=torch.float32, device=dev)
             segs = []
             for c in range(M):
@@ -536,7 +592,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                                        router.overflow, router.ws)
 
             def gather(s, c):
-                ops.gather_rows(self.st.shard, s.recv_ids, s.served)
+                ops.gather_rows(self.st.shard[:, : self.st.W], s.recv_ids, s.served)
 
             def compute(s, c):
                 self._slot = s
@@ -545,7 +601,8 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 finally:
                     self._slot = None
                 ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
-                                   self.dlogit if self.use_linear else None, s.pos, s.grad_rows)
+                                   self.dlogit if self.use_linear else None, s.pos, s.grad_rows,
+                                   lin_field_mask=self.lin_field_mask)
                 if c == 0:
                     self._seg_loss.copy_(loss)
                 else:
@@ -590,6 +647,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                     gc.enable()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            self.hp = self._hp_full
 
         def _run_segments(self, eager=False):
             S, coll = self._segs, self._seg_coll
@@ -628,7 +686,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 self.shard_grad_ids = [s.recv_ids for s in S]
                 self.shard_grad_rows = [s.grad_out for s in S]
             allreduce_dense(self.grads, world, group, self._flat_grads, average=False)
-            return self._seg_loss
+            return self._seg_loss + self._l2_once()
 
         def _replay_segments(self, idx, dense, y):
             for src, dst in zip((idx, dense, y), self._seg_in):
@@ -667,6 +725,29 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                               f"{b} examples per launch)", symbol="embed_fwd_kernel", fn=fn,
                          work=self._embed_fwd_bytes(b, fm), bound="hbm")]
 
+        def optimizer(self, name="adam", lr=1e-3):
+            """The training step's second half for this engine: ShardedOptimizer(self, ...)."""
+            return ShardedOptimizer(self, name, lr)
+
+        def optimizer_probe_sharded(self, idx, dense, y, iters=5):
+            """Times the owner-side optimizer step (every rank calls it: no collective inside, but the
+            ranks stay in step).  Uses the gradients of the last fwd_bwd."""
+            opt = self.optimizer("adam", 1e-3)
+            for _ in range(2):
+                opt.step()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            for _ in range(iters):
+                opt.step()
+            ev[1].record()
+            torch.cuda.synchronize()
+            n = sum(int(i.numel()) for i in (self.shard_grad_ids if isinstance(self.shard_grad_ids, list)
+                                             else [self.shard_grad_ids]))
+            return {"ms": round(ev[0].elapsed_time(ev[1]) / iters, 4), "gradient_rows_received": n,
+                    "what": "owner-side row-wise lazy Adam on this rank's shard, straight from the gradient rows "
+                            "the backward all_to_all delivered (rm_sparse_optimizer_step_rows), + Adam on the "
+                            "all-reduced dense parameters (rm_dense_optimizer_step); NOT part of value"}
+
         def overflowed(self):
             """True when a fixed-capacity batch did not fit (host sync; clears the flag): every
             result since the last call must be discarded and redone with the dynamic layout."""
@@ -678,3 +759,51 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             return hit
 
     return Sharded()
+
+
+class ShardedOptimizer:
+    """The optimizer step of a row-sharded engine (what optimizer.minimize(...) over ALL variables is in
+    the reference, xDeepFM.py:116-126, utils.py:201-213), owner side: every rank updates ITS shard rows
+    straight from the gradient rows the backward all_to_all delivered (IndexedSlices: local row id +
+    [dE | g_bias | g_lin | 0]; duplicates summed in arrival-independent order by the stable sort inside
+    rm_sparse_optimizer_step_rows; empty fixed-capacity slots carry id -1 and are skipped), and its replica
+    of the dense parameters from the all-reduced gradient (identical on every rank, so the replicas stay
+    bit-identical).  Keras Adam / Adagrad / SGD, lazy on the table rows - the same semantics as
+    optim.SparseTableOptimizer on one GPU.  The moments of a shard row's embedding live in a second
+    [R_local, 2 D] array, those of its bias / linear entries in the row's own state columns."""
+
+    def __init__(self, engine, name="adam", lr=1e-3):
+        from . import ops
+        from .optim import FusedDenseOptimizer
+
+        if name not in ("adam", "adagrad", "gd", "sgd"):
+            raise ValueError(f"ShardedOptimizer: {name!r} unsupported (adam, adagrad, sgd)")
+        self.ops, self.e, self.name, self.lr = ops, engine, name, float(lr)
+        st, D = engine.st, engine.D
+        n = st.shard.shape[0]
+        self.mom = None
+        if name in ("adam", "adagrad"):
+            self.mom = torch.zeros(n, 2 * D, device=st.shard.device)
+            if name == "adagrad":
+                self.mom.view(n, D // 4, 2, 4)[:, :, 1, :] = 0.1
+        st.shard[:, D + 2: D + 6] = 0.0
+        if name == "adagrad":
+            st.shard[:, D + 4: D + 6] = 0.1
+        self.dense = FusedDenseOptimizer(engine, name, lr)
+        self._ws = None
+        self.t = 0
+
+    def step(self, reset=False):
+        e = self.e
+        self.t += 1
+        ids, rows = e.shard_grad_ids, e.shard_grad_rows
+        if isinstance(ids, list):  # micro-batches: ONE update per row from all their pieces together
+            ids, rows = (ids[0], rows[0]) if len(ids) == 1 else (torch.cat(ids), torch.cat(rows))
+        n = ids.numel()
+        need = self.ops.sparse_optimizer_workspace(max(n, 1))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.zeros(need, dtype=torch.uint8, device=e.device)
+        if n:
+            self.ops.sparse_optimizer_step_rows(ids.contiguous(), rows.contiguous(), e.D, e.st.shard, self.mom,
+                                                self._ws, self.t, self.name, self.lr, reset=reset)
+        self.dense.step(reset=reset)

@@ -192,9 +192,14 @@ def cross_param_grads(P, colsum, w, b, w_out, d_w, d_b, d_w_out):
 
 
 def gather_rows(table, rows, out):
+    """out[i, :] = table[rows[i], :width] with width = out.shape[1] <= table.shape[1] (the shard keeps
+    optimizer state behind the exchanged columns)."""
     n = rows.shape[0]
-    width = table.shape[1]
-    _lib.call("rm_gather_rows", _chk(table, "table", F32), _chk(rows, "rows", I64, (n,)), n, width,
+    width = out.shape[1]
+    tp, ld, cols = _rows2d(table, "table")  # (a [:, :width] view of a wider shard is fine)
+    if cols < width:
+        raise ValueError(f"gather_rows: table has {cols} columns, out needs {width}")
+    _lib.call("rm_gather_rows", tp, ld, _chk(rows, "rows", I64, (n,)), n, width,
               _chk(out, "out", F32, (n, width)), _stream())
 
 
@@ -383,15 +388,16 @@ def shard_route_padded(idx, field_off, world, cap, pos, send_ids, counts, overfl
               _chk(counts, "counts", I64, (world,)), overflow.data_ptr(), workspace.data_ptr(), _stream())
 
 
-def pack_grad_rows(d_rows, g_bias, g_lin, pos, out):
+def pack_grad_rows(d_rows, g_bias, g_lin, pos, out, lin_field_mask=None):
     B, F, D = d_rows.shape
     n, width = out.shape
     if n < B * F:
         raise ValueError("pack_grad_rows: out must have at least B*F rows")
     _lib.call("rm_pack_grad_rows", _chk(d_rows, "d_rows", F32),
               _chk(g_bias, "g_bias", F32, (B,), allow_none=True),
-              _chk(g_lin, "g_lin", F32, (B,), allow_none=True), _chk(pos, "pos", I64, (B * F,)), B, F, D,
-              width, _chk(out, "out", F32), _stream())
+              _chk(g_lin, "g_lin", F32, (B,), allow_none=True),
+              _chk(lin_field_mask, "lin_field_mask", F32, (F,), allow_none=True),
+              _chk(pos, "pos", I64, (B * F,)), B, F, D, width, _chk(out, "out", F32), _stream())
 
 
 OPT_KINDS = {"adam": 0, "adagrad": 1, "gd": 2, "sgd": 2}

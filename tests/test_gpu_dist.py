@@ -166,3 +166,104 @@ def test_segment_graphs_equal_eager_sharded_step(hip_lib, model, kw, micro):
     assert float((got[1] - want[1]).abs().max()) <= 1e-6 * max(1.0, float(want[1].abs().max()))
     for k in want[2]:
         assert float((got[2][k] - want[2][k]).abs().max()) <= 1e-6 * max(1.0, float(want[2][k].abs().max())), k
+
+
+def _train_worker(rank, world, port, model, kw, fixed, micro, segments, l2, lin_names, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("RECMAN_FORCE_COLLECTIVES", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from recman_amd import dist as rd
+        from recman_amd import engine as eng
+        from tests.cases import make_case
+
+        Bl = 24
+        spec, p, idx, dense, y, hp = make_case(model, B=world * Bl, D=16, **kw)
+        hp = dict(hp, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=l2, cross_layer_l2_reg=l2, cin_l2_reg=l2)
+        espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names, linear_names=lin_names)
+        dev = torch.device("cuda", 0)
+        s = rd.make_sharded_engine(model, espec, 16, hp, dev, rank, world,
+                                   capacity_factor=1.5 if fixed else None, micro_batches=micro)
+        s.load_params({k: v for k, v in p.items() if k in s.params})
+        full = torch.cat([p[f"{n}_feat_embed"] for n in spec.sparse_names])
+        bias = (torch.cat([p[f"{n}_feat_bias"].reshape(-1) for n in spec.sparse_names])
+                if model == "deepfm" else None)
+        R = full.shape[0]
+        s.st.load_global(full, bias=bias)  # linear weights start at zero (the reference's init), as on one GPU
+        opt = s.optimizer("adam", 0.01)    # BEFORE any graph capture: it re-homes the dense parameters
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        il, dl, yl = idx[sl].cuda(), dense[sl].cuda(), y[sl].cuda()
+        if segments:
+            s.capture_segments(il.clone(), dl.clone(), yl.clone())
+        losses = []
+        for _ in range(3):
+            losses.append(float(s.fwd_bwd(il, dl, yl)))
+            assert not s.overflowed()
+            opt.step()
+        torch.save({"rows": s.st.shard[:, : 16 + 2].cpu(), "losses": losses,
+                    "params": {k: v.detach().cpu() for k, v in s.params.items() if k != "table_shard"}},
+                   f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,kw,fixed,micro,segments,l2,lin_names", [
+    ("deepfm", {}, True, 1, False, 0.0, None),
+    ("xdeepfm", dict(cin_units=(16, 8), scale=0.2), False, 2, False, 1e-3, None),
+    ("dcn", dict(cross_layers=2, scale=0.15), True, 2, True, 1e-3, ["C1", "I0", "C3"]),
+    ("deepfm", {}, True, 2, True, 0.0, None),
+    ("dcn", dict(cross_layers=2, scale=0.15), True, 1, True, 1e-3, None),
+])
+def test_two_ranks_three_optimizer_steps_equal_single_gpu(hip_lib, tmp_path, model, kw, fixed, micro, segments, l2,
+                                                          lin_names):
+    """The sharded TRAINING step: fwd+bwd, owner-side row-wise Adam on each rank's shard from the gradient
+    rows it received, Adam on the all-reduced dense gradients - three steps on two ranks equal three steps
+    of the single-GPU engine with optim.SparseTableOptimizer + FusedDenseOptimizer on the whole batch
+    (same lazy-Adam semantics), to 1e-6; with the dense parameters' l2 terms (added once, not once per rank
+    and micro-batch) and a linear_features subset."""
+    from recman_amd import engine as eng
+    from recman_amd.optim import FusedDenseOptimizer, SparseTableOptimizer
+    from tests.cases import make_case
+
+    world, Bl = 2, 24
+    out = str(tmp_path / "t")
+    port = 29900 + (hash((model, fixed, micro, segments, l2, str(lin_names))) % 90)
+    mp.spawn(_train_worker, args=(world, port, model, kw, fixed, micro, segments, l2, lin_names, out),
+             nprocs=world, join=True)
+    res = [torch.load(f"{out}.{r}", weights_only=True) for r in range(world)]
+
+    spec, p, idx, dense, y, hp = make_case(model, B=world * Bl, D=16, **kw)
+    hp = dict(hp, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=l2, cross_layer_l2_reg=l2, cin_l2_reg=l2)
+    e = eng.ENGINES[model](eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names,
+                                           linear_names=lin_names), 16, hp)
+    e.load_params({k: v for k, v in p.items() if k in e.params})   # (no linear_w: it starts at zero)
+    sopt, dopt = SparseTableOptimizer(e, "adam", 0.01), FusedDenseOptimizer(e, "adam", 0.01)
+    ib, db, yb = idx.cuda(), dense.cuda(), y.cuda()
+    losses = []
+    for _ in range(3):
+        losses.append(float(e.fwd_bwd(ib, db, yb)))
+        sopt.step(ib)
+        dopt.step()
+    D = 16
+    for r in range(world):
+        want = e.rows[r::world, : D + 2].cpu()
+        diff = (res[r]["rows"] - want).abs()
+        err = float(diff.max())
+        assert err <= 1e-6 * max(1.0, float(want.abs().max())), (
+            f"rank {r} shard rows after 3 steps: {err:.3e}; rows off: {torch.nonzero(diff.max(1).values > 1e-6).reshape(-1).tolist()[:20]}"
+            f" of {diff.shape[0]}; per-column max {[round(float(x), 5) for x in diff.max(0).values]}")
+        for k, v in res[r]["params"].items():
+            w = e.params[k].detach().cpu()
+            assert float((v - w).abs().max()) <= 1e-6 * max(1.0, float(w.abs().max())), (r, k)
+    # the ranks' replicas of the dense parameters are bit-identical
+    for k in res[0]["params"]:
+        assert torch.equal(res[0]["params"][k], res[1]["params"][k]), k
+    # loss of the global batch = mean of the ranks' data losses + the l2 value once
+    mean_losses = [sum(res[r]["losses"][t] for r in range(world)) / world for t in range(3)]
+    for t in range(3):
+        assert abs(mean_losses[t] - losses[t]) < 2e-5, (t, mean_losses[t], losses[t])
+    assert losses[2] < losses[0]
