@@ -11,6 +11,14 @@ Differences from the reference, all deliberate and documented:
     with dropout active (DeepModel.py:103-111) and a new optimizer is built for every
     batch (xDeepFM.py:121-126); the default evaluates without dropout and keeps the
     optimizer state.
+
+Multi-GPU (new: the reference is single-process): when the process is one rank of a torch.distributed
+job (`torchrun --nproc-per-node N train.py`, backend "nccl" = RCCL; every rank constructs the same model
+on the same data and calls the same methods), the embedding table is ROW-SHARDED over the ranks
+(recman_amd/dist.py; hparams["table_sharding"] = "auto" | "row" | "none") and fit() is data parallel:
+each global mini-batch is split over the ranks, every rank runs fwd+bwd on its part, owners update
+their shard rows, the dense parameters follow the all-reduced gradient.  predict() / evaluate() run
+every rank over all rows in step (the lookups are an exchange) and return the full result everywhere.
 """
 import logging
 from time import time
@@ -46,6 +54,7 @@ class DeepModel(BaseEstimator, TransformerMixin):
         self.device = device
         self._engine = None
         self._opt = None
+        self._shard, self._w = None, None  # (rank, world) of a row-sharded table; this rank's batch share
 
     # ------------------------------------------------------------------ engine
     def _build(self):
@@ -61,6 +70,9 @@ class DeepModel(BaseEstimator, TransformerMixin):
                                linear_names=self._linear_names())
         hp = dict(self.hparams)
         hp["strict_reference"] = self.strict_reference
+        self._shard = self._dist_info()
+        if self._shard is not None:
+            return self._build_sharded(spec, hp)
         e = eng.ENGINES[self.model](spec, hp["embedding_size"], hp, task=self.task, device=self.device)
         eng.init_reference(e, self.random_seed)
         self._engine = e
@@ -77,6 +89,66 @@ class DeepModel(BaseEstimator, TransformerMixin):
             # for densified table gradients: small tables, l2 terms, FM bias dropout)
             self._dense_fused = FusedDenseOptimizer(e, hp.get("optimizer", "adam"), hp.get("learning_rate", 1e-3))
         return e
+
+    # ------------------------------------------------------------ row-sharded table (multi-GPU)
+    def _dist_info(self):
+        """(rank, world) when the table is to be row-sharded: this process is one rank of a
+        torch.distributed job with more than one rank (or hparams["table_sharding"] == "row")."""
+        import torch.distributed as dist
+
+        mode = self.hparams.get("table_sharding", "auto")
+        if mode == "none":
+            return None
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or mode == "row"):
+            return dist.get_rank(), dist.get_world_size()
+        if mode == "row":
+            return 0, 1
+        return None
+
+    def _build_sharded(self, spec, hp):
+        from .. import dist as rdist
+
+        rank, world = self._shard
+        if spec.scratch_names:
+            raise NotImplementedError("row-sharded table: multi-valued / value features are single-GPU only")
+        name = hp.get("optimizer", "adam")
+        dev = torch.device(self.device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        e = rdist.make_sharded_engine(self.model, spec, hp["embedding_size"], hp, dev, rank, world,
+                                      capacity_factor=hp.get("exchange_capacity_factor"),  # None: exact split sizes
+                                      micro_batches=int(hp.get("micro_batches", 1)))
+        e.task = self.task
+        eng.init_reference(e, self.random_seed)       # dense parameters: the same stream on every rank
+        e.st.init_reference(spec.offsets(), spec.feat_sizes, self.random_seed)
+        self._engine = e
+        self._opt = self._sparse_opt = None
+        self._shard_opt = e.optimizer(name, hp.get("learning_rate", 1e-3))
+        return e
+
+    def _local_part(self, s, t):
+        """This rank's rows [a, b) of the global batch [s, t) and its weight B_local / B_global (None:
+        fewer rows than ranks - every rank skips the batch)."""
+        rank, world = self._shard
+        n = t - s
+        base, rem = divmod(n, world)
+        if base == 0:
+            return None
+        a = s + rank * base + min(rank, rem)
+        b = a + base + (1 if rank < rem else 0)
+        return a, b, (b - a) / n
+
+    def _fit_sharded_batch(self, idx, dense, yt):
+        e = self._engine
+        M = e.micro_batches
+        if idx.shape[0] % M:           # a ragged part: this step without the micro-batch pipeline
+            e.micro_batches = 1
+        try:
+            loss = e.fwd_bwd(idx, dense, yt, weight=self._w)
+        finally:
+            e.micro_batches = M
+        self._shard_opt.step(reset=self.strict_reference)
+        return loss
 
     @property
     def variables(self):
@@ -145,6 +217,8 @@ class DeepModel(BaseEstimator, TransformerMixin):
         n = idx.shape[0]
         out = np.empty((n,), dtype=np.float32)
         mw = None if training else self._manual_weights()
+        if mw is not None and self._shard is not None:
+            raise NotImplementedError("row-sharded table: manual feature weights are single-GPU only")
         total_batch = n // self.batch_size + 1  # DeepModel.py:49
         for bi in range(total_batch):
             s, t = bi * self.batch_size, min((bi + 1) * self.batch_size, n)
@@ -200,6 +274,11 @@ class DeepModel(BaseEstimator, TransformerMixin):
         e = self._build()
         if idx.shape[0] == 0:
             return None
+        if self._shard is not None:
+            if self._dropout_masks(1) is not None:
+                raise NotImplementedError("row-sharded fit(): dropout is not wired through the exchange yet")
+            self._w = getattr(self, "_w", None)
+            return self._fit_sharded_batch(idx, dense, yt)
         side = None
         if self._sparse_opt is not None and not e.spec.scratch_names:
             # the id-only third of the row-wise step (keys + sort by row) runs on a side stream beside the
@@ -256,6 +335,7 @@ class DeepModel(BaseEstimator, TransformerMixin):
         for epoch in range(1, self.epoch + 1):
             start = time()
             seed = np.random.randint(1, 2019) if random_seed_for_mini_batch else self.random_seed
+            seed = self._same_on_all_ranks(seed)
             # sklearn.utils.shuffle(X, random_state=seed) (DeepModel.py:182-187): the same
             # permutation, applied to the encoded arrays instead of the DataFrame
             perm = np.arange(n)
@@ -269,6 +349,11 @@ class DeepModel(BaseEstimator, TransformerMixin):
                 s, t = i * self.batch_size, min((i + 1) * self.batch_size, n)
                 if t <= s:
                     continue  # the reference's trailing empty batch
+                if self._shard is not None:  # data parallel: this rank's part of the global batch
+                    part = self._local_part(s, t)
+                    if part is None:
+                        continue
+                    s, t, self._w = part
                 self._fit_encoded(idx[s:t].contiguous(), dense[s:t].contiguous(), yt[s:t].contiguous(),
                                   self._mv_batch(mv_host, s, t))
                 if i % batch_number_to_show_progress == 0:
@@ -278,7 +363,19 @@ class DeepModel(BaseEstimator, TransformerMixin):
                 epoch_callback(model=self, eval_results=eval_results, df_all=X_train[:1])
         return None  # the reference's fit returns None
 
+    def _same_on_all_ranks(self, value):
+        """Rank 0's value on every rank (the per-epoch shuffle seed must agree)."""
+        if self._shard is None or self._shard[1] == 1:
+            return value
+        import torch.distributed as dist
+
+        box = [value]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
     def _use_feeder(self, n):
+        if self._build() is not None and self._shard is not None:
+            return False  # (sharded fit keeps the encoded dataset on the GPU)
         """hparams["feeder"]: "gpu" (whole encoded dataset resident in HBM, the default while it is
         small), "pinned" (host-resident, batches through the pinned-memory feeder), or "auto":
         pinned once the encoded arrays exceed a quarter of the free HBM."""
@@ -337,7 +434,24 @@ class DeepModel(BaseEstimator, TransformerMixin):
     def save(self, path):
         """state_dict with the reference's variable names (tf.train.Checkpoint(**variables),
         BestModelFinder.py:57-68)."""
-        torch.save({k: v.cpu() for k, v in self._build().state_dict().items()}, path)
+        e = self._build()
+        if self._shard is not None:
+            # one file per rank for its shard rows (<path>.shard<r>of<W>.pt) + the dense parameters (rank 0)
+            e.st.save(path)
+            if self._shard[0] == 0:
+                torch.save({k: v.detach().cpu() for k, v in e.params.items() if k != "table_shard"}, path)
+            return
+        torch.save({k: v.cpu() for k, v in e.state_dict().items()}, path)
 
     def restore(self, path="ckpt_model.pt"):
-        self._build().load_params(torch.load(path, weights_only=True))
+        e = self._build()
+        if self._shard is not None:
+            if self._shard[1] > 1:
+                import torch.distributed as dist
+
+                dist.barrier()  # rank 0's file must be complete
+            for k, v in torch.load(path, weights_only=True).items():
+                e.params[k].copy_(v.to(e.device))
+            e.st.load(path)
+            return
+        e.load_params(torch.load(path, weights_only=True))

@@ -267,3 +267,69 @@ def test_two_ranks_three_optimizer_steps_equal_single_gpu(hip_lib, tmp_path, mod
     for t in range(3):
         assert abs(mean_losses[t] - losses[t]) < 2e-5, (t, mean_losses[t], losses[t])
     assert losses[2] < losses[0]
+
+
+def _fit_worker(rank, world, port, model, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("RECMAN_FORCE_COLLECTIVES", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import numpy as np
+        from sklearn.metrics import log_loss
+
+        import recman_amd.th as th
+        from tests.test_gpu_models import ml_features, ml_frame
+
+        df = ml_frame().iloc[:1000]          # 1000 rows, batch 96: a ragged last batch (40 rows -> 20 + 20)
+        fd = ml_features(df)
+        hp = {"embedding_size": 16, "deep_dropout": (1, 1, 1), "cin_cross_layer_units": [16, 16],
+              "cin_dropout": [1, 1, 1], "learning_rate": 0.01, "embedding_l2_reg": 0.0, "linear_l2_reg": 0.0,
+              "deep_l2_reg": 1e-4, "micro_batches": 2}
+        if model == "xdeepfm":
+            m = th.xDeepFM(fd, hp, epoch=2, batch_size=96)
+        else:
+            m = th.DeepFM(fd, embedding_size=16, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_dropout=(1, 1, 1),
+                          learning_rate=0.01, epoch=2, batch_size=96)
+        yv = df["label"].values
+        before = log_loss(yv, m.predict(df).astype(np.float64))
+        assert m._shard == (rank, world) and m._engine.st.shard.shape[0] < m._engine.spec.rows
+        m.fit(df, yv, random_seed_for_mini_batch=True)   # the shuffle seed is rank 0's on every rank
+        pred = m.predict(df)
+        after = log_loss(yv, pred.astype(np.float64))
+        path = f"{out_path}.ckpt"
+        m.save(path)
+        dist.barrier()
+        m2 = (th.xDeepFM(fd, hp, epoch=1, batch_size=96) if model == "xdeepfm" else
+              th.DeepFM(fd, embedding_size=16, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_dropout=(1, 1, 1),
+                        epoch=1, batch_size=96))
+        m2.restore(path)
+        pred2 = m2.predict(df)
+        torch.save({"before": float(before), "after": float(after), "pred": torch.from_numpy(pred),
+                    "pred_restored": torch.from_numpy(pred2),
+                    "dense": {k: v.detach().cpu() for k, v in m._engine.params.items() if k != "table_shard"}},
+                   f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["deepfm", "xdeepfm"])
+def test_model_fit_predict_save_restore_with_a_row_sharded_table_on_two_ranks(hip_lib, tmp_path, model):
+    """The model classes under a two-rank torch.distributed job: the table row-sharded, fit() data parallel
+    (ragged last batch, micro-batches, dense l2), predict() on every rank, save() / restore() with one shard
+    file per rank.  Both ranks end with identical predictions and identical dense parameters, the loss
+    went down, a restored model predicts the same."""
+    world = 2
+    out = str(tmp_path / "f")
+    mp.spawn(_fit_worker, args=(world, 29990 + (1 if model == "xdeepfm" else 0), model, out), nprocs=world, join=True)
+    res = [torch.load(f"{out}.{r}", weights_only=True) for r in range(world)]
+    assert res[0]["after"] < res[0]["before"] - 0.01
+    assert torch.equal(res[0]["pred"], res[1]["pred"])
+    for k in res[0]["dense"]:
+        assert torch.equal(res[0]["dense"][k], res[1]["dense"][k]), k
+    for r in range(world):
+        assert float((res[r]["pred"] - res[r]["pred_restored"]).abs().max()) < 1e-6
+    assert os.path.exists(f"{out}.ckpt.shard0of2.pt") and os.path.exists(f"{out}.ckpt.shard1of2.pt")

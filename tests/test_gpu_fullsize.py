@@ -139,3 +139,111 @@ def test_full_size_properties(hip_lib, model):
     acc.index_add_(0, inv0, e.d_rows[:, 0, :].detach().cpu().double())
     # (row gradients pass through every layer of the backward in fp32: 2e-4 of the largest entry)
     assert float((acc - want_rows).abs().max()) <= 2e-4 * max(1e-12, float(want_rows.abs().max()))
+
+
+def test_config4_100m_rows_row_sharded_path_full_size(hip_lib):
+    """BASELINE configs[4] - xDeepFM on a 100 M-row x 64-dim table, row-sharded - at FULL size through the
+    sharded code path at world size 1 (the shard is the whole table: 100,000,004 rows x 72 floats = 28.8 GB
+    on the one test GPU; the same route | gather | exchange-order | pack | owner-side-update kernels run,
+    the all_to_alls degenerate to identity).  Size-independent properties + the oracle on a slice:
+      * determinism of a step (loss, logits, every dense gradient, the gradient rows),
+      * linearity of the mean over the two halves of the batch,
+      * oracle logits / loss / dense gradients on the last 512 examples (float64 CPU pass over the touched rows),
+      * one owner-side optimizer step touches exactly the rows of the batch, bit-reproducibly."""
+    from recman_amd import dist as rd
+    from recman_amd import engine as eng
+
+    F, V, Dn, D, B = 26, 3_846_154, 13, 64, 65536
+    hp = dict(deep_hidden_units=(32, 32), deep_activation="leaky_relu", cin_cross_layer_units=(128, 128),
+              cin_activation="leaky_relu", embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=0.0, cin_l2_reg=0.0)
+    spec = eng.FeatureSpec([f"C{i + 1}" for i in range(F)], [V] * F, [f"I{j + 1}" for j in range(Dn)])
+    e = rd.make_sharded_engine("xdeepfm", spec, D, hp, torch.device("cuda", 0), 0, 1, capacity_factor=1.0,
+                               micro_batches=1)
+    assert e.st.shard.shape == (F * V, D + 8)
+    g = torch.Generator(device="cuda").manual_seed(2019)
+    e.st.init_reference(spec.offsets(), spec.feat_sizes, 2019)
+    e.st.shard[:, D + 1].normal_(0, 0.01, generator=g)               # linear weights
+    for k, v in e.params.items():
+        if k != "table_shard":
+            v.normal_(0, 0.01, generator=g)
+    idx = torch.randint(0, V, (B, F), generator=g, device="cuda")
+    dense = torch.randn(B, Dn, generator=g, device="cuda")
+    y = (torch.rand(B, generator=g, device="cuda") < 0.25).long()
+
+    def rows_sum():
+        dt = torch.zeros(4096, D + rd.PAD, device="cuda", dtype=torch.float64)   # hashed: a checksum of the rows
+        ids, rows = e.shard_grad_ids, e.shard_grad_rows
+        live = ids >= 0
+        dt.index_add_(0, ids[live] % 4096, rows[live].double())
+        return dt
+
+    loss = e.fwd_bwd(idx, dense, y).clone()
+    assert not e.overflowed()
+    logit, grads, chk = e.logit.clone(), {k: v.clone() for k, v in e.grads.items()}, rows_sum()
+    loss2 = e.fwd_bwd(idx, dense, y)
+    assert torch.equal(loss2, loss) and torch.equal(e.logit, logit) and torch.equal(rows_sum(), chk)
+    for k in grads:
+        assert torch.equal(e.grads[k], grads[k]), k
+    # linearity of the mean
+    h = B // 2
+    acc, lsum = {k: torch.zeros_like(v) for k, v in grads.items()}, 0.0
+    for sl in (slice(0, h), slice(h, B)):
+        lsum = lsum + e.fwd_bwd(idx[sl].contiguous(), dense[sl].contiguous(), y[sl].contiguous())
+        for k in acc:
+            acc[k] += e.grads[k]
+    assert abs(float(lsum) / 2 - float(loss)) < 1e-6
+    for k, want in grads.items():
+        assert float((acc[k] / 2 - want).abs().max()) <= 2e-5 * max(1e-3, float(want.abs().max())), k
+    # the oracle on a slice (the table rows it touches, compacted)
+    n = 512
+    sl = slice(B - n, B)
+    e.fwd_bwd(idx[sl].contiguous(), dense[sl].contiguous(), y[sl].contiguous())
+    assert torch.equal(e.logit, logit[sl]), "logits depend on the rest of the batch"
+    p = {k: v.detach().cpu().double() for k, v in e.params.items() if k not in ("table_shard", "linear_w_dense")}
+    idx_c = idx[sl].cpu()
+    small_sizes, idx_small, lin_parts = [], torch.empty_like(idx_c), []
+    offs = spec.offsets()
+    for f, name in enumerate(spec.sparse_names):
+        uniq, inv = torch.unique(idx_c[:, f], return_inverse=True)
+        small_sizes.append(len(uniq))
+        idx_small[:, f] = inv
+        rows = e.st.shard[(offs[f] + uniq).cuda()].cpu().double()
+        p[f"{name}_feat_embed"] = rows[:, :D].contiguous()
+        lin_parts.append(rows[:, D + 1: D + 2])
+    lin_parts.append(e.params["linear_w_dense"].detach().cpu().double().view(-1, 1))
+    p["linear_w"] = torch.cat(lin_parts)
+    small = T.Spec(spec.sparse_names, small_sizes, spec.dense_names)
+    loss_o, logit_o, _, grads_o = T.fwd_bwd("xdeepfm", p, small, idx_small, dense[sl].cpu().double(), y[sl].cpu(), hp)
+    assert float((e.logit.cpu().double() - logit_o).abs().max()) < 1e-5
+    assert abs(float(e.loss) - float(loss_o)) < 1e-5
+    checked = 0
+    for k, gk in e.grads.items():
+        if k not in grads_o:
+            continue
+        want = grads_o[k].reshape(-1)
+        err = (gk.detach().cpu().double().reshape(-1) - want).abs()
+        scale = float(want.abs().max())
+        off = int((err > 2e-5 * torch.clamp(want.abs(), min=0.1 * scale)).sum())
+        assert off <= max(2, want.numel() // 100) and float(err.max()) <= 1e-3 * scale, (k, off, float(err.max()), scale)
+        checked += 1
+    assert checked >= 8
+    # one owner-side optimizer step at this size: touches exactly the batch's rows, reproducibly
+    e.fwd_bwd(idx, dense, y)
+    opt = e.optimizer("adam", 1e-3)
+    touched = torch.unique((idx + e.field_off).reshape(-1))
+    probe = torch.cat([touched[:5000], (touched[:5000] + 1) % (F * V)])
+    before = e.st.shard[probe, : D + 2].clone()
+    opt.step()
+    after = e.st.shard[probe, : D + 2].clone()
+    is_touched = torch.isin(probe, touched)
+    assert bool(((after - before).abs().max(1).values > 0)[is_touched].all())
+    assert bool(((after - before).abs().max(1).values == 0)[~is_touched].all())
+    e.st.shard[probe, : D + 2] = before
+    opt.mom[probe] = 0
+    e.st.shard[probe, D + 2: D + 6] = 0
+    opt.t = 0
+    opt.dense.t = 0
+    opt.step()
+    assert torch.equal(e.st.shard[probe[is_touched], : D + 2], after[is_touched])
+    del e, opt
+    torch.cuda.empty_cache()
