@@ -1,14 +1,18 @@
 #!/bin/bash
-# Regenerates the round's final bench lines and rocprofv3 kernel summaries on the GPU box:
-#   gpurun -- 'bash tools/final_profiles.sh'   then copy gpurun_out/final/* into profiles/.
+# Regenerates a round's bench line and rocprofv3 kernel summaries on the GPU box:
+#   gpurun -- 'bash tools/final_profiles.sh r02'   then copy gpurun_out/final_r02/* into profiles/.
 set -e
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/final
+out=gpurun_out/final_$tag
 mkdir -p $out
+python3 bench.py --steps 30 --warmup 5 > $out/bench_default.json 2> $out/bench_default.err
 for w in deepfm xdeepfm dcn; do
-  python bench.py --workload $w --steps 30 --warmup 5 > $out/bench_$w.json
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$w -- python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --no-graph > /dev/null 2>&1
-  python tools/prof_summary.py $out/prof_$w 30 > $out/summary_$w.md
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$w -- python3 bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --no-graph --no-pmc --no-optimizer > /dev/null 2>&1
+  python3 tools/prof_summary.py $out/prof_$w 30 > $out/summary_$w.md
 done
-python bench.py --zipf 1.05 --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_deepfm_zipf.json
+bash tools/pmc_kernel.sh ${tag}_cross tools/bench_cross.py > /dev/null 2>&1 || true
+bash tools/pmc_kernel.sh ${tag}_optim tools/bench_optim.py > /dev/null 2>&1 || true
+cp gpurun_out/${tag}_cross/summary.md $out/pmc_cross.md 2>/dev/null || true
+cp gpurun_out/${tag}_optim/summary.md $out/pmc_optim.md 2>/dev/null || true
 echo done
