@@ -9,15 +9,15 @@
 //   rm_dense_fwd   C[M,N]  = epilogue([A1 | A2][M,K] . op(W))      "NN": M = batch
 //   rm_dense_wgrad dW[K,N] = [A1 | A2]^T . G[M,N]                   "TN": reduction over batch
 //
-// NN kernel: block = 8 waves = 4 row groups x 2 column groups; a wave owns 32 rows x NT 32-column
-// blocks (NT <= 7: a 13-block N = 400 splits 7 + 6 over the two waves of one SIMD, so every SIMD
-// issues 13 MFMAs per k-step).  (4-wave blocks, two per CU, were slower: each weight chunk is
-// then staged for 64 rows instead of 128 and the 7/6 split unbalances the SIMDs.)  A is loaded straight into the MFMA operand layout (a lane reads
-// 16 B of its own row per 8 k), the weight chunk [16 k][cols] is staged in LDS, double-buffered,
-// pre-arranged by dense_prep_kernel so that a lane's NT operands are two ds_read_b128.
+// NN kernel: block = 4 waves (one per SIMD) = 128 batch rows x ONE column group of <= 7 32-column blocks
+// (a 13-block N = 400 is two groups, 7 + 6), two blocks per CU: the blocks drift out of phase, so one's
+// MFMAs cover the other's barriers, staging and epilogue.  The A tile [128][32 k] and the group's weight
+// chunk [16 k][<= 224 cols] are staged in LDS, double-buffered; the weights are pre-arranged by
+// dense_prep_kernel so that a lane's NT operands are two ds_read_b128.
 // TN kernel: no LDS at all - both operands are row-contiguous along the MFMA's M / N index, so
 // every wave loads them coalesced (128 B per half-wave) in operand layout; the batch is split
 // into slabs, partial tiles go to a workspace and a second kernel reduces them (deterministic).
+#include <cstdlib>
 #include <type_traits>
 
 #include "rm_common.h"
@@ -25,6 +25,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 #ifndef RM_GEMM_KC
 #define RM_GEMM_KC 16
@@ -32,13 +33,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef RM_GEMM_SGB
 #define RM_GEMM_SGB 0
 #endif
+// ablation builds of the NN kernel (WRONG results; tools/bench_dense.py + `python -m recman_amd.build --out`):
+// 1 no epilogue stores, 2 no per-chunk barrier, 4 no weight loads, 8 no A loads / commits,
+// 16 no B operand reads in the k-steps, 32 no weight ds_writes
+#ifndef RM_NN_ABL
+#define RM_NN_ABL 0
+#endif
+// diagnostic build (-DRM_NN_STAMP): wave 0 of every NN block records s_memrealtime (100 MHz) at block
+// start / after the prologue / after the chunk loop / after the epilogue + its HW_ID; read back with
+// rm_debug_nn_stamps (tools/probe/nn_stamps.py).  Never defined in the product build.
+#ifdef RM_NN_STAMP
+__device__ unsigned long long rm_nn_stamp_buf[8 * 8192];
+#define RM_STAMP(i_)                                                                              \
+  if (tid == 0 && blockIdx.x < 8192) rm_nn_stamp_buf[8 * blockIdx.x + (i_)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define RM_STAMP(i_)
+#endif
 constexpr int KC = RM_GEMM_KC;               // k per staged weight chunk
 constexpr int kRowsPerBlock = 128;           // TN kernel: 4 row groups x 32 rows of K
 constexpr int kNNRows = 128;                 // NN kernel: 4 row groups x 32 batch rows per block
-constexpr int kNNThreads = 512;              // 8 waves = 2 per SIMD (one 7-block and one 6-block wave)
+constexpr int kNNThreads = 256;              // 4 waves = one per SIMD; two blocks per CU
 constexpr int kMaxNB = 14;                   // 32-column blocks per column tile (2 x 7)
 constexpr int kTileCols = kMaxNB * 32;       // 448
-constexpr int WCH = KC * 2 * 2 * 32 * 4;     // floats per prepped chunk: [k][g][half][c][4] = 32 KB
+constexpr int WCHG = KC * 2 * 32 * 4;        // floats per prepped chunk of ONE column group: [k][half][c][4] = 16 KB
+constexpr int WCH = 2 * WCHG;                // both groups of a column tile
 constexpr int kThreads = 512;
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -62,15 +80,16 @@ __host__ __device__ inline ColTile col_tile(int N, int ct) {
   return ColTile{nb, (nb + 1) / 2};
 }
 
-// Wp[ct][chunk][k][g][half][c][j] = op(W)[chunk*16 + k][col(ct, g, nt = half*4 + j, c)], zero padded
+// Wp[ct][g][chunk][k][half][c][j] = op(W)[chunk*16 + k][col(ct, g, nt = half*4 + j, c)], zero padded:
+// the chunks of ONE column group are contiguous (a block stages only its own group's 16 KB per chunk)
 __global__ void dense_prep_kernel(const float *__restrict__ W, int64_t ldw, int trans, int K, int N,
                                   int nch, int nct, float *__restrict__ Wp) {
-  const int64_t total = (int64_t)nct * nch * WCH;
+  const int64_t total = (int64_t)nct * 2 * nch * WCHG;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
-    const int j = t & 3, c = (t >> 2) & 31, half = (t >> 7) & 1, g = (t >> 8) & 1, k = (t >> 9) & (KC - 1);
-    const int64_t chunk = t / WCH;
-    const int ch = (int)(chunk % nch), ct = (int)(chunk / nch);
+    const int j = t & 3, c = (t >> 2) & 31, half = (t >> 7) & 1, k = (t >> 8) & (KC - 1);
+    const int64_t chunk = t / WCHG;
+    const int ch = (int)(chunk % nch), g = (int)((chunk / nch) & 1), ct = (int)(chunk / (2 * nch));
     const ColTile tl = col_tile(N, ct);
     const int nt = half * 4 + j;
     const int ntw = g == 0 ? tl.nt0 : tl.nb - tl.nt0;
@@ -96,6 +115,8 @@ struct NNArgs {
   int64_t M;
   float *C, *C2;
   int64_t ldc, ldc2;
+  int span, groups;  // blockIdx.x -> (row tile, column group): see dense_nn_kernel
+  int stagger_ticks; // 100 MHz ticks the odd-group blocks of the first round wait before they start
 };
 
 constexpr int AQ = KC / 8;  // float4 of A fragments per lane per weight chunk
@@ -105,93 +126,144 @@ constexpr int AQ = KC / 8;  // float4 of A fragments per lane per weight chunk
 // of column blocks that really exist (the prepped weights of the others are zero).
 template <int NT>
 __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int c, int h, int rg,
-                                        int cg, int ct, const ColTile tl, int ntw) {
-  const int64_t row0 = (int64_t)blockIdx.x * kNNRows + 32 * rg;
-  const float *Wp = a.Wp + (int64_t)ct * a.nch * WCH;
+                                        int cg, int ct, const ColTile tl, int ntw, int64_t tile) {
+  const int64_t row0 = tile * kNNRows + 32 * rg;
+  const float *Wp = a.Wp + (int64_t)(ct * 2 + cg) * a.nch * WCHG;
 
+  RM_STAMP(0);
+#ifdef RM_NN_STAMP
+  if (tid == 0 && blockIdx.x < 8192) {
+    rm_nn_stamp_buf[8 * blockIdx.x + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    rm_nn_stamp_buf[8 * blockIdx.x + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+    rm_nn_stamp_buf[8 * blockIdx.x + 5] = cg;
+  }
+#endif
+  // the accumulators START at bias[col] (a lane's 16 outputs of a column block share one column): no
+  // bias loads or adds in the epilogue, where every VALU instruction is expensive (see below)
   f32x16 acc[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = ct * kTileCols + 32 * (cg == 0 ? nt : tl.nt0 + nt) + c;
+    const float bn = (a.bias != nullptr && nt < ntw) ? a.bias[col < a.N ? col : a.N - 1] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[nt][r] = bn;
+  }
 
   // A goes through LDS in FULL 128-byte lines: per group of 32 k the block stages its 128 rows once
-  // (8 lanes per row) and both column-group waves read their fragments from there.  The first
-  // version loaded fragments straight to registers - 32 rows x 32 bytes per instruction, issued
-  // twice (once per column group): +85 us of 525 in the ablation (profiles/r01_p8).
+  // (8 lanes per row) and the waves read their fragments from there.
   constexpr int AG = 32;                      // k per A group = 2 weight chunks
   constexpr int ALD = AG + 4;                 // LDS row stride of the A tile (floats)
-  float *As = Ws + 2 * WCH;                   // [2][kNNRows][ALD]
-  const int64_t brow0 = (int64_t)blockIdx.x * kNNRows;
+  float *As = Ws + 2 * WCHG;                  // [2][kNNRows][ALD]
+  const int64_t brow0 = tile * kNNRows;
   const int ngroups = (a.nch + 1) / 2;
   const int gfast = a.a_vec ? a.K1 / AG : 0;  // groups inside A1 that float4 loads can take
   const float *A2 = a.K2 > 0 ? a.A2 : a.A1;
   const int64_t lda2 = a.K2 > 0 ? a.lda2 : a.lda1;
-  // this thread's two float4 of a group: f = tid + 512*i -> row f >> 3, piece f & 7
-  auto load_group = [&](int g, int i) -> float4 {
-    const int f = tid + i * kNNThreads, r = f >> 3, piece = f & 7;
-    int64_t gr = brow0 + r;
+  // this thread's four float4 of a group: f = tid + 256*i -> row f >> 3, piece f & 7.
+  // Two loaders, picked at COMPILE time per loop (a run-time `if (g < gfast)` inside one loop made
+  // hipcc join the two paths behind s_waitcnt vmcnt(0): every A group then waited for the weight
+  // prefetch issued just before it AND for its own first load, profiles/r02_dense_gemm.md):
+  //   fast: the group lies inside A1 with 16-byte rows -> one float4;
+  //   slow: the ragged groups (x = [A1 | A2] boundary, end of K): both candidates of every element
+  //   through raw buffer loads (unconditional by construction; rows past M read as 0) and the
+  //   choice A1 / A2 / zero is made at commit time, behind the chunk's MFMAs.
+  const int piece = tid & 7, arow = tid >> 3;  // + 32 i
+  auto load_fast = [&](int g, int i) -> float4 {
+    int64_t gr = brow0 + arow + 32 * i;
     gr = gr < a.M ? gr : a.M - 1;
+    return *reinterpret_cast<const float4 *>(a.A1 + gr * a.lda1 + g * AG + 4 * piece);
+  };
+  const int64_t rows_here = a.M - brow0 < kNNRows ? a.M - brow0 : kNNRows;
+  const rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.A1 + brow0 * a.lda1), 0,
+                                                       (int)((rows_here - 1) * a.lda1 + a.K1) * 4, 0x00020000);
+  const rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A2 + brow0 * lda2), 0,
+                                                       (int)((rows_here - 1) * lda2 + (a.K2 > 0 ? a.K2 : a.K1)) * 4,
+                                                       0x00020000);
+  auto load_slow = [&](int g, int i, float4 &x1, float4 &x2) {
+    const int r = arow + 32 * i, k = g * AG + 4 * piece;
+    float t1[4], t2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kk = k + e, k2 = kk - a.K1;
+      const int o1 = (r * (int)a.lda1 + (kk < a.K1 ? kk : 0)) * 4;
+      const int o2 = (r * (int)lda2 + ((k2 >= 0 && k2 < a.K2) ? k2 : 0)) * 4;
+      t1[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, o1, 0, 0));
+      t2[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, o2, 0, 0));
+    }
+    x1 = make_float4(t1[0], t1[1], t1[2], t1[3]);
+    x2 = make_float4(t2[0], t2[1], t2[2], t2[3]);
+  };
+  auto pick_slow = [&](int g, const float4 &x1, const float4 &x2) -> float4 {
     const int k = g * AG + 4 * piece;
-    if (g < gfast) return *reinterpret_cast<const float4 *>(a.A1 + gr * a.lda1 + k);
+    const float v1[4] = {x1.x, x1.y, x1.z, x1.w}, v2[4] = {x2.x, x2.y, x2.z, x2.w};
     float t[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {  // ragged group: A1 / second piece / zero, by selects
-      const int kk = k + e;
-      const bool in1 = kk < a.K1;
-      const int k2 = kk - a.K1;
-      const bool in2 = !in1 && k2 < a.K2;
-      const float x1 = a.A1[gr * a.lda1 + (in1 ? kk : 0)];
-      const float x2 = A2[gr * lda2 + (in2 ? k2 : 0)];
-      t[e] = in1 ? x1 : (in2 ? x2 : 0.f);
+    for (int e = 0; e < 4; ++e) {
+      const int kk = k + e, k2 = kk - a.K1;
+      t[e] = kk < a.K1 ? v1[e] : ((k2 < a.K2) ? v2[e] : 0.f);
     }
     return make_float4(t[0], t[1], t[2], t[3]);
   };
-  const int a_lds0 = (tid >> 3) * ALD + 4 * (tid & 7);                   // float4 slot i = 0
-  const int a_lds1 = ((tid + kNNThreads) >> 3) * ALD + 4 * (tid & 7);    // float4 slot i = 1
+  auto load_group = [&](int g, int i) -> float4 {  // prologue only (waits right away)
+    if (g < gfast) return load_fast(g, i);
+    float4 x1, x2;
+    load_slow(g, i, x1, x2);
+    return pick_slow(g, x1, x2);
+  };
+  const int a_lds = arow * ALD + 4 * piece;  // float4 slot i: + 32 i rows
 
   // prologue: weight chunk 0 and A group 0 to LDS
-  constexpr int WQ = WCH / 4 / kNNThreads;  // float4 of a weight chunk per thread
+  constexpr int WQ = WCHG / 4 / kNNThreads;  // float4 of a weight chunk per thread
+  static_assert(WQ == 4 && kNNRows * 8 / kNNThreads == 4, "the staging below is written out for 4 + 4 float4 per thread");
 #pragma unroll
   for (int q = 0; q < WQ; ++q)
     *reinterpret_cast<float4 *>(Ws + (tid + q * kNNThreads) * 4) =
         *reinterpret_cast<const float4 *>(Wp + (tid + q * kNNThreads) * 4);
-  *reinterpret_cast<float4 *>(As + a_lds0) = load_group(0, 0);
-  *reinterpret_cast<float4 *>(As + a_lds1) = load_group(0, 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(As + a_lds + 32 * i * ALD) = load_group(0, i);
   __syncthreads();
+  RM_STAMP(1);
+#ifdef RM_NN_STAMP
+  const uint64_t clk0 = __builtin_amdgcn_s_memtime();
+#endif
 
   // B operands of one k-step: the lane's NT weights = two ds_read_b128
   auto read_b = [&](const float *Wb, int s, float4 &t0, float4 &t1) {
     const int k = 8 * (s >> 2) + 4 * h + (s & 3);
-    const float *wp = Wb + ((k * 2 + cg) * 2) * 128 + c * 4;
+    const float *wp = Wb + k * 256 + c * 4;
     t0 = *reinterpret_cast<const float4 *>(wp);
     if constexpr (NT > 4) t1 = *reinterpret_cast<const float4 *>(wp + 128);
   };
-  float4 an0, an1;  // the next A group, in flight over the two chunks of the current one
+  // the next A group, in flight over the two chunks of the current one (named registers: arrays
+  // captured by the lambda went to scratch); b*: the slow loader's A2 candidates
+  float4 an0, an1, an2, an3, bn0, bn1, bn2, bn3;
   // one weight chunk: prefetch the next chunk (always - the last iteration re-loads its own chunk
   // into the idle buffer: a conditional prefetch made hipcc park the registers in scratch behind
   // an s_waitcnt vmcnt(0)), KC/2 k-steps of MFMAs, commit the prefetch, barrier.
   // first_of_group: also issue the next A group's loads; otherwise commit them before the barrier.
-  auto chunk = [&](int ch, auto first_of_group) {
+  auto chunk = [&](int ch, auto first_of_group, auto fast_loader) {
     constexpr bool kFirst = decltype(first_of_group)::value;
+    constexpr bool kFast = decltype(fast_loader)::value;
     const int nx = ch + 1 < a.nch ? ch + 1 : ch;
-    const float *wsrc = Wp + (int64_t)nx * WCH + tid * 4;
-    static_assert(WQ <= 8, "the prefetch below is written out for up to 8 float4 per thread");
-    // named registers: a float4 w[WQ] array captured by this lambda went to scratch
+    const float *wsrc = Wp + (int64_t)nx * WCHG + tid * 4;
 #define RM_W(q) \
-  const float4 w##q = q < WQ ? *reinterpret_cast<const float4 *>(wsrc + (q < WQ ? q : 0) * kNNThreads * 4) : float4{}
-    RM_W(0); RM_W(1); RM_W(2); RM_W(3); RM_W(4); RM_W(5); RM_W(6); RM_W(7);
+  const float4 w##q = !(RM_NN_ABL & 4) ? *reinterpret_cast<const float4 *>(wsrc + q * kNNThreads * 4) : float4{}
+    RM_W(0); RM_W(1); RM_W(2); RM_W(3);
 #undef RM_W
     const int g = ch >> 1;
-    if constexpr (kFirst) {
-      const int gn = g + 1 < ngroups ? g + 1 : g;
-      an0 = load_group(gn, 0);
-      an1 = load_group(gn, 1);
+    const int gn = g + 1 < ngroups ? g + 1 : g;
+    if constexpr (kFirst && !(RM_NN_ABL & 8)) {
+      if constexpr (kFast) {
+        an0 = load_fast(gn, 0); an1 = load_fast(gn, 1); an2 = load_fast(gn, 2); an3 = load_fast(gn, 3);
+      } else {
+        load_slow(gn, 0, an0, bn0); load_slow(gn, 1, an1, bn1);
+        load_slow(gn, 2, an2, bn2); load_slow(gn, 3, an3, bn3);
+      }
     }
     // keep the prefetch HERE: without the fence the scheduler sinks the global loads to their
     // first use (the ds_write at the end of the chunk) and the whole L2 latency is exposed
     __builtin_amdgcn_sched_barrier(0);
-    const float *Wb = Ws + (ch & 1) * WCH;
+    const float *Wb = Ws + (ch & 1) * WCHG;
     // this lane's A fragments of the chunk: row 32*rg + c, k = 16*(ch & 1) + 8q + 4h + e
     const float *ap = As + (g & 1) * (kNNRows * ALD) + (32 * rg + c) * ALD + 16 * (ch & 1) + 4 * h;
     float4 acur[AQ];
@@ -202,13 +274,13 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
 #if RM_GEMM_SGB
     // the schedule groups are filled in PROGRAM order: this one takes the chunk's opening reads (A
     // fragments + step 0's weights), so that inside the loop [reads of step s + 1] precede [MFMAs of
-    // step s].  Without the pinning hipcc issued every step's reads right before their MFMAs behind
-    // an s_waitcnt lgkmcnt (two exposed LDS latencies per k-step: profiles/r01_p11).
+    // step s].  (Measured neutral-to-slower on this kernel: profiles/r01_p11.)
     __builtin_amdgcn_sched_group_barrier(0x100, AQ + (NT > 4 ? 2 : 1), 0);
 #endif
 #pragma unroll
     for (int s = 0; s < KC / 2; ++s) {
-      if (s + 1 < KC / 2) read_b(Wb, s + 1, b0[(s + 1) & 1], b1[(s + 1) & 1]);
+      if (s + 1 < KC / 2 && !(RM_NN_ABL & 16)) read_b(Wb, s + 1, b0[(s + 1) & 1], b1[(s + 1) & 1]);
+      if (RM_NN_ABL & 16) { b0[(s + 1) & 1] = b0[s & 1]; b1[(s + 1) & 1] = b1[s & 1]; }
       const float4 aq = acur[s >> 2];
       const float av = (s & 3) == 0 ? aq.x : ((s & 3) == 1 ? aq.y : ((s & 3) == 2 ? aq.z : aq.w));
       const float4 t0 = b0[s & 1], t1 = b1[s & 1];
@@ -223,84 +295,171 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
     }
 #if RM_GEMM_SGB
     __builtin_amdgcn_sched_barrier(0);  // the commit of the prefetch stays BEHIND the chunk's MFMAs
+#else
+    // (slow loader: hipcc hoisted pick_slow's selects - and their s_waitcnt vmcnt - above the MFMAs)
+    if constexpr (!kFast && !kFirst) __builtin_amdgcn_sched_barrier(0);
 #endif
-    float *wdst = Ws + ((ch + 1) & 1) * WCH + tid * 4;
+    float *wdst = Ws + ((ch + 1) & 1) * WCHG + tid * 4;
 #define RM_W(q) \
-  if constexpr (q < WQ) *reinterpret_cast<float4 *>(wdst + q * kNNThreads * 4) = w##q
-    RM_W(0); RM_W(1); RM_W(2); RM_W(3); RM_W(4); RM_W(5); RM_W(6); RM_W(7);
+  if constexpr (!(RM_NN_ABL & 32)) *reinterpret_cast<float4 *>(wdst + q * kNNThreads * 4) = w##q
+    RM_W(0); RM_W(1); RM_W(2); RM_W(3);
 #undef RM_W
-    if constexpr (!kFirst) {  // the group is done after this chunk: publish the next one
-      float *adst = As + ((g + 1) & 1) * (kNNRows * ALD);
-      *reinterpret_cast<float4 *>(adst + a_lds0) = an0;
-      *reinterpret_cast<float4 *>(adst + a_lds1) = an1;
+    if constexpr (!kFirst && !(RM_NN_ABL & 8)) {  // the group is done after this chunk: publish the next one
+      float *adst = As + ((g + 1) & 1) * (kNNRows * ALD) + a_lds;
+      if constexpr (kFast) {
+        *reinterpret_cast<float4 *>(adst) = an0;
+        *reinterpret_cast<float4 *>(adst + 32 * ALD) = an1;
+        *reinterpret_cast<float4 *>(adst + 64 * ALD) = an2;
+        *reinterpret_cast<float4 *>(adst + 96 * ALD) = an3;
+      } else {
+        *reinterpret_cast<float4 *>(adst) = pick_slow(gn, an0, bn0);
+        *reinterpret_cast<float4 *>(adst + 32 * ALD) = pick_slow(gn, an1, bn1);
+        *reinterpret_cast<float4 *>(adst + 64 * ALD) = pick_slow(gn, an2, bn2);
+        *reinterpret_cast<float4 *>(adst + 96 * ALD) = pick_slow(gn, an3, bn3);
+      }
     }
-    __syncthreads();
+    if constexpr (!(RM_NN_ABL & 2)) __syncthreads();
   };
   static_assert(KC == 16, "two weight chunks per A group");
   int ch = 0;
-  for (; ch + 1 < a.nch; ch += 2) {
-    chunk(ch, std::true_type{});
-    chunk(ch + 1, std::false_type{});
+  for (; ch + 1 < a.nch && (ch >> 1) + 1 < gfast; ch += 2) {  // groups whose successor is a fast group
+    chunk(ch, std::true_type{}, std::true_type{});
+    chunk(ch + 1, std::false_type{}, std::true_type{});
   }
-  if (ch < a.nch) chunk(ch, std::true_type{});  // odd chunk count: the last group has one chunk
-
-  // ---- epilogue: one straight-line pass per column block - all aux loads of a block are
-  // issued before the first use and the epilogue kind is switched ONCE per wave.  (The first
-  // version tested a.epi per element: every element became load -> s_waitcnt vmcnt(0) ->
-  // store, which also drains the earlier stores - 22 % of the kernel.)
-  auto run = [&](auto epi_tag) {
+  for (; ch + 1 < a.nch; ch += 2) {
+    chunk(ch, std::true_type{}, std::false_type{});
+    chunk(ch + 1, std::false_type{}, std::false_type{});
+  }
+  if (ch < a.nch) chunk(ch, std::true_type{}, std::false_type{});  // odd chunk count: the last group has one chunk
+  RM_STAMP(2);
+#ifdef RM_NN_STAMP
+  if (tid == 0 && blockIdx.x < 8192) rm_nn_stamp_buf[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memtime() - clk0;  // shader clocks
+#endif
+  // ---- epilogue.  The f32 MFMA runs on the SIMD's vector ALU: beside a partner block in its chunk loop a
+  // VALU instruction of this wave gets one issue slot per partner MFMA (64 cycles), whatever its priority
+  // (s_setprio(3) changed nothing) - the first version's epilogue (per element: 64-bit address arithmetic,
+  // bounds predicate with exec-mask updates, bias add, activation) took 30-40 us beside a computing partner
+  // and 10-18 us beside one in its own epilogue (tools/probe/nn_stamps.py).  So: as few vector instructions
+  // per element as possible.  Every access is a raw buffer access on a tile-based descriptor: rows past M
+  // fall outside num_records (loads return 0, stores are dropped), lanes whose column is past N get an
+  // out-of-range offset, the row term of the address is a scalar offset (SALU) - no predicates, no 64-bit
+  // vector arithmetic; the bias is already in the accumulators.
+  // vmcnt retires loads and stores in ONE order: a load issued behind stores is not usable before those
+  // stores are acknowledged - aux values are requested two column blocks at a time, ahead of their stores.
+  const int lane_row = 4 * h;  // + 32 rg (in the descriptor base) + (r & 3) + 8 (r >> 2) (scalar offset)
+  auto tile_rsrc = [&](const float *p, int64_t ld, bool present = true) -> rsrc_t {
+    const int64_t rows_w = a.M - row0 < 32 ? a.M - row0 : 32;  // rows of this wave's row group that exist
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p + row0 * ld), 0,
+                                             (present && rows_w > 0) ? (int)((rows_w - 1) * ld + a.N) * 4 : 0, 0x00020000);
+  };
+  auto run = [&](auto epi_tag, auto act_tag) {
     constexpr int EPI = decltype(epi_tag)::value;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (nt >= ntw) continue;
+    constexpr int ACT = decltype(act_tag)::value;  // compile-time: a run-time id cost 4-6 instructions per element
+    constexpr bool kAux = EPI != RM_DENSE_BIAS_ACT;
+    constexpr int kAuxB = EPI == RM_DENSE_CROSS ? 1 : 2;  // column blocks per batch of aux loads
+    const rsrc_t rc = tile_rsrc(a.C, a.ldc);
+    // (an absent C2 gets an empty descriptor: its stores are dropped; ADD without aux1 never gets here -
+    // the host turns it into BIAS_ACT / identity)
+    const rsrc_t rc2 = tile_rsrc(EPI == RM_DENSE_CROSS && a.C2 != nullptr ? a.C2 : a.C, EPI == RM_DENSE_CROSS ? a.ldc2 : a.ldc,
+                                 a.C2 != nullptr);
+    const rsrc_t r1 = tile_rsrc(kAux ? a.aux1 : a.C, kAux ? a.ld1 : a.ldc);
+    const rsrc_t r2 = tile_rsrc(EPI == RM_DENSE_CROSS ? a.aux2 : a.C, EPI == RM_DENSE_CROSS ? a.ld2 : a.ldc);
+    constexpr int kOob = 0x7ffffff0;
+    // per-lane offsets (bytes) of column block nt in each array; out of range when the column is past N
+    auto lane_off = [&](int nt, int64_t ld) -> int {
       const int col = ct * kTileCols + 32 * (cg == 0 ? nt : tl.nt0 + nt) + c;
-      const bool colok = col < a.N;
-      const int colc = colok ? col : a.N - 1;
-      const float bn = a.bias != nullptr ? a.bias[colc] : 0.f;
-      float x1[16], x2[16];
+      return col < a.N ? (lane_row * (int)ld + col) * 4 : kOob;
+    };
+    auto row_off = [&](int r, int64_t ld) -> int { return ((r & 3) + 8 * (r >> 2)) * (int)ld * 4; };
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        rr = rr < a.M ? rr : a.M - 1;
-        if constexpr (EPI == RM_DENSE_MUL_ACTGRAD || EPI == RM_DENSE_CROSS) x1[r] = a.aux1[rr * a.ld1 + colc];
-        if constexpr (EPI == RM_DENSE_ADD) x1[r] = a.aux1 != nullptr ? a.aux1[rr * a.ld1 + colc] : 0.f;
-        if constexpr (EPI == RM_DENSE_CROSS) x2[r] = a.aux2[rr * a.ld2 + colc];
+    for (int n0 = 0; n0 < NT; n0 += kAuxB) {
+      float x1[kAux ? kAuxB : 1][16], x2[EPI == RM_DENSE_CROSS ? kAuxB : 1][16];
+      if constexpr (kAux) {
+#pragma unroll
+        for (int q = 0; q < kAuxB; ++q) {
+          const int nt = n0 + q;
+          if (nt >= NT || nt >= ntw) continue;
+          const int o1 = lane_off(nt, a.ld1), o2 = EPI == RM_DENSE_CROSS ? lane_off(nt, a.ld2) : 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            x1[q][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, o1, row_off(r, a.ld1), 0));
+            if constexpr (EPI == RM_DENSE_CROSS)
+              x2[q][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2, o2, row_off(r, a.ld2), 0));
+          }
+        }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float v = acc[nt][r] + bn;
-        const bool ok = colok && rr < a.M;
-        if constexpr (EPI == RM_DENSE_BIAS_ACT) v = act_apply(v, a.act);
-        if constexpr (EPI == RM_DENSE_MUL_ACTGRAD) v *= act_grad_from_out(x1[r], a.act);
-        if constexpr (EPI == RM_DENSE_ADD) v += x1[r];
-        if constexpr (EPI == RM_DENSE_CROSS) {
-          if (a.C2 != nullptr && ok) a.C2[rr * a.ldc2 + col] = v;  // u, kept for the backward
-          v = x1[r] * v + x2[r];
+      for (int q = 0; q < kAuxB; ++q) {
+        const int nt = n0 + q;
+        if (nt >= NT || nt >= ntw) continue;
+        const int oc = lane_off(nt, a.ldc), oc2 = EPI == RM_DENSE_CROSS ? lane_off(nt, a.ldc2) : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[nt][r];
+          if constexpr (EPI == RM_DENSE_BIAS_ACT) v = act_apply(v, ACT);
+          if constexpr (EPI == RM_DENSE_MUL_ACTGRAD) v *= act_grad_from_out(x1[q][r], ACT);
+          if constexpr (EPI == RM_DENSE_ADD) v += x1[q][r];
+          if constexpr (EPI == RM_DENSE_CROSS) {
+            // u, kept for the backward
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rc2, oc2, row_off(r, a.ldc2), 0);
+            v = x1[q][r] * v + x2[q][r];
+          }
+          if (!(RM_NN_ABL & 1) || v == 1234.5f)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rc, oc, row_off(r, a.ldc), 0);
         }
-        if (ok) a.C[rr * a.ldc + col] = v;
       }
     }
   };
-  if (a.epi == RM_DENSE_BIAS_ACT) run(std::integral_constant<int, RM_DENSE_BIAS_ACT>{});
-  else if (a.epi == RM_DENSE_MUL_ACTGRAD) run(std::integral_constant<int, RM_DENSE_MUL_ACTGRAD>{});
-  else if (a.epi == RM_DENSE_ADD) run(std::integral_constant<int, RM_DENSE_ADD>{});
-  else run(std::integral_constant<int, RM_DENSE_CROSS>{});
+  auto run_act = [&](auto epi_tag) {
+    if (a.act == RM_ACT_RELU) run(epi_tag, std::integral_constant<int, RM_ACT_RELU>{});
+    else if (a.act == RM_ACT_LEAKY_RELU) run(epi_tag, std::integral_constant<int, RM_ACT_LEAKY_RELU>{});
+    else run(epi_tag, std::integral_constant<int, RM_ACT_IDENTITY>{});
+  };
+  if (a.epi == RM_DENSE_BIAS_ACT) run_act(std::integral_constant<int, RM_DENSE_BIAS_ACT>{});
+  else if (a.epi == RM_DENSE_MUL_ACTGRAD) run_act(std::integral_constant<int, RM_DENSE_MUL_ACTGRAD>{});
+  else if (a.epi == RM_DENSE_ADD) run(std::integral_constant<int, RM_DENSE_ADD>{}, std::integral_constant<int, RM_ACT_IDENTITY>{});
+  else run(std::integral_constant<int, RM_DENSE_CROSS>{}, std::integral_constant<int, RM_ACT_IDENTITY>{});
+#ifdef RM_NN_STAMP
+  __builtin_amdgcn_s_waitcnt(0);  // (the stores have left the wave)
+#endif
+  RM_STAMP(3);
 }
 
-// P0 / P1: accumulators of the waves of column group 0 / 1 (the two waves that share a SIMD):
-// (7,6) for a 13-block N = 400, (7,7) for 14 blocks, (n,n) otherwise.  Both bodies execute the
-// same number of barriers.
+// One block = 4 waves (one per SIMD) = 128 batch rows x ONE column group of <= 7 32-column blocks; TWO
+// blocks per CU.  P0 / P1: accumulators of column group 0 / 1 of a column tile: (7,6) for a 13-block
+// N = 400, (7,7) for 14 blocks, (n,n) otherwise.  The two groups of a row tile used to be the two waves
+// of each SIMD inside ONE 8-wave block: every barrier, staging phase and epilogue then stopped the MFMA
+// pipes of the whole CU at once (MfmaUtil 0.63, profiles/r02_dense_gemm.md).  As independent blocks they
+// drift out of phase and one's MFMAs cover the other's barrier / staging / epilogue; the weights are
+// still staged once per 128 rows (each block stages only its own group's half), only the A tile is
+// read by both (the second read hits L2: blocks w and w + span run on the same XCD).
 template <int P0, int P1>
-__global__ __launch_bounds__(kNNThreads, 1) void dense_nn_kernel(NNArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float Ws[];  // [2][WCH]
+__global__ __launch_bounds__(kNNThreads, 2) void dense_nn_kernel(NNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float Ws[];  // [2][WCHG] + [2][128][36]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPR
-  const int c = lane & 31, h = lane >> 5, rg = wave & 3, cg = wave >> 2;
-  const int ct = blockIdx.y;
+  const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPR
+  const int c = lane & 31, h = lane >> 5;
+  const int per_round = a.span * a.groups;
+  // (integer division runs on the VALU: without readfirstlane hipcc treats the quotients as divergent and
+  // wraps every buffer load that uses a tile-derived descriptor in a waterfall loop)
+  const int w = blockIdx.x, round = __builtin_amdgcn_readfirstlane(w / per_round), in_round = w - round * per_round;
+  const int gi = __builtin_amdgcn_readfirstlane(in_round / a.span);
+  const int64_t tile = (int64_t)round * a.span + (in_round - gi * a.span);
+  if (tile * kNNRows >= a.M) return;
+  const int ct = gi >> 1, cg = gi & 1;
+  // Phase stagger.  The two blocks of a CU start together and do the same work at the same speed: left
+  // alone they stay in lockstep (tools/probe/nn_stamps.py: both in the chunk loop for 87 us, then both in
+  // the epilogue for 10-20 us - and so is every other CU: the whole chip computes with HBM idle, then
+  // stores 54 MB at once with the MFMA pipes idle).  The odd-group blocks of the FIRST round start half a
+  // block later (their partner has the SIMDs to itself meanwhile); every later round inherits the offset
+  // because a CU slot is refilled the moment its block ends.
+  if (a.stagger_ticks > 0 && round == 0 && cg == 1) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)a.stagger_ticks) __builtin_amdgcn_s_sleep(16);
+  }
   const ColTile tl = col_tile(a.N, ct);
-  if (cg == 0) nn_wave<P0>(a, Ws, tid, c, h, rg, 0, ct, tl, tl.nt0);
-  else nn_wave<P1>(a, Ws, tid, c, h, rg, 1, ct, tl, tl.nb - tl.nt0);
+  if (cg == 0) nn_wave<P0>(a, Ws, tid, c, h, rg, 0, ct, tl, tl.nt0, tile);
+  else if (tl.nb > tl.nt0) nn_wave<P1>(a, Ws, tid, c, h, rg, 1, ct, tl, tl.nb - tl.nt0, tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -769,6 +928,12 @@ TnPlan tn_plan(int K, int N, int64_t M, bool allow_split) {
 
 }  // namespace
 
+#ifdef RM_NN_STAMP
+extern "C" int rm_debug_nn_stamps(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rm_nn_stamp_buf), sizeof(unsigned long long) * n);
+}
+#endif
+
 extern "C" int64_t rm_dense_filter_workspace(int K, int N) {
   if (K <= 0 || N <= 0) return 0;
   const int nch = (K + KC - 1) / KC;
@@ -787,6 +952,9 @@ extern "C" int rm_dense_fwd(const float *A1, int64_t lda1, int K1, const float *
   RM_REQUIRE(K2 == 0 || A2, "rm_dense_fwd: K2 > 0 needs A2");
   RM_REQUIRE(lda1 >= K1, "rm_dense_fwd: lda1 < K1");
   RM_REQUIRE(K2 == 0 || lda2 >= K2, "rm_dense_fwd: lda2 < K2");
+  RM_REQUIRE(lda1 < (1 << 22) && lda2 < (1 << 22) && ldc < (1 << 22) && ldc2 < (1 << 22) && ld_aux1 < (1 << 22) &&
+                 ld_aux2 < (1 << 22),
+             "rm_dense_fwd: row stride too long for the 32-bit tile offsets");
   RM_REQUIRE(rm_aligned16(filter_ws), "rm_dense_fwd: filter_ws must be 16-byte aligned");
   RM_REQUIRE(epilogue >= RM_DENSE_BIAS_ACT && epilogue <= RM_DENSE_CROSS, "rm_dense_fwd: bad epilogue id");
   RM_REQUIRE(act >= RM_ACT_IDENTITY && act <= RM_ACT_LEAKY_RELU, "rm_dense_fwd: bad activation id");
@@ -803,10 +971,24 @@ extern "C" int rm_dense_fwd(const float *A1, int64_t lda1, int K1, const float *
   hipLaunchKernelGGL(dense_prep_kernel, dim3(rm_grid_cap(((int64_t)nct * nch * WCH + 255) / 256, 1024)),
                      dim3(256), 0, st, W, ldw, w_transposed, K, N, nch, nct, filter_ws);
   RM_CHECK_LAUNCH("rm_dense_fwd(prep)");
+  // blockIdx.x -> (row tile, column group): rounds of `span` row tiles, inside a round all tiles of group 0,
+  // then all of group 1, ...: the groups of one row tile are `span` blocks apart - with span % 8 == 0 on the
+  // same XCD (round-robin placement) and, the dispatcher filling CU slots in order, about the same time
+  const int64_t ntiles = (M + kNNRows - 1) / kNNRows;
+  const int span = (int)(ntiles < 256 ? ntiles : 256);
+  const int groups = 2 * nct;
+  RM_REQUIRE((ntiles + span - 1) / span * span * groups < ((int64_t)1 << 31), "rm_dense_fwd: grid too large");
   NNArgs a{A1, A2, lda1, lda2, K1, K2, (rm_aligned16(A1) && lda1 % 4 == 0) ? 1 : 0, filter_ws, N, nch, bias, epilogue, act, aux1, aux2,
-           ld_aux1, ld_aux2, M, C, C2, ldc, ldc2};
-  const dim3 grid((unsigned)((M + kNNRows - 1) / kNNRows), (unsigned)nct);
-  const size_t smem = (2 * WCH + 2 * kNNRows * 36) * sizeof(float);  // 100 KB: one block per CU
+           ld_aux1, ld_aux2, M, C, C2, ldc, ldc2, span, groups, 0};
+  if (epilogue == RM_DENSE_ADD && !aux1) { a.epi = RM_DENSE_BIAS_ACT; a.act = RM_ACT_IDENTITY; }
+  if (ntiles * groups > 512) {  // more blocks than CU slots: rounds exist, stagger them
+    static const int pct = [] { const char *e = getenv("RECMAN_NN_STAGGER_PCT"); return e ? atoi(e) : 25; }();
+    const int nb_first = nbt < kMaxNB ? nbt : kMaxNB;
+    // one block-time ~ nch chunks x 8 k-steps x nb MFMAs x 64 cycles at ~2.3 GHz, in 10 ns ticks
+    a.stagger_ticks = (int)((int64_t)pct * nch * 8 * nb_first * 64 / 23 / 100);
+  }
+  const dim3 grid((unsigned)((ntiles + span - 1) / span * span * groups));
+  const size_t smem = (2 * WCHG + 2 * kNNRows * 36) * sizeof(float);  // 68 KB: two blocks per CU
   const int nb0 = nbt < kMaxNB ? nbt : kMaxNB;  // blocks of the widest (first) column tile
 #define RM_NN(P0, P1)                                                                         \
   {                                                                                         \

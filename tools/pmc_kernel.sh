@@ -13,6 +13,7 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WA
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 "$@" > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 "$@" > /dev/null 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/tcc -- python3 "$@" > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --kernel-trace --output-format csv -d $out/mfma -- python3 "$@" > /dev/null 2>&1 || true
 python3 tools/prof_summary.py $out/stats 12 > $out/summary.md
-for d in sq sq2 fetch write tcc; do echo "## $d" >> $out/summary.md; python3 tools/pmc_summary.py $out/$d >> $out/summary.md 2>&1 || true; done
+for d in sq sq2 fetch write tcc mfma; do echo "## $d" >> $out/summary.md; python3 tools/pmc_summary.py $out/$d >> $out/summary.md 2>&1 || true; done
 cat $out/summary.md
