@@ -17,6 +17,7 @@
 // TN kernel: no LDS at all - both operands are row-contiguous along the MFMA's M / N index, so
 // every wave loads them coalesced (128 B per half-wave) in operand layout; the batch is split
 // into slabs, partial tiles go to a workspace and a second kernel reduces them (deterministic).
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -736,7 +737,12 @@ __global__ __launch_bounds__(kThreads, 1) void dense_tn_kernel(TNArgs a) {
     }
     return;
   }
-  if (total % 8 == 0) L = (L % 8) * (total / 8) + L / 8;
+  {  // blocks L, L + 8, L + 16, ... share an XCD: give XCD x a contiguous range of (slab, K tile) pairs
+    const int x = (int)(L & 7);
+    int64_t first = 0;
+    for (int y = 0; y < x; ++y) first += (total - y + 7) >> 3;
+    L = first + (L >> 3);
+  }
   const int slab = (int)(L / ktsf), kt = (int)(L % ktsf);
   const bool fa = kt < a.kts_fast;  // block-uniform: this K tile lies inside A1 with 16-byte rows
   if (cg == 0) {
@@ -904,20 +910,36 @@ TnPlan tn_plan(int K, int N, int64_t M, bool allow_split) {
 #ifndef RM_TN_SPLIT
 #define RM_TN_SPLIT 1
 #endif
+#ifndef RM_TN_RATIO2
+#define RM_TN_RATIO2 0.667
+#define RM_TN_RATIO1 0.41
+#endif
   // (only with float4 staging of G: with the per-element G loader the blocks are staging-bound and the
   // ragged tile's longer slabs became the critical path - dcn_matrix's N = 429 went 17.3 -> 18.6 ms)
   if (RM_TN_SPLIT && allow_split && p.kts >= 2 && live <= 2) {
-    // the ragged tile's blocks run about twice as fast per batch row (a quarter / half of the MFMA
-    // work per chunk, the same staging): half as many, twice as long slabs for it
-    int64_t sf = (int64_t)(256 / p.nct) * 2 / (2 * p.kts - 1);  // (kts - 1) sf + sf / 2 <= 256 / nct
+    // A ragged-tile block does a half (live = 2) / a quarter (live = 1) of the MFMA work per chunk, but its
+    // staging costs more than a full tile's (per-element loader): measured per chunk 10.3k cycles (live 2) /
+    // 7.0k (live 1) against 15.5k for a full tile (profiles/r02_dense_gemm.md).  Its slabs are longer by that
+    // ratio so that both kinds of block end together: slabs_r = ratio * slabs, with (kts - 1) slabs +
+    // slabs_r <= one round of blocks.  (Round 1 used slabs / 2 for both cases: at K = 429 the ragged blocks
+    // then ran 1.33x longer than the rest - 510 us against 385 us at K = 400.)
+    const double ratio = live == 2 ? RM_TN_RATIO2 : RM_TN_RATIO1;
+    const int64_t round_blocks = 256 / p.nct;
+    int64_t sf = (int64_t)(round_blocks / (p.kts - 1 + ratio));
     const int64_t cap = (M + 511) / 512;
     sf = sf < cap ? sf : cap;
-    sf = sf / 2 * 2;
-    if (sf >= 4) {
+    int64_t sr = round_blocks - (p.kts - 1) * sf;              // what is left of the round
+    const int64_t sr_want = (int64_t)(ratio * sf + 0.999);
+    sr = sr < sr_want ? sr : sr_want;
+    if (const char *e = getenv("RECMAN_TN_SLABS")) {  // experiments: "slabs,slabs_r"
+      int x = 0, y = 0;
+      if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 4 && y >= 1 && (p.kts - 1) * x + y <= round_blocks) { sf = x; sr = y; }
+    }
+    if (sf >= 4 && sr >= 1) {
       p.slabs = (int)sf;
       p.split_f = 4 / live;
       p.live = live;
-      p.slabs_r = (int)(sf / 2);
+      p.slabs_r = (int)sr;
     }
   }
   p.rows_f = ((M + p.slabs - 1) / p.slabs + TRC - 1) / TRC * TRC;
