@@ -204,6 +204,25 @@ int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int NL, const i
                const float *const *W, const float *const *bias, const float *w_out,
                const float *w0_out, int act, int64_t B, float *const *h_out, float *logit,
                const rm_mlp_tail *tail, rm_stream_t stream);
+/* Gather + FM + linear term + skinny MLP (+ training head) in ONE kernel: rm_embed_fwd followed by rm_mlp_fwd
+ * on E without the round trip of x through HBM (FeatEmbeddingLayer + FMLayer + LinearLayer + DNNCombiner + DNN of
+ * DeepFM._init_graph, recman/tf/core/DeepFM.py:96-150 over layers.py:238-261,457-478,330-347,494-501,576-609).
+ * Fused-row layout only: table rows [16 embedding | bias | linear weight | ...] with table_ld = 32, D = 16;
+ * Dn <= 16, 16 F + Dn <= 448, hidden widths <= 32 (rm_embed_mlp_fwd_supported).  want_bias / want_lin: the FM
+ * bias sum / the sparse part of the linear term are wanted; lin_w_dense [Dn] (NULL: the linear term has no
+ * dense part), lin_w0 [1] or NULL; xd [B,Dn] feeds the MLP (and the linear term).  Outputs as the two calls':
+ * E [B,F,16] (always written: the backward reads it), fm_sum [B,16], fm_logit [B], lin_logit [B] (NULL = not
+ * wanted), h_out / logit / tail as rm_mlp_fwd - tail->logit_a / logit_b must be this call's lin_logit /
+ * fm_logit buffers (or NULL).  flags: RM_EMBED_STREAM_ROWS.  No dropout masks (the callers fall back to the
+ * two separate entry points). */
+int rm_embed_mlp_fwd_supported(int F, int D, int64_t table_ld, int Dn, int NL, const int *H);
+int rm_embed_mlp_fwd(const int64_t *idx, const float *table, int64_t table_ld, const int64_t *field_off,
+                     int want_bias, int want_lin, const float *lin_w_dense, const float *lin_w0,
+                     const float *xd, int Dn, int64_t B, int F, int D, float *E, float *fm_sum,
+                     float *fm_logit, float *lin_logit, int flags, int NL, const int *H,
+                     const float *const *W, const float *const *bias, const float *w_out,
+                     const float *w0_out, int act, float *const *h_out, float *logit,
+                     const rm_mlp_tail *tail, rm_stream_t stream);
 int64_t rm_mlp_bwd_workspace(int FD, int Dn);
 int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const int *H,
                const float *const *W, const float *w_out, int act, int64_t B, const float *g,

@@ -43,6 +43,9 @@ SIGNATURES = {
                       P, P, P],
     "rm_mlp_supported": [c_int, c_int, c_int, P],
     "rm_mlp_fwd": [P, P, c_int, c_int, c_int, P, P, P, P, P, c_int, I64, P, P, P, P],
+    "rm_embed_mlp_fwd_supported": [c_int, c_int, I64, c_int, c_int, P],
+    "rm_embed_mlp_fwd": [P, P, I64, P, c_int, c_int, P, P, P, c_int, I64, c_int, c_int, P, P, P, P, c_int,
+                         c_int, P, P, P, P, P, c_int, P, P, P, P],
     "rm_mlp_bwd": [P, P, c_int, c_int, c_int, P, P, P, c_int, I64, P, P, P, c_int, P, P, P, P, P, P,
                    P, P, P, P, c_int, P],
     "rm_bias_act": [P, P, I64, c_int, c_int, P],

@@ -35,6 +35,8 @@ __device__ __forceinline__ float actg(float o, int act) {
 #define RM_MLP_NT 2  // bit 1: non-temporal x loads in mlp_bwd (last use of E in the MLP).  (Bit 0, non-temporal d_rows stores, is now the CALLER's flag RM_MLP_STREAM_DROWS: -1.3 % on a bare fwd+bwd step together with bit 1, but the optimizer step that follows in training gathers d_rows again and paid +0.05 ms for it: profiles/r01_p11)
 #endif
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store4_stream(float *p, const float4 &v) {
   f4v t;
   t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
@@ -337,6 +339,382 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
     if constexpr (TAIL) {
       // ---- final logit, PredictionLayer, loss term, dLoss/dlogit (rm_logit_loss's arithmetic, same
       // order of the branch sum), then the dh chain; both lane halves compute the example's scalars
+      float z = 0.f;
+      if (tl.logit_a) z += tl.coef_a * ta;
+      if (tl.logit_b) z += tl.coef_b * tb;
+      z += tl.coef_mlp * dnn;
+      const float t = ty;
+      float p, dz;
+      const float lt = rm_loss_point(z, t, tl.task, &p, &dz);
+      float gb = dz * (1.0f / (float)B);
+      gb *= tl.grad_scale;
+      if (valid && h == 0) {
+        if (tl.logit) tl.logit[b] = z;
+        if (tl.pred) tl.pred[b] = p;
+        tl.dlogit[b] = gb;
+      }
+      const float ls = rm_wave_sum((valid && h == 0) ? lt : 0.f);
+      if (lane == 0) tl.loss_partial[tile] = ls;
+      float dh[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dh[r] = gb * bs[NL * 32 + unit_of(r, h)] * actg(hl[NL - 1][r], act);
+#pragma unroll
+      for (int l = NL - 1; l >= 1; --l) {
+        if (valid) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4 *>(tl.dh[l] + b * 32 + 8 * gq + 4 * h) =
+                make_float4(dh[4 * gq], dh[4 * gq + 1], dh[4 * gq + 2], dh[4 * gq + 3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WBt[(l - 1) * 1024 + (s * 2 + h) * 32 + c], dh[s],
+                                                     acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = acc[r] * actg(hl[l - 1][r], act);
+      }
+      if (valid) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<float4 *>(tl.dh[0] + b * 32 + 8 * gq + 4 * h) =
+              make_float4(dh[4 * gq], dh[4 * gq + 1], dh[4 * gq + 2], dh[4 * gq + 3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// forward of the whole DeepFM-style front: gather + FM + linear + skinny MLP (+ training head) in ONE kernel
+// (rm_embed_mlp_fwd).  rm_embed_fwd writes E [B, F*D] and rm_mlp_fwd reads it back 40 us later through a
+// 7-deep chain of dependent loads per wave (37 us for 109 MB); here a wave gathers the rows of its 32-example
+// tile four fields (= one 64-k chunk of x) at a time, stores them to E (the backward needs it), adds them
+// into the FM sums and drops them into its private LDS chunk - the layer-0 MFMAs of that chunk run while
+// the other waves' row loads are in flight.  Fixed layout: D = 16, table rows of 32 floats
+// [16 emb | bias | lin | ...] (8 lanes per row: 4 embedding slices + 1 side lane), Dn <= 16.
+// Lane roles: gather phase (ex_l = lane >> 3, sub = lane & 7) owns examples 8 eg + ex_l, eg = 0..3;
+// MFMA phase (c = lane & 31, h = lane >> 5) as in mlp_fwd_kernel.  Prologue and tile epilogue are
+// mlp_fwd_kernel's (kept textually parallel: a change there belongs here too).
+// ---------------------------------------------------------------------------
+#ifndef RM_EMF_ABL
+#define RM_EMF_ABL 0  // ablation builds (wrong results): 1 no layer-0 MFMAs, 2 no E stores, 4 no x writes to LDS
+#endif
+struct EmbFront {
+  const int64_t *idx;        // [B, F]
+  const float *table;        // fused rows, stride 32 floats
+  const int64_t *field_off;  // [F]
+  const float *lin_w_dense, *lin_w0, *dense;  // linear term's dense part (NULL: none); dense = xd
+  int F, want_bias, want_lin;
+  float *E, *fm_sum, *fm_logit, *lin_logit;   // fm_sum / fm_logit / lin_logit may be NULL
+};
+
+template <int NL, bool TAIL, bool NT>
+__global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void embed_mlp_fwd_kernel(
+    EmbFront ef, const float *__restrict__ xd, int Dn, MlpW w, const float *__restrict__ w_out,
+    const float *__restrict__ w0_out, int act, int64_t B, float *__restrict__ h0, float *__restrict__ h1,
+    float *__restrict__ h2, float *__restrict__ logit, rm_mlp_tail tl) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int F = ef.F, FD = 16 * F;
+  const int K = FD + Dn;
+  const int Kp = ((K + 63) / 64) * 64;
+  const int LDW = Kp + 4;
+  float *W0t = smem;                         // [32][LDW]: W0t[u][k] = W0[k][u]
+  float *WA = W0t + 32 * LDW;                // [NL-1][16][2][32]: W_l[u(s,h)][c]
+  float *bs = WA + (NL - 1) * 1024;          // [NL][32] biases, then [32] w_out
+  float *WBt = bs + (NL + 1) * 32;           // TAIL: [NL-1][16][2][32]: W_l[c][u(s,h)] (the chain's operand)
+  float *xs_all = WBt + (TAIL ? (NL - 1) * 1024 : 0);  // [waves][32][kLDX]
+  constexpr int NW = RM_MLP_FWD_WAVES, NTHR = 64 * NW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+  const int ex_l = lane >> 3, sub = lane & 7;
+  const bool emb = sub < 4, side = sub == 4 && (ef.want_bias || ef.want_lin);
+  static_assert(NTHR == 512, "the staging below is written for 8 waves");
+
+  const int64_t ntiles = (B + 31) / 32;
+  const int64_t tile0 = (int64_t)blockIdx.x * NW + wave;
+  // ---- prologue: parameter loads (L2 hits), then this wave's first ids, then the parameters' LDS stores
+  float w0v[kW0Regs];
+  stage_w0_load<NTHR>(w0v, w.W[0], K, Kp, w.H[0], tid);
+  float wav[(NL > 1 ? NL - 1 : 1) * 2];
+#pragma unroll
+  for (int l = 1; l < NL; ++l)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = tid + i * NTHR;
+      const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
+      const int ku = unit_of(s, hh);
+      const bool ok = ku < w.H[l - 1] && cc < w.H[l];
+      const float x = w.W[l][ok ? ku * w.H[l] + cc : 0];
+      wav[(l - 1) * 2 + i] = ok ? x : 0.f;
+    }
+  float wbv[(NL > 1 ? NL - 1 : 1) * 2];
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int l = 1; l < NL; ++l)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int t = tid + i * NTHR;
+        const int cc = t & 31, hh = (t >> 5) & 1, s = t >> 6;
+        const int ku = unit_of(s, hh);
+        const bool ok = cc < w.H[l - 1] && ku < w.H[l];
+        const float x = w.W[l][ok ? cc * w.H[l] + ku : 0];
+        wbv[(l - 1) * 2 + i] = ok ? x : 0.f;
+      }
+  }
+  float bsv = 0.f;
+  {
+    const int u = tid & 31, lsel = tid >> 5;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const bool ok = lsel == l && u < w.H[l];
+      const float x = w.b[l][ok ? u : 0];
+      bsv = ok ? x : bsv;
+    }
+    const bool oko = lsel == NL && u < w.H[NL - 1];
+    const float xo = w_out[oko ? u : 0];
+    bsv = oko ? xo : bsv;
+  }
+  // The chunk loop works on HALF chunks of 32 k = 2 fields (8 row loads per lane: 4 example groups x 2
+  // fields) with two register buffers: the rows of half chunk i + 1 are requested before half chunk i is
+  // consumed.  (A store holds its data registers until it is acknowledged, and vmcnt retires loads and
+  // stores in one order: re-loading into the registers the E stores have just read - a one-buffer pipeline
+  // - made every load wait for those stores: 96 -> 111 us.  With two buffers the stores of half chunk i
+  // have a whole iteration to drain before their registers are loaded again.)
+  // row numbers (field offset + id) of one half chunk; fields past F repeat F - 1
+  auto load_rows = [&](int64_t ex0, int hc, int64_t (&r)[8]) {
+#pragma unroll
+    for (int eg = 0; eg < 4; ++eg) {
+      int64_t b = ex0 + 8 * eg + ex_l;
+      b = b < B ? b : B - 1;
+#pragma unroll
+      for (int fl = 0; fl < 2; ++fl) {
+        int f = 2 * hc + fl;
+        f = f < F ? f : F - 1;
+        r[eg * 2 + fl] = ef.idx[b * F + f] + ef.field_off[f];
+      }
+    }
+  };
+  const int nhc = Kp / 32;
+  int64_t rows[8];
+  load_rows((tile0 < ntiles ? tile0 : 0) * 32, 0, rows);
+  __builtin_amdgcn_sched_barrier(0);
+  stage_w0_store<true, NTHR>(W0t, LDW, w0v, Kp, tid);
+#pragma unroll
+  for (int l = 1; l < NL; ++l)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      WA[(l - 1) * 1024 + tid + i * NTHR] = wav[(l - 1) * 2 + i];
+      if constexpr (TAIL) WBt[(l - 1) * 1024 + tid + i * NTHR] = wbv[(l - 1) * 2 + i];
+    }
+  if (tid < (NL + 1) * 32) bs[tid] = bsv;
+  __syncthreads();
+
+  constexpr int kLDH = 36;  // row stride of the half-chunk x tile (32 + 4: conflict-free b128 reads)
+  float *xs = xs_all + wave * 32 * kLDX;
+  for (int64_t tile = tile0; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
+    const int64_t ex0 = tile * 32;
+    if (tile != tile0) load_rows(ex0, 0, rows);
+    // dense inputs of this lane's examples: columns FD + sub + 8 i (i = 0, 1) of example 8 eg + ex_l
+    float dv[4][2];
+#pragma unroll
+    for (int eg = 0; eg < 4; ++eg) {
+      int64_t b = ex0 + 8 * eg + ex_l;
+      b = b < B ? b : B - 1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int j = sub + 8 * i;
+        const float x = Dn > 0 ? xd[b * Dn + (j < Dn ? j : 0)] : 0.f;
+        dv[eg][i] = j < Dn ? x : 0.f;
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 S[4];
+    float ss[4], y1[4], lin[4];
+#pragma unroll
+    for (int eg = 0; eg < 4; ++eg) {
+      S[eg] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ss[eg] = 0.f; y1[eg] = 0.f; lin[eg] = 0.f;
+    }
+    const int64_t rows_t = B - ex0 < 32 ? B - ex0 : 32;
+    const rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(ef.E + ex0 * F * 16, 0, (int)(rows_t * F * 64), 0x00020000);
+    auto load_v = [&](float4 (&v)[8]) {
+      if (emb || side) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float *p = ef.table + rows[q] * 32 + sub * 4;
+          v[q] = NT ? load4_stream(p) : *reinterpret_cast<const float4 *>(p);
+        }
+      }
+    };
+    // one half chunk: request the next one's rows into `vn`, then consume `vc`
+    auto half = [&](int hc, float4 (&vc)[8], float4 (&vn)[8]) {
+      if (hc + 1 < nhc) {  // wave-uniform
+        load_v(vn);
+        load_rows(ex0, hc + 2 < nhc ? hc + 2 : hc + 1, rows);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // FM / linear sums, E stores, x values to LDS - without per-element lane predicates (`if (f < F) /
+      // if (emb) / if (valid)` per value compiled to three exec-mask branches per row): every lane adds every
+      // value (only the embedding lanes' S / ss and the side lane's y1 / lin are ever read), E is stored
+      // through a tile descriptor with out-of-range offsets for the lanes that must not store (examples past
+      // B fall outside num_records), the LDS writes sit in ONE `if (emb)` region
+      const int nf = F - 2 * hc;  // fields of this half chunk that exist (wave-uniform)
+#pragma unroll
+      for (int eg = 0; eg < 4; ++eg)
+#pragma unroll
+        for (int fl = 0; fl < 2; ++fl)
+          if (fl < nf) {
+            const float4 t = vc[eg * 2 + fl];
+            S[eg].x += t.x; S[eg].y += t.y; S[eg].z += t.z; S[eg].w += t.w;
+            ss[eg] += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+            y1[eg] += t.x;
+            lin[eg] += t.y;
+          }
+#ifndef RM_EMF_ESTORE
+#define RM_EMF_ESTORE 0  // 0: one 64-byte store per (example, field); 1: two fields per store = whole 128-byte lines
+#endif
+#ifndef RM_EMF_EAUX
+#define RM_EMF_EAUX 0    // aux bits of the E stores (2 = nt)
+#endif
+#pragma unroll
+      for (int eg = 0; eg < 4; ++eg) {
+        if (RM_EMF_ESTORE == 1 && nf >= 2) {
+          // lanes 4..7 of an example's group take field 2 hc + 1's four slices from lanes 0..3 (DPP row_shr:4
+          // into banks 1 and 3): the group's 8 lanes x 16 bytes are the 128 contiguous bytes of both fields
+          const float4 t0 = vc[eg * 2], t1 = vc[eg * 2 + 1];
+          u32x4v tv;
+          tv.x = __builtin_amdgcn_update_dpp(__builtin_bit_cast(unsigned, t0.x), __builtin_bit_cast(unsigned, t1.x), 0x114, 0xf, 0xa, false);
+          tv.y = __builtin_amdgcn_update_dpp(__builtin_bit_cast(unsigned, t0.y), __builtin_bit_cast(unsigned, t1.y), 0x114, 0xf, 0xa, false);
+          tv.z = __builtin_amdgcn_update_dpp(__builtin_bit_cast(unsigned, t0.z), __builtin_bit_cast(unsigned, t1.z), 0x114, 0xf, 0xa, false);
+          tv.w = __builtin_amdgcn_update_dpp(__builtin_bit_cast(unsigned, t0.w), __builtin_bit_cast(unsigned, t1.w), 0x114, 0xf, 0xa, false);
+          const int o = ((8 * eg + ex_l) * F + 2 * hc) * 64 + sub * 16;
+          if (!(RM_EMF_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(tv, re, o, 0, RM_EMF_EAUX);
+        } else {
+          const int o = emb ? ((8 * eg + ex_l) * F + 2 * hc) * 64 + sub * 16 : 0x7ffffff0;
+#pragma unroll
+          for (int fl = 0; fl < 2; ++fl)
+            if (fl < nf) {
+              const float4 t = vc[eg * 2 + fl];
+              f4v tv;
+              tv.x = t.x; tv.y = t.y; tv.z = t.z; tv.w = t.w;
+              if (!(RM_EMF_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, tv), re, o + 64 * fl, 0, RM_EMF_EAUX);
+            }
+        }
+      }
+      if (emb && !(RM_EMF_ABL & 4)) {
+#pragma unroll
+        for (int eg = 0; eg < 4; ++eg)
+#pragma unroll
+          for (int fl = 0; fl < 2; ++fl)
+            *reinterpret_cast<float4 *>(xs + (8 * eg + ex_l) * kLDH + fl * 16 + sub * 4) =
+                fl < nf ? vc[eg * 2 + fl] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (32 * hc + 32 > FD) {  // wave-uniform: this half chunk holds dense columns / zero padding
+#pragma unroll
+        for (int eg = 0; eg < 4; ++eg)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = 32 * hc + sub + 8 * q;  // this lane's columns of the half chunk
+            const int j = col - FD;                 // dense index; FD % 8 == 0, so j & 7 == sub: dv[eg][j >> 3]
+            const float x = (j >= 0 && j < 8) ? dv[eg][0] : ((j >= 8 && j < 16) ? dv[eg][1] : 0.f);
+            if (col >= FD) xs[(8 * eg + ex_l) * kLDH + sub + 8 * q] = x;
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < ((RM_EMF_ABL & 1) ? 0 : 4); ++u) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(W0t + c * LDW + hc * 32 + 8 * u + 4 * h);
+        const float4 b4 = *reinterpret_cast<const float4 *>(xs + c * kLDH + 8 * u + 4 * h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      }
+    };
+    float4 vA[8], vB[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vA[q] = vB[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    load_v(vA);
+    load_rows(ex0, nhc > 1 ? 1 : 0, rows);
+    for (int hc = 0; hc < nhc; hc += 2) {  // nhc is even (Kp % 64 == 0)
+      half(hc, vA, vB);
+      half(hc + 1, vB, vA);
+    }
+    // ---- FM second order + bias sum, linear term (rm_embed_fwd's arithmetic and order)
+#pragma unroll
+    for (int eg = 0; eg < 4; ++eg) {
+      const int64_t b = ex0 + 8 * eg + ex_l;
+      const bool valid = b < B;
+      if (ef.fm_sum != nullptr && valid && emb) *reinterpret_cast<float4 *>(ef.fm_sum + b * 16 + sub * 4) = S[eg];
+      float part = emb ? S[eg].x * S[eg].x + S[eg].y * S[eg].y + S[eg].z * S[eg].z + S[eg].w * S[eg].w - ss[eg] : 0.f;
+      part = rm_group_sum<8>(part);
+      const float ys = rm_group_sum<8>(side ? y1[eg] : 0.f);
+      float ls = rm_group_sum<8>(side ? lin[eg] : 0.f);
+      const float fmv = (ef.want_bias ? ys : 0.f) + 0.5f * part;
+      float lv = ef.want_lin ? ls : 0.f;
+      if (ef.lin_w_dense != nullptr) {
+        // (serial over j like rm_embed_fwd, so that the sums are bit-identical: lane sub == 0 does it)
+        if (sub == 0) {
+          const int64_t bq = valid ? b : B - 1;
+          for (int j = 0; j < Dn; ++j) lv += ef.dense[bq * Dn + j] * ef.lin_w_dense[j];
+        }
+      }
+      if (ef.lin_w0 != nullptr) lv += ef.lin_w0[0];
+      if (valid && sub == 0) {
+        if (ef.fm_logit != nullptr) ef.fm_logit[b] = fmv;
+        if (ef.lin_logit != nullptr) ef.lin_logit[b] = lv;
+      }
+      if (sub == 0) {  // for the head: example 8 eg + ex_l -> xs[2 e], xs[2 e + 1] (the chunk loop is done with xs)
+        xs[2 * (8 * eg + ex_l)] = lv;
+        xs[2 * (8 * eg + ex_l) + 1] = fmv;
+      }
+    }
+    const int64_t b = ex0 + c;
+    const bool valid = b < B;
+    float ta = 0.f, tb = 0.f, ty = 0.f;
+    if constexpr (TAIL) {
+      const int64_t bq = valid ? b : B - 1;
+      // logit_a / logit_b name the buffers this kernel has just written (lin_logit / fm_logit, in either
+      // order) or are NULL: take the values from LDS instead of reading them back
+      ta = tl.logit_a == nullptr ? 0.f : (tl.logit_a == ef.lin_logit ? xs[2 * c] : xs[2 * c + 1]);
+      tb = tl.logit_b == nullptr ? 0.f : (tl.logit_b == ef.lin_logit ? xs[2 * c] : xs[2 * c + 1]);
+      ty = tl.y ? (float)tl.y[bq] : tl.y_f[bq];
+    }
+    float hv[16];
+    float hl[TAIL ? NL : 1][16];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (l > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WA[(l - 1) * 1024 + (s * 2 + h) * 32 + c],
+                                                     hv[s], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hv[r] = actf(acc[r] + bs[l * 32 + unit_of(r, h)], act);
+      if constexpr (TAIL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hl[l][r] = hv[r];
+      }
+      float *hp = l == 0 ? h0 : (l == 1 ? h1 : h2);
+      if (valid && hp != nullptr) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<float4 *>(hp + b * 32 + 8 * gq + 4 * h) =
+              make_float4(hv[4 * gq], hv[4 * gq + 1], hv[4 * gq + 2], hv[4 * gq + 3]);
+      }
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part += hv[r] * bs[NL * 32 + unit_of(r, h)];
+    part += __shfl_xor(part, 32, 64);
+    const float dnn = part + (w0_out ? w0_out[0] : 0.f);
+    if (valid && h == 0) logit[b] = dnn;
+    if constexpr (TAIL) {
       float z = 0.f;
       if (tl.logit_a) z += tl.coef_a * ta;
       if (tl.logit_b) z += tl.coef_b * tb;
@@ -986,6 +1364,72 @@ extern "C" int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int 
   }
 #undef RM_MLP_FWD
   RM_CHECK_LAUNCH("rm_mlp_fwd");
+  return RM_OK;
+}
+
+extern "C" int rm_embed_mlp_fwd_supported(int F, int D, int64_t table_ld, int Dn, int NL, const int *H) {
+  if (D != 16 || table_ld != 32 || F < 1 || Dn < 0 || Dn > 16 || 16 * F + Dn > 448) return 0;
+  return rm_mlp_supported(16 * F, Dn, NL, H);
+}
+
+extern "C" int rm_embed_mlp_fwd(const int64_t *idx, const float *table, int64_t table_ld,
+                                const int64_t *field_off, int want_bias, int want_lin,
+                                const float *lin_w_dense, const float *lin_w0, const float *xd, int Dn,
+                                int64_t B, int F, int D, float *E, float *fm_sum, float *fm_logit,
+                                float *lin_logit, int flags, int NL, const int *H, const float *const *W,
+                                const float *const *bias, const float *w_out, const float *w0_out, int act,
+                                float *const *h_out, float *logit, const rm_mlp_tail *tail,
+                                rm_stream_t stream) {
+  RM_REQUIRE(H && rm_embed_mlp_fwd_supported(F, D, table_ld, Dn, NL, H),
+             "rm_embed_mlp_fwd: needs D = 16, table_ld = 32, Dn <= 16, 16 F + Dn <= 448 and hidden widths <= 32");
+  int rc = mlp_check("rm_embed_mlp_fwd", 16 * F, Dn, NL, H);
+  if (rc != RM_OK) return rc;
+  RM_REQUIRE(B >= 0, "rm_embed_mlp_fwd: B < 0");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(idx && table && field_off && E && rm_aligned16(table) && rm_aligned16(E) && (Dn == 0 || xd) && W &&
+                 bias && w_out && logit && h_out,
+             "rm_embed_mlp_fwd: NULL or unaligned argument");
+  RM_REQUIRE(fm_sum == nullptr || rm_aligned16(fm_sum), "rm_embed_mlp_fwd: fm_sum must be 16-byte aligned");
+  RM_REQUIRE(lin_w_dense == nullptr || Dn > 0, "rm_embed_mlp_fwd: lin_w_dense without dense inputs");
+  for (int l = 0; l < NL; ++l) RM_REQUIRE(W[l] && bias[l], "rm_embed_mlp_fwd: NULL weight / bias of layer %d", l);
+  if (tail) {
+    if ((rc = mlp_tail_check("rm_embed_mlp_fwd", tail, NL)) != RM_OK) return rc;
+    // the head's other branches are the ones this kernel produces (or absent)
+    RM_REQUIRE((tail->logit_a == nullptr || tail->logit_a == lin_logit || tail->logit_a == fm_logit) &&
+                   (tail->logit_b == nullptr || tail->logit_b == lin_logit || tail->logit_b == fm_logit),
+               "rm_embed_mlp_fwd: tail.logit_a / logit_b must be this call's lin_logit / fm_logit buffers");
+  }
+  MlpW w;
+  for (int l = 0; l < kMaxNL; ++l) {
+    w.W[l] = l < NL ? W[l] : nullptr;
+    w.b[l] = l < NL ? bias[l] : nullptr;
+    w.H[l] = l < NL ? H[l] : 0;
+  }
+  const EmbFront ef{idx, table, field_off, lin_w_dense, lin_w0, xd, F, want_bias, want_lin, E, fm_sum, fm_logit, lin_logit};
+  const size_t smem = mlp_fwd_smem(16 * F + Dn, NL, tail != nullptr);
+  const int64_t ntiles = (B + 31) / 32;
+  dim3 grid((unsigned)rm_grid_cap((ntiles + RM_MLP_FWD_WAVES - 1) / RM_MLP_FWD_WAVES, 256));
+  hipStream_t st = (hipStream_t)stream;
+  float *h0 = h_out[0], *h1 = NL > 1 ? h_out[1] : nullptr, *h2 = NL > 2 ? h_out[2] : nullptr;
+  const rm_mlp_tail tl = tail ? *tail : rm_mlp_tail{};
+  const bool nt = (flags & 1) != 0;  // RM_EMBED_STREAM_ROWS
+#define RM_EMF(NL_, TAIL_, NT_)                                                                          \
+  {                                                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(embed_mlp_fwd_kernel<NL_, TAIL_, NT_>),     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                    \
+    hipLaunchKernelGGL((embed_mlp_fwd_kernel<NL_, TAIL_, NT_>), grid, dim3(64 * RM_MLP_FWD_WAVES), smem, \
+                       st, ef, xd, Dn, w, w_out, w0_out, act, B, h0, h1, h2, logit, tl);                 \
+  }
+#define RM_EMF_NL(TAIL_, NT_)                                                                       \
+  if (NL == 1) RM_EMF(1, TAIL_, NT_) else if (NL == 2) RM_EMF(2, TAIL_, NT_) else RM_EMF(3, TAIL_, NT_)
+  if (tail) {
+    if (nt) { RM_EMF_NL(true, true) } else { RM_EMF_NL(true, false) }
+  } else {
+    if (nt) { RM_EMF_NL(false, true) } else { RM_EMF_NL(false, false) }
+  }
+#undef RM_EMF_NL
+#undef RM_EMF
+  RM_CHECK_LAUNCH("rm_embed_mlp_fwd");
   return RM_OK;
 }
 

@@ -424,6 +424,9 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 self.grad_rows_m = [self.grad_rows] + [torch.empty_like(self.grad_rows)
                                                        for _ in range(self.micro_batches - 1)]
 
+        def _front_fused(self, m, lin_w):
+            return False  # the rows arrive through the exchange: no local table for rm_embed_mlp_fwd to gather from
+
         def _embed(self, idx, dense, want_fm, masks, lin_w=None):
             from . import ops
 

@@ -849,11 +849,78 @@ class DeepFMEngine(Engine):
     def _has_fm(self):
         return self.use_fm
 
+    def _front_fused(self, m, lin_w):
+        """The one-kernel front (rm_embed_mlp_fwd: gather + FM + linear + MLP + head) covers this call:
+        plain id features on the fused-row table, a skinny MLP, no dropout masks."""
+        hp = self.hp
+        if not (self.use_deep and self.use_linear and hp.get("front_fusion", True)) or self.mv_fields:
+            return False
+        if lin_w is not None or m.get("dnn") is not None or any(x is not None for x in m.get("fm", (None, None))):
+            return False
+        if getattr(self, "_front_ok", None) is None:
+            self._front_ok = bool(self.mlp.fused_ok and ops.embed_mlp_fwd_supported(
+                self.F, self.D, self.LD, self.Dn, self.mlp.hidden))
+        return self._front_ok
+
+    def _front_fwd(self, idx, dense, branches):
+        mlp, p = self.mlp, self.params
+        B, n = idx.shape[0], len(self.mlp.hidden)
+        mlp._alloc(B, idx.device)
+        mlp.keep, mlp.masks = [1] * (n + 1), [None] * (n + 1)
+        mlp.xe, mlp.xd, mlp.fused = self.E.view(-1, self.FD), (dense if self.Dn else None), True
+        req = getattr(self, "_head_req", None) if self.fuse_head else None
+        head = dict(req, branches=branches, coef_mlp=1.0) if req is not None else None
+        mlp.tail = ops.mlp_tail(B, dh=mlp.dhb, **head) if head is not None else None
+        mlp.head_done = head is not None
+        pre = mlp.prefix
+        ops.embed_mlp_fwd(
+            idx, self.rows, self.field_off, self.D, self.LD, dense if self.Dn else None,
+            [p[f"{pre}dnn_layer_{i}_weights"] for i in range(n)], [p[f"{pre}dnn_layer_{i}_bias"] for i in range(n)],
+            p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"], mlp.act, self.E, mlp.hb, mlp.out.view(B),
+            want_bias=self.use_fm and self.use_bias_tables, want_lin=True,
+            lin_w_dense=self.linear_w_dense if self.Dn else None, lin_w0=p["linear_w0"],
+            fm_sum=self.fm_sum if self.use_fm else None, fm_logit=self.fm_logit if self.use_fm else None,
+            lin_logit=self.lin_logit, stream_rows=self.hp.get("table_row_reuse", "stream") == "stream",
+            tail=mlp.tail)
+        self._head_done = mlp.head_done
+        return mlp.out.view(B)
+
+    def roofline_probes(self, idx, dense, y):
+        probes = super().roofline_probes(idx, dense, y)
+        if not self._front_fused({}, None):
+            return probes
+        # the step's dominant kernel is the one-kernel front; its algorithmic bytes = rm_embed_fwd's
+        # (SURVEY.md 8d) + what the MLP and the head move per example on top of x: the dense columns when
+        # the linear term has not already counted them, h_l written, dh_l written, the label, logit /
+        # pred / dlogit written (E is NOT read back: that is the point of the fusion)
+        B, n = idx.shape[0], len(self.mlp.hidden)
+        yk = dict(y=y) if y.dtype == I64 else dict(y_f=y)
+
+        def run():
+            self._head_req = dict(task=self.task, grad_scale=1.0, logit=self.logit, pred=self.pred,
+                                  dlogit=self.dlogit, loss_partial=self.loss_part, loss=self.loss, **yk)
+            try:
+                branches = [(self.lin_logit, 1.0)] + ([(self.fm_logit, 1.0)] if self.use_fm else [])
+                self._front_fwd(idx, dense, branches)
+            finally:
+                self._head_req = None
+
+        work = self._embed_fwd_bytes(B, self._has_fm()) + B * (2 * n * 32 * 4 + y.element_size() + 4 * 4)
+        return [dict(name="embed_mlp_fwd_kernel (rm_embed_mlp_fwd: gather + FM + linear + MLP + head)",
+                     symbol="embed_mlp_fwd_kernel", fn=run, work=work, bound="hbm")] + probes
+
     def _branches_fwd(self, idx, dense, training, masks, lin_w):
         hp = self.hp
         m = masks or {}
         if not training:
             m = {}
+        if self._front_fused(m, lin_w):
+            branches = [(self.lin_logit, 1.0)]
+            if self.use_fm:
+                branches.append((self.fm_logit, 1.0))
+            self.dnn_logit = self._front_fwd(idx, dense, list(branches))
+            branches.append((self.dnn_logit, 1.0))
+            return branches
         self._embed(idx, dense, self.use_fm, m, lin_w)
         branches = [(self.lin_logit, 1.0)]
         if self.use_fm:

@@ -336,6 +336,37 @@ def mlp_fwd(xe, xd, Ws, bs, w_out, w0_out, act, h_out, logit, tail=None):
               _ptr_array(h_out), _chk(logit, "logit", F32, (B,)), _tail_ref(tail), _stream())
 
 
+def embed_mlp_fwd_supported(F, D, table_ld, Dn, hidden):
+    """rm_embed_mlp_fwd_supported: the one-kernel gather + FM + linear + MLP forward covers this shape."""
+    return bool(_lib.lib().rm_embed_mlp_fwd_supported(int(F), int(D), int(table_ld), int(Dn), len(hidden),
+                                                      _int_array(list(hidden))))
+
+
+def embed_mlp_fwd(idx, rows, field_off, D, table_ld, xd, Ws, bs, w_out, w0_out, act, E, h_out, logit,
+                  want_bias=False, want_lin=False, lin_w_dense=None, lin_w0=None, fm_sum=None, fm_logit=None,
+                  lin_logit=None, stream_rows=False, tail=None):
+    """rm_embed_mlp_fwd: rm_embed_fwd (fused rows [D | bias | lin | ...]) + rm_mlp_fwd in one kernel."""
+    B, F = idx.shape
+    Dn = 0 if xd is None else xd.shape[1]
+    H = [W.shape[1] for W in Ws]
+    for l, W in enumerate(Ws):
+        _chk(W, f"W[{l}]", F32, (F * D + Dn if l == 0 else H[l - 1], H[l]))
+        _chk(bs[l], f"bias[{l}]", F32, (H[l],))
+        _chk(h_out[l], f"h_out[{l}]", F32, (B, 32))
+    if rows.dim() != 2 or rows.shape[1] != table_ld or not rows.is_contiguous():
+        raise ValueError("embed_mlp_fwd: rows must be the contiguous fused table [R, table_ld]")
+    _lib.call("rm_embed_mlp_fwd", _chk(idx, "idx", I64), _chk(rows, "rows", F32), int(table_ld),
+              _chk(field_off, "field_off", I64, (F,)), int(bool(want_bias)), int(bool(want_lin)),
+              _chk(lin_w_dense, "lin_w_dense", F32, (Dn,), allow_none=True),
+              _chk(lin_w0, "lin_w0", F32, (1,), allow_none=True), _chk(xd, "xd", F32, (B, Dn), allow_none=True),
+              Dn, B, F, int(D), _chk(E, "E", F32), _chk(fm_sum, "fm_sum", F32, (B, D), allow_none=True),
+              _chk(fm_logit, "fm_logit", F32, (B,), allow_none=True),
+              _chk(lin_logit, "lin_logit", F32, (B,), allow_none=True), 1 if stream_rows else 0, len(Ws),
+              _int_array(H), _ptr_array(Ws), _ptr_array(bs), _chk(w_out, "w_out", F32, (H[-1],)),
+              _chk(w0_out, "w0_out", F32, (1,)), ACT_IDS[act], _ptr_array(h_out), _chk(logit, "logit", F32, (B,)),
+              _tail_ref(tail), _stream())
+
+
 def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None, db=None,
             d_w_out=None, d_w0_out=None, d_xd_wsum=None, d_g_sum=None, tail=None, stream_d_rows=False):
     """tail: the struct the forward ran with - dh is already there (no chain launch) and the

@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recman_amd import ops  # noqa: E402
 
-B, FD, Dn, H = 131072, 416, 13, 400
+B, FD, Dn, H = int(os.environ.get("DENSE_B", 131072)), 416, 13, 400
 dev = "cuda"
 xe, xd = torch.randn(B, FD, device=dev), torch.randn(B, Dn, device=dev)
 W1, W2 = torch.randn(FD + Dn, H, device=dev) * 0.05, torch.randn(H, H, device=dev) * 0.05

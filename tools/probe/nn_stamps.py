@@ -10,16 +10,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from recman_amd import _lib, ops  # noqa: E402
 
-B, H = 131072, 400
+B, H = int(os.environ.get("DENSE_B", 131072)), 400
 dev = "cuda"
 h1, h2 = torch.randn(B, H, device=dev), torch.empty(B, H, device=dev)
 W2, b1 = torch.randn(H, H, device=dev) * 0.05, torch.zeros(H, device=dev)
 fws = torch.empty(ops.dense_filter_workspace(H, 448), device=dev)
-for _ in range(15):
+for _ in range(int(os.environ.get("DENSE_WARM", 15))):
     ops.dense_fwd(h1, None, W2, h2, fws, bias=b1, act="relu")
 torch.cuda.synchronize()
 lib = ctypes.CDLL(_lib.LIB_PATH)
-n = 2048
+n = min(8192, (B + 127) // 128 * 2)
 buf = (ctypes.c_ulonglong * (8 * n))()
 assert lib.rm_debug_nn_stamps(buf, 8 * n) == 0
 s = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
@@ -33,6 +33,9 @@ for g in (0, 1):
           f"epilogue {epi[m].mean():.2f} (max {epi[m].max():.2f})  block {(end - st)[m].mean():.2f}")
 ghz = s[:, 7] / np.maximum(s[:, 2] - s[:, 1], 1) * 0.1
 print(f"shader clock over the chunk loops: median {np.median(ghz):.3f} GHz (min {ghz.min():.3f} max {ghz.max():.3f})")
+print("clock by block start time: " + "  ".join(
+    f"[{lo:.0f}-{hi:.0f} us] {np.median(ghz[(st >= lo) & (st < hi)]):.3f}" for lo, hi in
+    [(q * end.max() / 8, (q + 1) * end.max() / 8) for q in range(8)] if ((st >= lo) & (st < hi)).any()))
 hw, xcc = s[:, 4], s[:, 6] & 15
 cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
 order = np.argsort(st)
