@@ -907,6 +907,9 @@ __global__ __launch_bounds__(256) void mlp_dh_chain_kernel(
   }
 }
 
+#ifndef RM_BWD_ABL
+#define RM_BWD_ABL 0  // ablation builds (wrong results): 1 no d_rows stores, 2 no dW0 MFMAs, 4 no dX MFMAs, 8 no x prefetch
+#endif
 template <bool NT_OUT>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(
     const float *__restrict__ xe, const float *__restrict__ xd, int FD, int Dn,
@@ -1017,10 +1020,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
       const int kb = kt * 32;
       float *xb = xs;  // single buffer: LDS ops of one wave execute in order
       store_ktile(xb, pf[j], lane);
-      load_ktile(pf[j], xe, xd, FD, Dn, B, ex_next, kb, lane);
+      if (!(RM_BWD_ABL & 8)) load_ktile(pf[j], xe, xd, FD, Dn, B, ex_next, kb, lane);
       // dW0[kb + c'][unit] += sum_ex x[ex][kb + c'] * dh0[ex][unit]   (first: needs the x tile intact)
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
+      for (int s = 0; s < ((RM_BWD_ABL & 2) ? 0 : 16); ++s)
         accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[(2 * s + h) * kLDT + c],
                                                       dT[(2 * s + h) * 33 + c], accw[j], 0, 0, 0);
       const bool has_dx = kb < FD;  // dX only for the embedding part of x (wave-uniform)
@@ -1029,7 +1032,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
+        for (int gq = 0; gq < ((RM_BWD_ABL & 4) ? 0 : 4); ++gq) {
           const float4 a4 = *reinterpret_cast<const float4 *>(W0r + (kb + c) * LDR + 8 * gq + 4 * h);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, dh[4 * gq + 0], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, dh[4 * gq + 1], acc, 0, 0, 0);
@@ -1068,7 +1071,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
             if (NT_OUT) {
               if (br < B && k < FD) store4_stream(d_rows + br * FD + k, o);
             } else {
-              if (br < B && k < FD) *reinterpret_cast<float4 *>(d_rows + br * FD + k) = o;
+              if (br < B && k < FD && (!(RM_BWD_ABL & 1) || o.x == 1234.5f)) *reinterpret_cast<float4 *>(d_rows + br * FD + k) = o;
             }
           }
         } else {
