@@ -107,7 +107,34 @@ __global__ void cin_prep_fwd_kernel(const float *__restrict__ W, int m, int H, i
 #ifndef RM_CIN_EXP
 #define RM_CIN_EXP 0  // ablation builds only (profiles/r01_p11): 1 = no per-chunk barrier, 2 = no output stores, 4 = non-temporal output stores (cin_fwd; none of them moves layer 1)
 #endif
-template <int NT, int MT>
+// Tile staging global -> LDS with ALL of a batch's loads issued before its first LDS store.  The plain
+// `for (t = tid; ...) lds[...] = global[...]` loops compiled to load -> s_waitcnt -> store per iteration:
+// 11 dependent round trips = 10.4 us of a 236 us cin_fwd block at layer 1, with every wave of the CU in the
+// same phase (tools/probe/cin_clock.py).  src(t) -> float4 (zero for rows past B), dst(t) -> LDS address.
+template <int NTHR, int BATCH, typename Src, typename Dst>
+__device__ __forceinline__ void cin_stage(int total, int tid, Src src, Dst dst) {
+  for (int base = tid; base < total; base += BATCH * NTHR) {
+    float4 v[BATCH];
+#pragma unroll
+    for (int q = 0; q < BATCH; ++q) {
+      const int t = base + q * NTHR;
+      v[q] = src(t < total ? t : total - 1);
+    }
+#pragma unroll
+    for (int q = 0; q < BATCH; ++q) {
+      const int t = base + q * NTHR;
+      if (t < total) *reinterpret_cast<float4 *>(dst(t)) = v[q];
+    }
+  }
+}
+
+// diagnostic build (-DRM_CIN_STAMP): thread 0 of every cin_fwd block records the shader clocks (s_memtime) and the
+// 100 MHz ticks (s_memrealtime) its chunk loop took, and the block's total ticks; rm_debug_cin_stamps reads them
+// (tools/probe/cin_clock.py).  Never defined in the product build.
+#ifdef RM_CIN_STAMP
+__device__ unsigned long long rm_cin_stamp_buf[4 * 8192];
+#endif
+template <int NT, int MT, int CPB = 1>
 __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
     const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride,
     const float *__restrict__ Wp, const float *__restrict__ bias, int act, int64_t B, int m, int H,
@@ -127,28 +154,51 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
   const int64_t b0 = (int64_t)blockIdx.x * epb;
   const int D4 = D / 4;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef RM_CIN_STAMP
+  const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
-  for (int t = tid; t < epb * m * D4; t += NTHR) {
-    const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
-    const int64_t b = b0 + bl;
-    const float4 v = b < B ? *reinterpret_cast<const float4 *>(X0 + (b * m + i) * D + 4 * d4) : z4;
-    *reinterpret_cast<float4 *>(X0s + i * kRows + bl * D + 4 * d4) = v;
-  }
+  cin_stage<NTHR, 4>(
+      epb * m * D4, tid,
+      [&](int t) {
+        const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+        const int64_t b = b0 + bl;
+        const float4 v = *reinterpret_cast<const float4 *>(X0 + ((b < B ? b : B - 1) * m + i) * D + 4 * d4);
+        return b < B ? v : z4;
+      },
+      [&](int t) {
+        const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+        return X0s + i * kRows + bl * D + 4 * d4;
+      });
   if (tid < kRows) X0s[m * kRows + tid] = 0.f;
-  for (int t = tid; t < epb * H * D4; t += NTHR) {
-    const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
-    const int64_t b = b0 + bl;
-    const float4 v =
-        b < B ? *reinterpret_cast<const float4 *>(Xk + b * xk_bstride + (int64_t)j * D + 4 * d4) : z4;
-    *reinterpret_cast<float4 *>(Xks + j * kRows + bl * D + 4 * d4) = v;
-  }
+  cin_stage<NTHR, 8>(
+      epb * H * D4, tid,
+      [&](int t) {
+        const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
+        const int64_t b = b0 + bl;
+        const float4 v =
+            *reinterpret_cast<const float4 *>(Xk + (b < B ? b : B - 1) * xk_bstride + (int64_t)j * D + 4 * d4);
+        return b < B ? v : z4;
+      },
+      [&](int t) {
+        const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
+        return Xks + j * kRows + bl * D + 4 * d4;
+      });
   if (He > H && tid < kRows) Xks[H * kRows + tid] = 0.f;
+  // CPB filter chunks of 32 k' are staged per barrier (CPB = 2 where the LDS allows: tools/probe/cin_clock.py
+  // showed the chunk loop at 81 % MFMA-busy with a barrier per chunk and 94 % with none - the two waves of a
+  // SIMD stall together at every barrier - so the barriers are halved: 2 buffers x CPB chunks)
   constexpr int PF = (NT * 256 + NTHR - 1) / NTHR;  // float4 of a filter chunk per thread
+  {
+    const int nch0 = Kp / 32;
 #pragma unroll
-  for (int q = 0; q < PF; ++q)
-    if (tid + q * NTHR < NT * 256)
-      *reinterpret_cast<float4 *>(Ws + (tid + q * NTHR) * 4) =
-          *reinterpret_cast<const float4 *>(Wp + (tid + q * NTHR) * 4);
+    for (int cq = 0; cq < CPB; ++cq)
+#pragma unroll
+      for (int q = 0; q < PF; ++q)
+        if (tid + q * NTHR < NT * 256)
+          *reinterpret_cast<float4 *>(Ws + cq * WCH + (tid + q * NTHR) * 4) =
+              *reinterpret_cast<const float4 *>(Wp + (int64_t)(cq < nch0 ? cq : nch0 - 1) * WCH + (tid + q * NTHR) * 4);
+  }
   __syncthreads();
 
   f32x16 acc[MT][NT];
@@ -159,23 +209,38 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+#ifdef RM_CIN_STAMP
+  const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int prow = wave * 32 * MT + c;  // + mt*32
   const int nchunks = Kp / 32;
+  const bool aligned = !sym && (He & 31) == 0;  // block-uniform
   int i_cur = 0, j_cur = 0;  // (i, even j) of the running k' pair: wave-uniform
   static_assert(PF <= 2, "the filter prefetch below is written out for at most 2 float4 per thread");
   const int pfi0 = tid < NT * 256 ? tid : NT * 256 - 1;                     // clamped: loads are
   const int pfi1 = tid + NTHR < NT * 256 ? tid + NTHR : NT * 256 - 1;       // always in bounds
-  for (int ch = 0; ch < nchunks; ++ch) {
-    // The next filter chunk is prefetched UNCONDITIONALLY into two named registers (the last
-    // iteration re-loads its own chunk).  As a conditional load into a float4 pf[PF] array the
+  static_assert(CPB == 1 || CPB == 2, "filter prefetch registers are written out for 1 or 2 chunks per barrier");
+  const int ngroups = (nchunks + CPB - 1) / CPB;
+  for (int grp = 0; grp < ngroups; ++grp) {
+    // The next group's filter chunks are prefetched UNCONDITIONALLY into named registers (chunk indices
+    // clamped: the last group re-loads the last chunk).  As a conditional load into a float4 pf[] array the
     // prefetch lived in scratch: global_load -> s_waitcnt vmcnt(0) -> scratch_store, i.e. the
     // whole L2 latency exposed twice per chunk (rocprof: 26 % of wave-cycles waiting).
-    const int nx = ch + 1 < nchunks ? ch + 1 : ch;
-    const float4 pf0 = *reinterpret_cast<const float4 *>(Wp + (int64_t)nx * WCH + pfi0 * 4);
-    float4 pf1 = pf0;
-    if constexpr (PF > 1) pf1 = *reinterpret_cast<const float4 *>(Wp + (int64_t)nx * WCH + pfi1 * 4);
+    const int na = (grp + 1) * CPB < nchunks ? (grp + 1) * CPB : nchunks - 1;
+    const int nb = (grp + 1) * CPB + 1 < nchunks ? (grp + 1) * CPB + 1 : nchunks - 1;
+    const float4 pf0 = *reinterpret_cast<const float4 *>(Wp + (int64_t)na * WCH + pfi0 * 4);
+    float4 pf1 = pf0, pf2 = pf0, pf3 = pf0;
+    if constexpr (PF > 1) pf1 = *reinterpret_cast<const float4 *>(Wp + (int64_t)na * WCH + pfi1 * 4);
+    if constexpr (CPB > 1) {
+      pf2 = *reinterpret_cast<const float4 *>(Wp + (int64_t)nb * WCH + pfi0 * 4);
+      if constexpr (PF > 1) pf3 = *reinterpret_cast<const float4 *>(Wp + (int64_t)nb * WCH + pfi1 * 4);
+    }
     __builtin_amdgcn_sched_barrier(0);  // keep the loads here, ahead of the MFMA steps
-    const float *Wb = Ws + (ch & 1) * WCH;
+#pragma unroll
+    for (int cq = 0; cq < CPB; ++cq) {
+    const int ch = grp * CPB + cq;
+    if (ch >= nchunks) break;  // block-uniform (odd chunk count)
+    const float *Wb = Ws + (grp & 1) * (CPB * WCH) + cq * WCH;
     // Operands one k-step ahead.  Left to itself hipcc issued every step's filter read right before
     // its first MFMA (ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs): the whole LDS latency sat in
     // front of every group of four MFMAs and the kernel ran at 67 % with or without its per-chunk
@@ -199,6 +264,48 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
       if (j_cur >= He) { ++i_cur; j_cur = sym ? (i_cur & ~1) : 0; }
     };
     static_assert(MT == 1, "the pipelined step loop is written for one M-tile per wave");
+    if (aligned) {
+      // He % 32 == 0 (layer 1 of configs[2]: H = 64): a chunk of 32 k' = (i, j0 .. j0 + 31) has ONE i - x0 is
+      // read once per chunk, the xk reads sit at compile-time offsets from one per-chunk base, and the
+      // (i, j) bookkeeping is two scalar operations per chunk.  The generic loop below spends 3-5 vector
+      // instructions per k-step on the two operand addresses; beside the partner wave's f32 MFMAs (which run
+      // on the same vector ALU) that was ~8 % of the chunk time (tools/probe/cin_clock.py: 81 % MFMA-busy).
+      const int cpi = He >> 5;  // chunks per i
+      const int ic = ch / cpi, j0 = (ch - ic * cpi) << 5;
+      const float x0v = X0s[ic * kRows + prow];
+      const float *xkp = Xks + (j0 + h) * kRows + prow;
+      auto read_fast = [&](int sidx, float &xkv, float (&wv)[NT]) {
+        xkv = xkp[2 * sidx * kRows];
+        const float *wp = Wb + (2 * sidx + h) * Np + c * NT;
+        if constexpr (NT == 4) {
+          const float4 t4 = *reinterpret_cast<const float4 *>(wp);
+          wv[0] = t4.x; wv[1] = t4.y; wv[2] = t4.z; wv[3] = t4.w;
+        } else if constexpr (NT == 2) {
+          const float2 t2 = *reinterpret_cast<const float2 *>(wp);
+          wv[0] = t2.x; wv[1] = t2.y;
+        } else {
+          wv[0] = wp[0];
+        }
+      };
+      float xkc, xkn, wc[NT], wn[NT];
+      read_fast(0, xkc, wc);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if (s + 1 < 16) read_fast(s + 1, xkn, wn);
+        const float av = x0v * xkc;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wc[nt], acc[0][nt], 0, 0, 0);
+        if (s + 1 < 16) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads of step s + 1
+          __builtin_amdgcn_sched_group_barrier(0x008, NT, 0); // MFMAs of step s
+          xkc = xkn;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
+        }
+      }
+    } else {
     float x0c, xkc, x0n, xkn, wc[NT], wn[NT];
     read_step(0, x0c, xkc, wc);
     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // (the groups are filled in program order)
@@ -217,14 +324,22 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
         for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
       }
     }
+    }  // generic (i, j) walk
+    }  // chunks of the group
     {
       // stores are unconditional wherever the chunk divides evenly over the threads: a store
       // inside `if (tid + ... < NT*256)` let the compiler sink the prefetch LOAD into that branch
-      float *Wn = Ws + ((ch + 1) & 1) * WCH;
+      float *Wn = Ws + ((grp + 1) & 1) * (CPB * WCH);
       constexpr bool kExact = (NT * 256) % NTHR == 0;
       if (kExact || tid < NT * 256) *reinterpret_cast<float4 *>(Wn + tid * 4) = pf0;
       if constexpr (PF > 1) {
         if (kExact || tid + NTHR < NT * 256) *reinterpret_cast<float4 *>(Wn + (tid + NTHR) * 4) = pf1;
+      }
+      if constexpr (CPB > 1) {
+        if (kExact || tid < NT * 256) *reinterpret_cast<float4 *>(Wn + WCH + tid * 4) = pf2;
+        if constexpr (PF > 1) {
+          if (kExact || tid + NTHR < NT * 256) *reinterpret_cast<float4 *>(Wn + WCH + (tid + NTHR) * 4) = pf3;
+        }
       }
     }
 #if !(RM_CIN_EXP & 1)
@@ -232,11 +347,14 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
 #endif
   }
 
+#ifdef RM_CIN_STAMP
+  const unsigned long long st_c2 = __builtin_amdgcn_s_memtime(), st_r2 = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- epilogue: bias + activation, [B,N,D] store, pooled sums through LDS ----
   // pool_s [rows / 4][Np]: every (4-row group, filter) partial has its OWN cell (plain stores), and the
   // D / 4 partials of an (example, filter) are then added in row order: bit-reproducible.  (The first
   // version added them with a float atomicAdd into one cell per example - four adders in hardware order.)
-  float *pool_s = Ws;  // 64 x Np floats <= 32 KB: fits the two filter buffers
+  float *pool_s = Ws;  // 64 x Np floats <= 32 KB: fits the filter buffers
   const bool want_pool = pooled != nullptr;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -284,7 +402,23 @@ __global__ __launch_bounds__(512 / MT) void cin_fwd_kernel(
       }
     }
   }
+#ifdef RM_CIN_STAMP
+  if (tid == 0 && blockIdx.x < 8192) {
+    __builtin_amdgcn_s_waitcnt(0);
+    rm_cin_stamp_buf[4 * blockIdx.x] = st_c2 - st_c1;
+    rm_cin_stamp_buf[4 * blockIdx.x + 1] = st_r2 - st_r1;
+    rm_cin_stamp_buf[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    rm_cin_stamp_buf[4 * blockIdx.x + 3] = st_r1 - st_r0;
+  }
+#endif
 }
+#ifdef RM_CIN_STAMP
+}  // namespace
+extern "C" int rm_debug_cin_stamps(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rm_cin_stamp_buf), sizeof(unsigned long long) * n);
+}
+namespace {
+#endif
 
 // ===========================================================================
 // Backward.
@@ -1008,8 +1142,8 @@ __global__ __launch_bounds__(64 * kDwrG) void cin_dw_reduce_kernel(const float *
   }
 }
 
-size_t cin_fwd_smem(int m, int H, int NT) {
-  return (size_t)((m + 1) * kRows + cin_He(H) * kRows + 2 * 32 * 32 * NT) * sizeof(float);
+size_t cin_fwd_smem(int m, int H, int NT, int cpb = 1) {
+  return (size_t)((m + 1) * kRows + cin_He(H) * kRows + 2 * cpb * 32 * 32 * NT) * sizeof(float);
 }
 
 }  // namespace
@@ -1043,7 +1177,8 @@ extern "C" int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bst
   RM_REQUIRE(!pooled || (pool_from >= 0 && pool_from <= N && pool_stride >= pool_col0 + N - pool_from),
              "rm_cin_layer_fwd: bad pooled layout");
   const int NT = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
-  const size_t smem = cin_fwd_smem(m, H, NT);
+  const int cpb = cin_fwd_smem(m, H, NT, 2) <= 160 * 1024 ? 2 : 1;  // two filter chunks per barrier where they fit
+  const size_t smem = cin_fwd_smem(m, H, NT, cpb);
   RM_REQUIRE(smem <= 160 * 1024, "rm_cin_layer_fwd: m=%d H=%d needs %zu B of LDS (> 160 KiB)", m, H, smem);
   hipStream_t st = (hipStream_t)stream;
   // first layer (Xk is X0 itself): symmetric k' ordering with a folded filter, about half the K'
@@ -1051,15 +1186,19 @@ extern "C" int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bst
   hipLaunchKernelGGL(cin_prep_fwd_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, NT, sym, filter_ws);
   const int epb = kRows / D;
   dim3 grid((unsigned)((B + epb - 1) / epb));
-#define RM_CIN_FWD(NT_)                                                                          \
-  {                                                                                              \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_fwd_kernel<NT_, 1>),            \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
-    hipLaunchKernelGGL((cin_fwd_kernel<NT_, 1>), grid, dim3(512), smem, st, X0, Xk, xk_bstride,  \
-                       filter_ws, bias, act, B, m, H, N, D, out, pooled, pool_stride, pool_col0, \
-                       pool_from, sym);                                                          \
+#define RM_CIN_FWD(NT_, CPB_)                                                                         \
+  {                                                                                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_fwd_kernel<NT_, 1, CPB_>),           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
+    hipLaunchKernelGGL((cin_fwd_kernel<NT_, 1, CPB_>), grid, dim3(512), smem, st, X0, Xk, xk_bstride, \
+                       filter_ws, bias, act, B, m, H, N, D, out, pooled, pool_stride, pool_col0,      \
+                       pool_from, sym);                                                               \
   }
-  if (NT == 1) RM_CIN_FWD(1) else if (NT == 2) RM_CIN_FWD(2) else RM_CIN_FWD(4)
+  if (cpb == 2) {
+    if (NT == 1) RM_CIN_FWD(1, 2) else if (NT == 2) RM_CIN_FWD(2, 2) else RM_CIN_FWD(4, 2)
+  } else {
+    if (NT == 1) RM_CIN_FWD(1, 1) else if (NT == 2) RM_CIN_FWD(2, 1) else RM_CIN_FWD(4, 1)
+  }
 #undef RM_CIN_FWD
   RM_CHECK_LAUNCH("rm_cin_layer_fwd");
   return RM_OK;
