@@ -963,6 +963,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
   // on every tile's critical path: profiles/r01_p9_mlp_bwd.md.)
   float4 dn[4];
   float gn;
+  // D == 16 (block-uniform): the tile's S rows are prefetched with them - lane (c, h) holds pieces 2h and
+  // 2h + 1 of example c's S - and g*S goes to LDS from registers.  (The generic staging loop below loads
+  // g and S and stores g*S inside the tile: two exposed round trips per tile on every wave; with all x
+  // loads, MFMAs and stores compiled out the kernel still took 30 of its 75 us, profiles/r02_front_fusion.md.)
+  const bool s_pf = s_lds && D == 16;
+  float4 sn0 = make_float4(0.f, 0.f, 0.f, 0.f), sn1 = sn0;
   {
     int64_t bn = (int64_t)(blockIdx.x < ntiles ? blockIdx.x : 0) * 32 + c;
     bn = bn < B ? bn : B - 1;
@@ -970,6 +976,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq)
       dn[gq] = *reinterpret_cast<const float4 *>(dh0 + bn * 32 + 8 * gq + 4 * h);
+    if (s_pf) {
+      sn0 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 8 * h);
+      sn1 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 8 * h + 4);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   stage_w0_store<false, 512>(W0r, LDR, w0v, Kp, tid);
@@ -986,6 +996,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
       dh[4 * gq + 0] = dn[gq].x; dh[4 * gq + 1] = dn[gq].y;
       dh[4 * gq + 2] = dn[gq].z; dh[4 * gq + 3] = dn[gq].w;
     }
+    if (s_pf) {  // g*S of this tile from the prefetched registers (rows past B: gb = 0)
+      *reinterpret_cast<float4 *>(gS + c * 16 + 8 * h) = make_float4(gb * sn0.x, gb * sn0.y, gb * sn0.z, gb * sn0.w);
+      *reinterpret_cast<float4 *>(gS + c * 16 + 8 * h + 4) = make_float4(gb * sn1.x, gb * sn1.y, gb * sn1.z, gb * sn1.w);
+    }
     {  // next tile's values (the last tile re-loads its own)
       int64_t bn = ex_next + c;
       bn = bn < B ? bn : B - 1;
@@ -993,8 +1007,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq)
         dn[gq] = *reinterpret_cast<const float4 *>(dh0 + bn * 32 + 8 * gq + 4 * h);
+      if (s_pf) {
+        sn0 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 8 * h);
+        sn1 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 8 * h + 4);
+      }
     }
-    if (s_lds) {
+    if (s_lds && !s_pf) {
       // g[b] * S[b][:] of this tile, once per tile: every k-tile's epilogue adds the same 16-byte
       // piece of it (k % D repeats), read back row-major from LDS instead of from global memory
       const int D4 = D >> 2;
