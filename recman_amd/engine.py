@@ -675,8 +675,22 @@ class Engine:
         out = []
         for p in self.roofline_probes(idx, dense, y):
             fn = p["fn"]
+            # warm-up by TIME, not by count: the chip raises its clock only after ~10 ms of sustained load
+            # (in-kernel s_memtime / s_memrealtime: a 0.37 ms GEMM launch runs at 1.97 GHz after 15
+            # back-to-back launches and at 2.35 GHz after 30, profiles/r02_dense_gemm.md) - the training
+            # loop the kernel belongs to runs sustained, so it is priced at the sustained clock
+            t_warm = torch.cuda.Event(enable_timing=True)
+            t_warm.record()
             for _ in range(3):
                 fn()
+            while True:
+                for _ in range(5):
+                    fn()
+                t_now = torch.cuda.Event(enable_timing=True)
+                t_now.record()
+                t_now.synchronize()
+                if t_warm.elapsed_time(t_now) >= 40.0:
+                    break
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for _ in range(iters)]
             for a, b in ev:
