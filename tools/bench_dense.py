@@ -56,3 +56,14 @@ for name, flop, fn in calls:
     total += med
     print(f"{name:42s} {med:8.1f} us  {flop / med / 1e6:6.1f} TFLOP/s  {flop / med / 1e6 / 157.3:5.3f} of the f32 MFMA peak")
 print(f"sum {total:.1f} us   lib {os.environ.get('RECMAN_HIP_LIB', 'product')}")
+# the same six calls back to back without a host synchronisation in between (the state a training loop is in:
+# the chip raises its clock only under sustained load)
+for rounds in (5, 20, 100):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rounds):
+        for _, _, fn in calls[:6]:
+            fn()
+    e1.record()
+    e1.synchronize()
+    print(f"sustained: {rounds:3d} rounds of the six calls, {e0.elapsed_time(e1) * 1e3 / rounds:8.1f} us per round")
