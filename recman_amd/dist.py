@@ -145,15 +145,21 @@ class RowExchange:
             self.send_counts = self.recv_counts = [self.n]
             self.recv_ids = self.send_ids
 
-    def fetch(self, owner_rows, async_op=False):
+    def fetch(self, owner_rows, async_op=False, extra_rows=0):
         """owner_rows [len(recv_ids), W]: the rows this rank serves, in recv_ids order ->
         [n, W] rows for this rank's occurrences in BUCKETED order: occurrence o is row pos[o].
         async_op: returns (rows, work) - the caller calls work.wait() before it reads the rows,
         and whatever it enqueues in between overlaps the exchange."""
         if not self.coll:
+            if extra_rows:
+                out = torch.empty(self.slots + extra_rows, owner_rows.shape[1], dtype=owner_rows.dtype,
+                                  device=owner_rows.device)
+                out[: self.slots].copy_(owner_rows)
+                owner_rows = out
             return (owner_rows, None) if async_op else owner_rows
-        out = torch.empty(self.slots, owner_rows.shape[1], dtype=owner_rows.dtype, device=owner_rows.device)
-        work = _all_to_all(out, owner_rows, self.send_counts, self.recv_counts, group=self.group,
+        out = torch.empty(self.slots + extra_rows, owner_rows.shape[1], dtype=owner_rows.dtype,
+                          device=owner_rows.device)
+        work = _all_to_all(out[: self.slots], owner_rows, self.send_counts, self.recv_counts, group=self.group,
                            async_op=async_op)
         return (out, work) if async_op else out
 
@@ -238,20 +244,22 @@ class ShardedTable:
             mine = (g % self.world) == self.rank
             self.shard[(g[mine] // self.world).to(self.shard.device)] = ck["rows"][mine].to(self.shard.device)
 
-    def lookup(self, idx, field_off):
+    def lookup(self, idx, field_off, extra_rows=0):
         """idx [B,F] -> (rows [n, D+4] in BUCKETED order, the RowExchange): the row of
-        occurrence o = b*F+f is rows[ex.pos[o]] - consumers gather through pos, no un-route copy."""
-        ex = self.lookup_start(idx, field_off)
+        occurrence o = b*F+f is rows[ex.pos[o]] - consumers gather through pos, no un-route copy.
+        extra_rows: that many more rows are allocated behind the received ones (the pooled rows of
+        multi-valued features are built there, addressable like received rows)."""
+        ex = self.lookup_start(idx, field_off, extra_rows)
         return self.lookup_finish(ex), ex
 
-    def lookup_start(self, idx, field_off):
+    def lookup_start(self, idx, field_off, extra_rows=0):
         """Routes, exchanges the ids, gathers this shard's rows and STARTS the row exchange; what
         the caller enqueues before lookup_finish(ex) runs while the rows travel."""
         ex = RowExchange(idx, field_off, self.world, self.route_fn, self.group, self.capacity(idx.numel()))
         served = torch.empty(len(ex.recv_ids), self.W, dtype=torch.float32, device=self.shard.device)
         self.gather_fn(self.shard[:, : self.W], ex.recv_ids, served)  # (the state columns stay home)
         ex.served = served  # keeps the send buffer alive until the exchange is done
-        ex.rows, ex.rows_work = ex.fetch(served, async_op=True)
+        ex.rows, ex.rows_work = ex.fetch(served, async_op=True, extra_rows=extra_rows)
         return ex
 
     def lookup_finish(self, ex):
@@ -378,12 +386,12 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
         sharded = True
 
         def __init__(self):
-            if spec.scratch_names:
-                # their pooled rows are built from table rows that live on other ranks: the tags
-                # would have to travel as an expanded occurrence list ("Next")
+            if spec.scratch_names and (capacity_factor or int(micro_batches) > 1):
+                # their tags travel as an expanded occurrence list whose length changes from batch to batch:
+                # dynamic split sizes only (no fixed-capacity buckets, no captured segments, no micro-batches)
                 raise NotImplementedError(
-                    f"row-sharded table: multi-valued / value features {sorted(spec.scratch_names)} "
-                    "are not supported yet (single-GPU engines handle them)")
+                    f"row-sharded table: multi-valued / value features {sorted(spec.scratch_names)} need the "
+                    "dynamic exchange layout (capacity_factor=None) and micro_batches=1")
             for k in ("embedding_l2_reg", "linear_l2_reg"):
                 if hp.get(k, 0.0):
                     # a dense l2 term on the table makes EVERY row's gradient non-zero (layers.py:188-193):
@@ -412,11 +420,17 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             self.params["table_shard"] = self.st.shard
             self.params["linear_w_dense"] = self.linear_w_dense
 
+        def _alloc_mv(self, B):
+            # (no scratch block beside a local table: the pooled rows are built behind the received rows)
+            self._arange = torch.arange(B, dtype=torch.int64, device=self.device)
+            self._fix_cols = [f for f in range(self.F) if f not in self.mv_fields]
+
         def _alloc(self, B):
             first = self._B != B
             super()._alloc(B)
             if first:
                 self._zoff = torch.zeros(self.F, dtype=torch.int64, device=self.device)
+                self._zoff1 = torch.zeros(1, dtype=torch.int64, device=self.device)
                 slots = world * self.st.capacity(B * self.F) or B * self.F
                 self.grad_rows = torch.empty(slots, self.D + PAD, dtype=torch.float32, device=self.device)
                 # one send buffer per micro-batch: its exchange is still in flight while the
@@ -434,17 +448,23 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             fm_masks = m.get("fm", (None, None))
             B = idx.shape[0]
             # rows arrive owner-bucketed; the gather kernel reads occurrence (b,f) at row pos[b,f]
-            if self._slot is not None:      # captured segment: static buffers, exchange done by the caller
+            if self.mv_fields:
+                pos = self._lookup_mv(idx)
+            elif self._slot is not None:      # captured segment: static buffers, exchange done by the caller
                 self.ex, self.rows = self._slot, self._slot.rows
+                pos = self.ex.pos.view(B, self.F)
             elif self._pending is not None:   # a micro-batch whose exchange was started earlier
                 self.ex, self._pending = self._pending, None
                 self.rows = self.st.lookup_finish(self.ex)
+                pos = self.ex.pos.view(B, self.F)
             else:
                 self.rows, self.ex = self.st.lookup(idx, self.field_off)
+                pos = self.ex.pos.view(B, self.F)
+            self._pos = pos
             W = self.D + PAD
             flat = self.rows.view(-1)
             ops.embed_fwd(
-                self.ex.pos.view(B, self.F), self.rows, self._zoff, table_ld=W, D=self.D,
+                pos, self.rows, self._zoff, table_ld=W, D=self.D,
                 bias_table=flat[self.D:] if want_fm else None, bias_ld=W,
                 lin_w=flat[self.D + 1:] if self.use_linear else None, lin_ld=W, lin_off=self._zoff,
                 lin_w_dense=self.linear_w_dense if (self.use_linear and self.Dn) else None,
@@ -455,20 +475,85 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 fm_logit=self.fm_logit if want_fm else None,
                 lin_logit=self.lin_logit if self.use_linear else None)
 
-        def _one(self, idx, dense, y, masks, grad_rows):
+        def _lookup_mv(self, idx):
+            """Multi-valued / value features: the exchange carries ONE flat occurrence list - the plain
+            fields' (b, f) occurrences followed by every tag of every scratch-row feature - and each
+            example's pooled row (rm_pool_rows: sqrtn combiner, or value-weighted) is built from the
+            received tag rows into rows BEHIND the received ones; returns pos [B, F] for the gather."""
+            from . import ops
+
+            B, D, W = idx.shape[0], self.D, self.D + PAD
+            fix = self._fix_cols
+            lists = [(idx[:, fix] + self.field_off[fix]).reshape(-1)]
+            ents = []
+            for f in self.mv_fields:
+                offsets, ids, vals = self._mv_entry(f)
+                ents.append((offsets, ids, vals))
+                lists.append(ids + self.field_off[f])
+            flat = torch.cat(lists).view(-1, 1)
+            nmv = len(self.mv_fields)
+            self.rows, self.ex = self.st.lookup(flat, self._zoff1, extra_rows=nmv * B)
+            slots = self.ex.slots
+            pos = torch.empty(B, self.F, dtype=torch.int64, device=idx.device)
+            nfix = B * len(fix)
+            pos[:, fix] = self.ex.pos[:nfix].view(B, len(fix))
+            self._mv_pos, o = [], nfix
+            for j, (f, (offsets, ids, vals)) in enumerate(zip(self.mv_fields, ents)):
+                ptag = self.ex.pos[o: o + ids.numel()]
+                o += ids.numel()
+                self._mv_pos.append(ptag)
+                tag_rows = self.rows.index_select(0, ptag)
+                if vals is None:
+                    tag_rows[:, D + 1] *= (ids >= 1).to(tag_rows.dtype)  # slot 0 leaves the multi-hot count (utils.py:108)
+                # (ids shifted by one against row0 = -1: rm_pool_rows' own `id >= 1` rule then keeps every row)
+                ops.pool_rows(tag_rows, -1, D, offsets, torch.arange(1, ids.numel() + 1, device=ids.device), 
+                              self.rows[slots + j * B: slots + (j + 1) * B], vals=vals)
+                pos[:, f] = slots + j * B + self._arange
+            return pos
+
+        def _pack_mv(self, grad_rows):
+            """Gradient rows of the tags: each tag occurrence has its own slot; its row is the pooled row's
+            gradient times the tag's pooling factors (what rm_pool_rows_bwd scatters on one GPU)."""
+            B, D = self._B, self.D
+            g_fm = self.dlogit if self._has_fm() else None
+            for j, f in enumerate(self.mv_fields):
+                offsets, ids, vals = self._mv_entry(f)
+                n = offsets[1:] - offsets[:-1]
+                seg = torch.repeat_interleave(self._arange, n)
+                if vals is not None:   # value feature: embedding and linear scaled by the value, bias not
+                    we, wb, wl = vals, torch.ones_like(vals), vals
+                else:                  # sqrtn combiner; the linear term is a multi-hot count without slot 0
+                    inv = n.clamp(min=1).to(torch.float32).rsqrt()[seg]
+                    we, wb, wl = inv, inv, (ids >= 1).to(torch.float32)
+                g = torch.zeros(ids.numel(), D + PAD, dtype=torch.float32, device=ids.device)
+                g[:, :D] = self.d_rows[seg, f, :] * we.unsqueeze(1)
+                if g_fm is not None:
+                    g[:, D] = g_fm[seg] * wb
+                lin_on = self.lin_field_mask is None or float(self.lin_field_mask[f]) != 0.0
+                if self.use_linear and lin_on:
+                    g[:, D + 1] = self.dlogit[seg] * wl
+                grad_rows.index_copy_(0, self._mv_pos[j], g)
+
+        def _one(self, idx, dense, y, masks, grad_rows, mv=None):
             """fwd+bwd of one (micro-)batch; its gradient rows are packed into grad_rows and their
             exchange is started: returns (loss, ids, rows, work)."""
             from . import ops
 
-            loss = base.fwd_bwd(self, idx, dense, y, masks)
+            loss = base.fwd_bwd(self, idx, dense, y, masks, mv=mv) if mv is not None else base.fwd_bwd(self, idx, dense, y, masks)
+            if self.mv_fields:
+                # (slots + pooled-row region; the pooled rows' own gradients land behind the slots and stay home)
+                grad_rows = torch.zeros(self.rows.shape[0], self.D + PAD, dtype=torch.float32, device=self.device)
             # gradient rows [dE | g_fm | g_lin | 0 0], written straight in bucketed order -> owners
             ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
-                               self.dlogit if self.use_linear else None, self.ex.pos, grad_rows,
+                               self.dlogit if self.use_linear else None, self._pos.reshape(-1), grad_rows,
                                lin_field_mask=self.lin_field_mask)
+            if self.mv_fields:
+                self._pack_mv(grad_rows)
+                grad_rows = grad_rows[: self.ex.slots]
             out, work = self.ex.push(grad_rows, async_op=True)
             return loss, self.ex.recv_ids, out, work
 
-        def fwd_bwd(self, idx, dense, y, masks=None, weight=None):
+        def fwd_bwd(self, idx, dense, y, masks=None, weight=None, mv=None):
             """One step.  weight: this rank's share of the global batch (default 1 / world: equal
             per-rank batches; fit() passes B_local / B_global for a ragged last batch).
             micro_batches = M > 1 splits the batch into M equal micro-batches and
@@ -491,7 +576,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             self.hp = dict(self._hp_full, **{k: self._hp_full.get(k, 0.0) * self.grad_scale for k in _DENSE_L2})
             if M <= 1:
                 try:
-                    loss, ids, rows, work = self._one(idx, dense, y, masks, self.grad_rows)
+                    loss, ids, rows, work = self._one(idx, dense, y, masks, self.grad_rows, mv=mv)
                 finally:
                     self.hp = self._hp_full
                 if work is not None:
@@ -707,10 +792,10 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             if getattr(self, "ex", None) is None or getattr(self, "rows", None) is None:
                 raise RuntimeError("run fwd_bwd once before roofline_probe")
             fm = self._has_fm()
-            b = self.ex.pos.numel() // self.F  # the (micro-)batch of the last exchange
+            pos = self._pos                    # [b, F] of the (micro-)batch of the last exchange
+            b = pos.shape[0]
             W = self.D + PAD
             flat = self.rows.view(-1)
-            pos = self.ex.pos.view(b, self.F)
             d = dense[:b].contiguous() if (self.use_linear and self.Dn) else None
 
             def fn():

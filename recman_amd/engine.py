@@ -496,6 +496,11 @@ class Engine:
         self.loss_part = torch.empty((B + 31) // 32, dtype=F32, device=dev)  # fused head: per-tile loss sums
         self.ws = torch.empty(256 * 1024, dtype=F32, device=dev)
         self.mv_fields = [f for f, n in enumerate(self.spec.sparse_names) if n in self.spec.scratch_names]
+        self._alloc_mv(B)
+        self._alloc_model(B)
+
+    def _alloc_mv(self, B):
+        dev = self.device
         if self.mv_fields:
             # per-batch pooled rows of the multi-valued features live in a scratch block that is
             # addressed AS ROWS OF THE TABLE: its start is aligned so that (scratch - table) is a
@@ -512,7 +517,6 @@ class Engine:
                 self.field_off_mv[f] = base + j * B
             self.idx_mv = torch.zeros(B, self.F, dtype=I64, device=dev)
             self._arange = torch.arange(B, dtype=I64, device=dev)
-        self._alloc_model(B)
 
     def _alloc_model(self, B):
         pass

@@ -269,6 +269,114 @@ def test_two_ranks_three_optimizer_steps_equal_single_gpu(hip_lib, tmp_path, mod
     assert losses[2] < losses[0]
 
 
+def _mv_case(world, Bl):
+    """A DeepFM case with a multi-valued feature (C1) and a value feature (C3) over world * Bl examples."""
+    from tests.cases import make_case
+
+    spec, p, idx, dense, y, hp = make_case("deepfm", B=world * Bl, D=16, sizes=[7, 11, 5, 13, 3])
+    hp = dict(hp, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_l2_reg=1e-3)
+    g = torch.Generator().manual_seed(23)
+    B = world * Bl
+    n = torch.randint(0, 4, (B,), generator=g)           # 0..3 tags per example (empty lists included)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), n.cumsum(0)])
+    ids = torch.randint(0, spec.feat_sizes[1], (int(n.sum()),), generator=g)
+    vids = torch.randint(0, spec.feat_sizes[3], (B,), generator=g)
+    vals = torch.randn(B, generator=g)
+    return spec, p, idx, dense, y, hp, (offsets, ids), (vids, vals)
+
+
+def _mv_slice(mvt, vt, sl, names):
+    """The mv dict of the examples sl (device tensors): CSR re-based to the slice."""
+    offsets, ids = mvt
+    vids, vals = vt
+    o = offsets[sl.start: sl.stop + 1]
+    b = sl.stop - sl.start
+    return {names[0]: ((o - o[0]).cuda(), ids[int(o[0]): int(o[-1])].cuda()),
+            names[1]: (torch.arange(b + 1).cuda(), vids[sl].cuda(), vals[sl].cuda())}
+
+
+def _mv_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("RECMAN_FORCE_COLLECTIVES", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from recman_amd import dist as rd
+        from recman_amd import engine as eng
+
+        Bl = 24
+        spec, p, idx, dense, y, hp, mvt, vt = _mv_case(world, Bl)
+        names = (spec.sparse_names[1], spec.sparse_names[3])
+        espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names, [names[0]], [names[1]])
+        dev = torch.device("cuda", 0)
+        s = rd.make_sharded_engine("deepfm", espec, 16, hp, dev, rank, world)
+        s.load_params({k: v for k, v in p.items() if k in s.params})
+        full = torch.cat([p[f"{n}_feat_embed"] for n in spec.sparse_names])
+        bias = torch.cat([p[f"{n}_feat_bias"].reshape(-1) for n in spec.sparse_names])
+        s.st.load_global(full, bias=bias)
+        opt = s.optimizer("adam", 0.01)
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        il, dl, yl = idx[sl].cuda(), dense[sl].cuda(), y[sl].cuda()
+        mv = _mv_slice(mvt, vt, sl, names)
+        losses, logits = [], None
+        for _ in range(3):
+            losses.append(float(s.fwd_bwd(il, dl, yl, mv=mv)))
+            if logits is None:
+                logits = s.logit.clone().cpu()
+            opt.step()
+        torch.save({"rows": s.st.shard[:, : 16 + 2].cpu(), "losses": losses, "logit0": logits,
+                    "params": {k: v.detach().cpu() for k, v in s.params.items() if k != "table_shard"}},
+                   f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_multi_valued_and_value_features_train_like_single_gpu(hip_lib, tmp_path):
+    """Scratch-row features on the row-sharded table: the tags of a MultiValCsvFeat field and the ids of a
+    SparseValueFeat field travel as an expanded occurrence list behind the plain fields' occurrences, the
+    pooled rows are built from the received tag rows, the tags' gradient rows go back to their owners - three
+    training steps on two ranks equal three steps of the single-GPU engine (which pools from its local table
+    and steps the tag rows through optim.SparseTableOptimizer) to 1e-6."""
+    from recman_amd import engine as eng
+    from recman_amd.optim import FusedDenseOptimizer, SparseTableOptimizer
+
+    world, Bl = 2, 24
+    out = str(tmp_path / "mv")
+    mp.spawn(_mv_worker, args=(world, 29871, out), nprocs=world, join=True)
+    res = [torch.load(f"{out}.{r}", weights_only=True) for r in range(world)]
+    spec, p, idx, dense, y, hp, mvt, vt = _mv_case(world, Bl)
+    names = (spec.sparse_names[1], spec.sparse_names[3])
+    e = eng.ENGINES["deepfm"](eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names, [names[0]],
+                                              [names[1]]), 16, hp)
+    e.load_params({k: v for k, v in p.items() if k in e.params})
+    sopt, dopt = SparseTableOptimizer(e, "adam", 0.01), FusedDenseOptimizer(e, "adam", 0.01)
+    ib, db, yb = idx.cuda(), dense.cuda(), y.cuda()
+    mv = _mv_slice(mvt, vt, slice(0, world * Bl), names)
+    losses, logit0 = [], None
+    for _ in range(3):
+        losses.append(float(e.fwd_bwd(ib, db, yb, mv=mv)))
+        if logit0 is None:
+            logit0 = e.logit.clone().cpu()
+        sopt.step(ib)
+        dopt.step()
+    got0 = torch.cat([res[r]["logit0"] for r in range(world)])
+    assert float((got0 - logit0).abs().max()) <= 1e-6, "first-step logits"
+    for r in range(world):
+        want = e.rows[r::world, : 16 + 2].cpu()
+        err = float((res[r]["rows"] - want).abs().max())
+        assert err <= 1e-6 * max(1.0, float(want.abs().max())), f"rank {r} shard rows after 3 steps: {err:.3e}"
+        for k, v in res[r]["params"].items():
+            w = e.params[k].detach().cpu()
+            assert float((v - w).abs().max()) <= 1e-6 * max(1.0, float(w.abs().max())), (r, k)
+    mean_losses = [sum(res[r]["losses"][t] for r in range(world)) / world for t in range(3)]
+    for t in range(3):
+        assert abs(mean_losses[t] - losses[t]) < 2e-5, (t, mean_losses[t], losses[t])
+    assert losses[2] < losses[0]
+
+
 def _fit_worker(rank, world, port, model, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
