@@ -109,8 +109,6 @@ class DeepModel(BaseEstimator, TransformerMixin):
         from .. import dist as rdist
 
         rank, world = self._shard
-        if spec.scratch_names:
-            raise NotImplementedError("row-sharded table: multi-valued / value features are single-GPU only")
         name = hp.get("optimizer", "adam")
         dev = torch.device(self.device)
         if dev.index is None:
@@ -138,13 +136,13 @@ class DeepModel(BaseEstimator, TransformerMixin):
         b = a + base + (1 if rank < rem else 0)
         return a, b, (b - a) / n
 
-    def _fit_sharded_batch(self, idx, dense, yt):
+    def _fit_sharded_batch(self, idx, dense, yt, mv=None):
         e = self._engine
         M = e.micro_batches
         if idx.shape[0] % M:           # a ragged part: this step without the micro-batch pipeline
             e.micro_batches = 1
         try:
-            loss = e.fwd_bwd(idx, dense, yt, weight=self._w)
+            loss = e.fwd_bwd(idx, dense, yt, weight=self._w, mv=mv)
         finally:
             e.micro_batches = M
         self._shard_opt.step(reset=self.strict_reference)
@@ -278,7 +276,7 @@ class DeepModel(BaseEstimator, TransformerMixin):
             if self._dropout_masks(1) is not None:
                 raise NotImplementedError("row-sharded fit(): dropout is not wired through the exchange yet")
             self._w = getattr(self, "_w", None)
-            return self._fit_sharded_batch(idx, dense, yt)
+            return self._fit_sharded_batch(idx, dense, yt, mv)
         side = None
         if self._sparse_opt is not None and not e.spec.scratch_names:
             # the id-only third of the row-wise step (keys + sort by row) runs on a side stream beside the

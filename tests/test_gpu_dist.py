@@ -392,13 +392,23 @@ def _fit_worker(rank, world, port, model, out_path):
         import recman_amd.th as th
         from tests.test_gpu_models import ml_features, ml_frame
 
-        df = ml_frame().iloc[:1000]          # 1000 rows, batch 96: a ragged last batch (40 rows -> 20 + 20)
+        df = ml_frame().iloc[:1000].copy()   # 1000 rows, batch 96: a ragged last batch (40 rows -> 20 + 20)
+        if model == "deepfm_genres":         # + the multi-valued `genres` feature (its tags travel through the exchange)
+            from tests.test_gpu_models import GOLD
+
+            df["genres"] = GOLD["raw_genres"][:1000].astype(object)
         fd = ml_features(df)
+        if model == "deepfm_genres":
+            fd["genres"] = th.MultiValCsvFeat(name="genres", tags=tuple(GOLD["genre_tags"].tolist()))
         hp = {"embedding_size": 16, "deep_dropout": (1, 1, 1), "cin_cross_layer_units": [16, 16],
               "cin_dropout": [1, 1, 1], "learning_rate": 0.01, "embedding_l2_reg": 0.0, "linear_l2_reg": 0.0,
               "deep_l2_reg": 1e-4, "micro_batches": 2}
         if model == "xdeepfm":
             m = th.xDeepFM(fd, hp, epoch=2, batch_size=96)
+        elif model == "deepfm_genres":
+            m = th.DeepFM(fd, embedding_size=16, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_dropout=(1, 1, 1),
+                          learning_rate=0.01, epoch=2, batch_size=96)
+            assert m._build().spec.multi_names == ["genres"]
         else:
             m = th.DeepFM(fd, embedding_size=16, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_dropout=(1, 1, 1),
                           learning_rate=0.01, epoch=2, batch_size=96)
@@ -424,15 +434,16 @@ def _fit_worker(rank, world, port, model, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model", ["deepfm", "xdeepfm"])
+@pytest.mark.parametrize("model", ["deepfm", "xdeepfm", "deepfm_genres"])
 def test_model_fit_predict_save_restore_with_a_row_sharded_table_on_two_ranks(hip_lib, tmp_path, model):
     """The model classes under a two-rank torch.distributed job: the table row-sharded, fit() data parallel
-    (ragged last batch, micro-batches, dense l2), predict() on every rank, save() / restore() with one shard
-    file per rank.  Both ranks end with identical predictions and identical dense parameters, the loss
+    (ragged last batch, micro-batches, dense l2; "deepfm_genres": with ml-100k's multi-valued `genres`, whose tags
+    travel through the exchange), predict() on every rank, save() / restore() with one shard file per rank.  Both ranks end with identical predictions and identical dense parameters, the loss
     went down, a restored model predicts the same."""
     world = 2
     out = str(tmp_path / "f")
-    mp.spawn(_fit_worker, args=(world, 29990 + (1 if model == "xdeepfm" else 0), model, out), nprocs=world, join=True)
+    port = 29990 + ["deepfm", "xdeepfm", "deepfm_genres"].index(model)
+    mp.spawn(_fit_worker, args=(world, port, model, out), nprocs=world, join=True)
     res = [torch.load(f"{out}.{r}", weights_only=True) for r in range(world)]
     assert res[0]["after"] < res[0]["before"] - 0.01
     assert torch.equal(res[0]["pred"], res[1]["pred"])
