@@ -451,9 +451,10 @@ __global__ __launch_bounds__(kNNThreads, 2) void dense_nn_kernel(NNArgs a) {
   // Phase stagger.  The two blocks of a CU start together and do the same work at the same speed: left
   // alone they stay in lockstep (tools/probe/nn_stamps.py: both in the chunk loop for 87 us, then both in
   // the epilogue for 10-20 us - and so is every other CU: the whole chip computes with HBM idle, then
-  // stores 54 MB at once with the MFMA pipes idle).  The odd-group blocks of the FIRST round start half a
-  // block later (their partner has the SIMDs to itself meanwhile); every later round inherits the offset
-  // because a CU slot is refilled the moment its block ends.
+  // stores 54 MB at once with the MFMA pipes idle).  The odd-group blocks of the FIRST round start a little
+  // later (5 % of a block, ~4 us: enough to take the two epilogues apart; 0 / 5 / 10 / 25 % all run the same
+  // speed, profiles/r02_dense_gemm.md); every later round inherits the offset because a CU slot is refilled
+  // the moment its block ends.
   if (a.stagger_ticks > 0 && round == 0 && cg == 1) {
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)a.stagger_ticks) __builtin_amdgcn_s_sleep(16);
@@ -1004,7 +1005,7 @@ extern "C" int rm_dense_fwd(const float *A1, int64_t lda1, int K1, const float *
            ld_aux1, ld_aux2, M, C, C2, ldc, ldc2, span, groups, 0};
   if (epilogue == RM_DENSE_ADD && !aux1) { a.epi = RM_DENSE_BIAS_ACT; a.act = RM_ACT_IDENTITY; }
   if (ntiles * groups > 512) {  // more blocks than CU slots: rounds exist, stagger them
-    static const int pct = [] { const char *e = getenv("RECMAN_NN_STAGGER_PCT"); return e ? atoi(e) : 25; }();
+    static const int pct = [] { const char *e = getenv("RECMAN_NN_STAGGER_PCT"); return e ? atoi(e) : 5; }();
     const int nb_first = nbt < kMaxNB ? nbt : kMaxNB;
     // one block-time ~ nch chunks x 8 k-steps x nb MFMAs x 64 cycles at ~2.3 GHz, in 10 ns ticks
     a.stagger_ticks = (int)((int64_t)pct * nch * 8 * nb_first * 64 / 23 / 100);
