@@ -774,8 +774,9 @@ constexpr int kLDT = 36;  // k-tile slice row stride in LDS (32 + 4 pad)
 constexpr int kWT = 2;    // k-tiles per wave: Kp <= 448 -> 14 tiles over the block's 8 waves
 
 // A k-tile that lies entirely inside xe (wave-uniform test; every tile but the last for the
-// Criteo shape) is four unconditional float4 loads issued back to back.  Only a tile that touches
-// the xe / xd boundary takes the per-lane-branch form below - hipcc serialises those loads
+// Criteo shape) is four unconditional float4 loads issued back to back; a tile entirely behind xe
+// takes raw buffer loads.  Only a tile that STRADDLES the xe / xd boundary (FD % 32 == 16) takes the
+// per-lane-branch form below - hipcc serialises those loads
 // (branch + s_waitcnt vmcnt(0) per load), but it keeps their register footprint small, and the
 // kernel is register-bound (a branch-free tail cost it spills: profiles/r01_p7_loader_ablation.md).
 __device__ __forceinline__ void load_ktile(float4 (&v)[4], const float *__restrict__ xe,
@@ -793,6 +794,34 @@ __device__ __forceinline__ void load_ktile(float4 (&v)[4], const float *__restri
 #else
       v[q] = *reinterpret_cast<const float4 *>(xe + b * FD + k);
 #endif
+    }
+    return;
+  }
+  if (kb >= FD) {
+    // wave-uniform: the tile holds only dense columns and padding (the last k-tile of the Criteo shape:
+    // FD = 416 = 13 x 32).  Raw buffer loads on a tile descriptor: columns past Dn get an out-of-range
+    // offset and rows past B fall outside num_records - both read as 0, every load is unconditional.  (This
+    // tile used to take the per-lane-branch form below: 16 serialised loads per example tile on ONE wave of
+    // the block - in-kernel timestamps, tools/probe/bwd_stamps.py: that wave finished at 68 us, the others at
+    // 46-61, and the block waits for it: 73 -> 62 us.)
+    const int64_t rows_t = B - ex0 < 32 ? B - ex0 : 32;
+    const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Dn > 0 ? xd + ex0 * Dn : xe), 0,
+                                                        Dn > 0 ? (int)(rows_t * Dn * 4) : 0, 0x00020000);
+    // (four per-lane offsets, one per element of the float4; the row term 8 q Dn is a scalar offset: the
+    // 16 loads must not cost 16 address registers - the kernel sits at 239 VGPRs)
+    int vo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kk = k + e - FD;
+      vo[e] = kk < Dn ? ((lane >> 3) * Dn + kk) * 4 : 0x7ffffff0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int so = __builtin_amdgcn_readfirstlane(8 * q * Dn * 4);
+      v[q] = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo[0], so, 0)),
+                         __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo[1], so, 0)),
+                         __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo[2], so, 0)),
+                         __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo[3], so, 0)));
     }
     return;
   }
@@ -907,6 +936,13 @@ __global__ __launch_bounds__(256) void mlp_dh_chain_kernel(
   }
 }
 
+// diagnostic build (-DRM_BWD_STAMP): thread 0 of wave 0 of every mlp_bwd block records s_memrealtime (100 MHz) at
+// start / after the prologue / after its tile loop / at the end, plus the ticks it spent in the per-tile staging
+// (dT, g*S) and in its k-tile loops; rm_debug_bwd_stamps reads them (tools/probe/bwd_stamps.py).
+#ifdef RM_BWD_STAMP
+__device__ unsigned long long rm_bwd_stamp_buf[8 * 8 * 256];
+#define RM_BT() __builtin_amdgcn_s_memrealtime()
+#endif
 #ifndef RM_BWD_ABL
 #define RM_BWD_ABL 0  // ablation builds (wrong results): 1 no d_rows stores, 2 no dW0 MFMAs, 4 no dX MFMAs, 8 no x prefetch
 #endif
@@ -930,6 +966,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
   // VGPRs and every change to its epilogue spilled (profiles/r01_p9_mlp_bwd.md).
   const int tid = threadIdx.x, lane = tid & 63, wv8 = tid >> 6, wave = wv8;
   const int h = lane >> 5, c = lane & 31;
+#ifdef RM_BWD_STAMP
+  const unsigned long long bt0 = RM_BT();
+  unsigned long long bt_stage = 0, bt_kt = 0;
+#endif
 
   // prologue loads in the order parameters (L2) -> first tile's x / g / dh0 (HBM) -> parameters' LDS
   // stores, as in mlp_fwd_kernel: the HBM stream starts at t = 0 and the staging runs under it
@@ -949,12 +989,21 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
   // x slices are prefetched ONE EXAMPLE TILE ahead: pf[j] always holds (or has in flight) the
   // wave's j-th k-tile of the tile about to be processed; it is re-issued for the next example
   // tile as soon as it has been copied to LDS (unconditionally - the last tile re-loads itself)
+  // k-tile slots of this wave: slot j = tile wave + 8 j, both products (dX and dW0) - except at 14 k-tiles
+  // (the Criteo shape), where that leaves SIMD 0 (waves 0 and 4) with four full tiles and SIMDs 2 and 3 with
+  // three (in-kernel timestamps: wave 4 finished at 61 us, waves 6 and 7 at 46; the block waits for the last):
+  // tile 12 is SPLIT - wave 4 keeps its dX, wave 6 (one tile so far) takes its dW0 - 3.5 / 3.5 / 3.5 / 3 tiles
+  // per SIMD.  Both waves stage the tile's x slices (the second read hits L2).
+  const bool split14 = nkt == 14;
+  auto slot_kt = [&](int j) { return (split14 && wave == 6 && j == 1) ? 12 : wave + 8 * j; };
+  auto slot_dw = [&](int j) { return !(split14 && wave == 4 && j == 1); };
+  auto slot_dx = [&](int j) { return !(split14 && wave == 6 && j == 1); };
   float4 pf[kWT][4];
   {
     const int64_t e0 = (int64_t)(blockIdx.x < ntiles ? blockIdx.x : 0) * 32;
 #pragma unroll
     for (int j = 0; j < kWT; ++j)
-      if (wave + 8 * j < nkt) load_ktile(pf[j], xe, xd, FD, Dn, B, e0, (wave + 8 * j) * 32, lane);
+      if (slot_kt(j) < nkt) load_ktile(pf[j], xe, xd, FD, Dn, B, e0, slot_kt(j) * 32, lane);
   }
   // ... and so are the tile's g and dh0 values (written by mlp_dh_chain_kernel, the launch before):
   // lane (c = example, h) holds dh0[example][8 gq + 4 h + e] - the B operand of the dX product as it
@@ -984,7 +1033,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
   __builtin_amdgcn_sched_barrier(0);
   stage_w0_store<false, 512>(W0r, LDR, w0v, Kp, tid);
   __syncthreads();
+#ifdef RM_BWD_STAMP
+  const unsigned long long bt1 = RM_BT();
+#endif
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef RM_BWD_STAMP
+    const unsigned long long bta = RM_BT();
+#endif
     const int64_t ex0 = tile * 32;
     const int64_t ex_next = (tile + gridDim.x < ntiles ? tile + gridDim.x : tile) * 32;
     const int64_t b = ex0 + c;
@@ -1030,21 +1085,29 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) dT[c * 33 + unit_of(r, h)] = valid ? dh[r] : 0.f;
 
+#ifdef RM_BWD_STAMP
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the staging's LDS writes have left
+    const unsigned long long btb = RM_BT();
+    bt_stage += btb - bta;
+#endif
     // ---- this wave's k-tiles: dX tile (-> d_rows) and dW0 tile ----
 #pragma unroll
     for (int j = 0; j < kWT; ++j) {
-      const int kt = wave + 8 * j;
+      const int kt = slot_kt(j);
       if (kt >= nkt) break;
       const int kb = kt * 32;
+      const bool do_dw = slot_dw(j);  // wave-uniform
       float *xb = xs;  // single buffer: LDS ops of one wave execute in order
       store_ktile(xb, pf[j], lane);
       if (!(RM_BWD_ABL & 8)) load_ktile(pf[j], xe, xd, FD, Dn, B, ex_next, kb, lane);
       // dW0[kb + c'][unit] += sum_ex x[ex][kb + c'] * dh0[ex][unit]   (first: needs the x tile intact)
+      if (do_dw) {
 #pragma unroll
-      for (int s = 0; s < ((RM_BWD_ABL & 2) ? 0 : 16); ++s)
-        accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[(2 * s + h) * kLDT + c],
-                                                      dT[(2 * s + h) * 33 + c], accw[j], 0, 0, 0);
-      const bool has_dx = kb < FD;  // dX only for the embedding part of x (wave-uniform)
+        for (int s = 0; s < ((RM_BWD_ABL & 2) ? 0 : 16); ++s)
+          accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[(2 * s + h) * kLDT + c],
+                                                        dT[(2 * s + h) * 33 + c], accw[j], 0, 0, 0);
+      }
+      const bool has_dx = kb < FD && slot_dx(j);  // dX only for the embedding part of x (wave-uniform)
       f32x16 acc;
       if (has_dx) {
 #pragma unroll
@@ -1111,19 +1174,39 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the unrolled k-tiles from being interleaved
     }
+#ifdef RM_BWD_STAMP
+    bt_kt += RM_BT() - btb;
+#endif
   }
+#ifdef RM_BWD_STAMP
+  const unsigned long long bt2 = RM_BT();
+#endif
 
   // ---- the block's dW0 partial: every wave owns the rows of its k-tiles ----
 #pragma unroll
   for (int j = 0; j < kWT; ++j) {
-    const int kt = wave + 8 * j;
-    if (kt < nkt) {
+    const int kt = slot_kt(j);
+    if (kt < nkt && slot_dw(j)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         dW0_part[((int64_t)blockIdx.x * Kp + kt * 32 + unit_of(r, h)) * 32 + c] = accw[j][r];
     }
   }
+#ifdef RM_BWD_STAMP
+  if (lane == 0 && blockIdx.x < 256) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long *o = rm_bwd_stamp_buf + 8 * (blockIdx.x * 8 + wave);
+    o[0] = bt1 - bt0; o[1] = bt2 - bt1; o[2] = RM_BT() - bt2; o[3] = bt_stage; o[4] = bt_kt; o[5] = bt0;
+  }
+#endif
 }
+#ifdef RM_BWD_STAMP
+}  // namespace
+extern "C" int rm_debug_bwd_stamps(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rm_bwd_stamp_buf), sizeof(unsigned long long) * n);
+}
+namespace {
+#endif
 
 // dW0[k][u] = sum_slabs part[slab][k][u]   (k < K, u < H0).  A block owns 64 consecutive
 // slab elements; its 4 waves take every 4th slab (coalesced 256-byte reads), partial sums
