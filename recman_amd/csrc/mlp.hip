@@ -398,6 +398,12 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void mlp_fwd_kernel(
 // MFMA phase (c = lane & 31, h = lane >> 5) as in mlp_fwd_kernel.  Prologue and tile epilogue are
 // mlp_fwd_kernel's (kept textually parallel: a change there belongs here too).
 // ---------------------------------------------------------------------------
+// diagnostic build (-DRM_EMF_STAMP): lane 0 of every wave of embed_mlp_fwd_kernel records s_memrealtime at start /
+// after the prologue / after the chunk loop of its (first) tile / at the end, and the ticks it spent waiting for row
+// loads at the top of each half chunk; rm_debug_emf_stamps reads them (tools/probe/emf_stamps.py).
+#ifdef RM_EMF_STAMP
+__device__ unsigned long long rm_emf_stamp_buf[8 * 8 * 256];
+#endif
 #ifndef RM_EMF_ABL
 #define RM_EMF_ABL 0  // ablation builds (wrong results): 1 no layer-0 MFMAs, 2 no E stores, 4 no x writes to LDS
 #endif
@@ -430,6 +436,10 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void embed_mlp_fwd_kernel(
   const int ex_l = lane >> 3, sub = lane & 7;
   const bool emb = sub < 4, side = sub == 4 && (ef.want_bias || ef.want_lin);
   static_assert(NTHR == 512, "the staging below is written for 8 waves");
+#ifdef RM_EMF_STAMP
+  const unsigned long long et0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long et1 = 0, et2 = 0, et_wait = 0;
+#endif
 
   const int64_t ntiles = (B + 31) / 32;
   const int64_t tile0 = (int64_t)blockIdx.x * NW + wave;
@@ -510,11 +520,29 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void embed_mlp_fwd_kernel(
   if (tid < (NL + 1) * 32) bs[tid] = bsv;
   __syncthreads();
 
+#ifdef RM_EMF_STAMP
+  et1 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int kLDH = 36;  // row stride of the half-chunk x tile (32 + 4: conflict-free b128 reads)
   float *xs = xs_all + wave * 32 * kLDX;
+  // linear term: this lane's two dense weights (columns sub and sub + 8; 0 past Dn)
+  float wd0 = 0.f, wd1 = 0.f;
+  if (ef.lin_w_dense != nullptr) {
+    const float a0 = ef.lin_w_dense[sub < Dn ? sub : 0], a1 = ef.lin_w_dense[sub + 8 < Dn ? sub + 8 : 0];
+    wd0 = sub < Dn ? a0 : 0.f;
+    wd1 = sub + 8 < Dn ? a1 : 0.f;
+  }
   for (int64_t tile = tile0; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
     const int64_t ex0 = tile * 32;
     if (tile != tile0) load_rows(ex0, 0, rows);
+    // the head's label of example c (MFMA-phase lane role), requested here: behind the chunk loop it was an
+    // exposed round trip in every wave's epilogue
+    float ty_pf = 0.f;
+    if constexpr (TAIL) {
+      int64_t bq = ex0 + c;
+      bq = bq < B ? bq : B - 1;
+      ty_pf = tl.y ? (float)tl.y[bq] : tl.y_f[bq];
+    }
     // dense inputs of this lane's examples: columns FD + sub + 8 i (i = 0, 1) of example 8 eg + ex_l
     float dv[4][2];
 #pragma unroll
@@ -556,6 +584,13 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void embed_mlp_fwd_kernel(
         load_rows(ex0, hc + 2 < nhc ? hc + 2 : hc + 1, rows);
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef RM_EMF_STAMP
+      {
+        const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_nop 0" ::"v"(vc[0].x), "v"(vc[7].w));  // wait for this half chunk's rows
+        et_wait += __builtin_amdgcn_s_memrealtime() - w0;
+      }
+#endif
       // FM / linear sums, E stores, x values to LDS - without per-element lane predicates (`if (f < F) /
       // if (emb) / if (valid)` per value compiled to three exec-mask branches per row): every lane adds every
       // value (only the embedding lanes' S / ss and the side lane's y1 / lin are ever read), E is stored
@@ -642,6 +677,9 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void embed_mlp_fwd_kernel(
       half(hc, vA, vB);
       half(hc + 1, vB, vA);
     }
+#ifdef RM_EMF_STAMP
+    if (tile == tile0) et2 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- FM second order + bias sum, linear term (rm_embed_fwd's arithmetic and order)
 #pragma unroll
     for (int eg = 0; eg < 4; ++eg) {
@@ -654,13 +692,11 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void embed_mlp_fwd_kernel(
       float ls = rm_group_sum<8>(side ? lin[eg] : 0.f);
       const float fmv = (ef.want_bias ? ys : 0.f) + 0.5f * part;
       float lv = ef.want_lin ? ls : 0.f;
-      if (ef.lin_w_dense != nullptr) {
-        // (serial over j like rm_embed_fwd, so that the sums are bit-identical: lane sub == 0 does it)
-        if (sub == 0) {
-          const int64_t bq = valid ? b : B - 1;
-          for (int j = 0; j < Dn; ++j) lv += ef.dense[bq * Dn + j] * ef.lin_w_dense[j];
-        }
-      }
+      // the linear term's dense part from the dense values this lane already holds (columns sub and sub + 8)
+      // and a group sum.  (rm_embed_fwd walks j = 0 .. Dn - 1 serially with two loads per step; done here
+      // that way - for bit-identical sums - it cost ~8 of the 14 us every wave spends behind its chunk loop,
+      // tools/probe/emf_stamps.py.  The order of the adds differs: lin_logit agrees to 1e-6, not bitwise.)
+      if (ef.lin_w_dense != nullptr) lv += rm_group_sum<8>(dv[eg][0] * wd0 + dv[eg][1] * wd1);
       if (ef.lin_w0 != nullptr) lv += ef.lin_w0[0];
       if (valid && sub == 0) {
         if (ef.fm_logit != nullptr) ef.fm_logit[b] = fmv;
@@ -675,12 +711,11 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void embed_mlp_fwd_kernel(
     const bool valid = b < B;
     float ta = 0.f, tb = 0.f, ty = 0.f;
     if constexpr (TAIL) {
-      const int64_t bq = valid ? b : B - 1;
       // logit_a / logit_b name the buffers this kernel has just written (lin_logit / fm_logit, in either
       // order) or are NULL: take the values from LDS instead of reading them back
       ta = tl.logit_a == nullptr ? 0.f : (tl.logit_a == ef.lin_logit ? xs[2 * c] : xs[2 * c + 1]);
       tb = tl.logit_b == nullptr ? 0.f : (tl.logit_b == ef.lin_logit ? xs[2 * c] : xs[2 * c + 1]);
-      ty = tl.y ? (float)tl.y[bq] : tl.y_f[bq];
+      ty = ty_pf;
     }
     float hv[16];
     float hl[TAIL ? NL : 1][16];
@@ -760,7 +795,21 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void embed_mlp_fwd_kernel(
       }
     }
   }
+#ifdef RM_EMF_STAMP
+  if (lane == 0 && blockIdx.x < 256) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long *o = rm_emf_stamp_buf + 8 * (blockIdx.x * 8 + wave);
+    o[0] = et1 - et0; o[1] = et2 - et1; o[2] = __builtin_amdgcn_s_memrealtime() - et2; o[3] = et_wait; o[4] = et0;
+  }
+#endif
 }
+#ifdef RM_EMF_STAMP
+}  // namespace
+extern "C" int rm_debug_emf_stamps(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rm_emf_stamp_buf), sizeof(unsigned long long) * n);
+}
+namespace {
+#endif
 
 // ---------------------------------------------------------------------------
 // backward: dh chain in registers, dX (+ FM term) -> d_rows, dW0 accumulated on the MFMA.

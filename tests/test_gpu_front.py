@@ -1,7 +1,7 @@
 """rm_embed_mlp_fwd (gather + FM + linear + skinny MLP + head in one kernel) against the two-kernel path
 (rm_embed_fwd + rm_mlp_fwd) it replaces in the DeepFM engine, and against the CPU oracle.  The gathered
-values, FM sums and linear term follow the same arithmetic in the same order: E, fm_sum, fm_logit and
-lin_logit must be BIT-identical (fm_logit's sum of squares may contract differently: 1e-6); the MLP's layer 0 accumulates in the same k order per accumulator, so the
+values and FM sums follow the same arithmetic in the same order: E and fm_sum must be BIT-identical, lin_logit
+and fm_logit agree to 1e-6 (the linear term's dense part and the sum of squares are added in another order); the MLP's layer 0 accumulates in the same k order per accumulator, so the
 logits are held to 1e-6 and the gradients to the parity tolerance."""
 import pytest
 import torch
@@ -36,7 +36,7 @@ def test_one_kernel_front_equals_the_two_kernel_path_and_the_oracle(hip_lib, cas
     torch.cuda.synchronize()
     assert e1._front_ok is True and getattr(e2, "_front_ok", None) is None
     assert torch.equal(e1.E, e2.E)
-    assert torch.equal(e1.lin_logit, e2.lin_logit)
+    _close(e1.lin_logit, e2.lin_logit, rtol=0, atol=1e-6, what="lin_logit vs two kernels")  # (dense part summed in another order)
     if use_fm:
         assert torch.equal(e1.fm_sum, e2.fm_sum)
         _close(e1.fm_logit, e2.fm_logit, rtol=0, atol=1e-6, what="fm_logit vs two kernels")  # (sum of squares: contraction)
