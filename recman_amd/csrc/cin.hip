@@ -891,12 +891,13 @@ DwPlan cin_dw_plan(int Kp, int64_t chunks_total, int target_blocks) {
     if (t > kDWW * kKT) t = kDWW * kKT;
     int per_simd[4] = {0, 0, 0, 0};
     for (int i = 0; i < t; ++i) per_simd[(i % kDWW) % 4]++;
-    // cost of one row chunk for this group, in MFMA tile-units per SIMD; never below 2: a
-    // chunk's staging (global loads, transposed LDS writes, two barriers) takes about as
-    // long as two tile-units, so lighter blocks are staging-bound (measured: weighting a
-    // 1-unit group as 1 made its blocks the critical path, 4.5 -> 6.1 ms)
-    u[g] = 2;
-    for (int q = 0; q < 4; ++q) u[g] = per_simd[q] > u[g] ? per_simd[q] : u[g];
+    // cost of one row chunk for this group, in hundredths of an MFMA tile-unit per SIMD; never below
+    // 1.56: a chunk's staging (global loads, transposed LDS writes, two barriers) keeps lighter blocks
+    // staging-bound (weighting a 1-unit group as 1 made its blocks the critical path, 4.5 -> 6.1 ms; as 2,
+    // its blocks finished 22 % early: per-block timestamps at H = 64, tools/probe/cin_dw_stamps.py -
+    // 6.61 us per chunk against 17.0 us for a 4-unit group)
+    u[g] = 156;
+    for (int q = 0; q < 4; ++q) u[g] = per_simd[q] * 100 > u[g] ? per_simd[q] * 100 : u[g];
     usum += u[g];
   }
   p.Smax = 0;
@@ -913,6 +914,9 @@ DwPlan cin_dw_plan(int Kp, int64_t chunks_total, int target_blocks) {
   }
   return p;
 }
+#ifdef RM_CIN_STAMP
+__device__ unsigned long long rm_cin_dw_stamp_buf[4 * 1024];
+#endif
 template <int NT>
 __global__ __launch_bounds__(512) void cin_dw_kernel(
     const float *__restrict__ X0, const float *__restrict__ Xk, int64_t xk_bstride,
@@ -928,6 +932,9 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(
   float *XkT = X0T + kRC * ld0;      // [64][ldk]
   float *dMs = XkT + kRC * ldk;      // [64][Np], n = nt*32+cc stored at cc*NT+nt
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+#ifdef RM_CIN_STAMP
+  const unsigned long long dwt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // split-major block order: the groups of one row range run side by side and share the
   // staged rows through L2 / Infinity Cache (group-major order re-read them from HBM)
   int group = 0, split = 0;
@@ -1091,7 +1098,22 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(
         part[((int64_t)split * Kp + kp) * Np + nt * 32 + c] = acc[q][nt][r];
       }
   }
+#ifdef RM_CIN_STAMP
+  if (tid == 0 && blockIdx.x < 1024) {
+    rm_cin_dw_stamp_buf[4 * blockIdx.x] = dwt0;
+    rm_cin_dw_stamp_buf[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    rm_cin_dw_stamp_buf[4 * blockIdx.x + 2] = group;
+    rm_cin_dw_stamp_buf[4 * blockIdx.x + 3] = chunks_per_split;
+  }
+#endif
 }
+#ifdef RM_CIN_STAMP
+}  // namespace
+extern "C" int rm_debug_cin_dw_stamps(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rm_cin_dw_stamp_buf), sizeof(unsigned long long) * n);
+}
+namespace {
+#endif
 
 size_t cin_dw_smem(int m, int H, int NT) {
   return (size_t)(kRC * (((m + 1) | 1) + (cin_He(H) | 1) + 32 * NT)) * sizeof(float);
