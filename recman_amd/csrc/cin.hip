@@ -559,19 +559,31 @@ __global__ __launch_bounds__(ROWS * 2) void cin_dx_kernel(
   const int D4 = D / 4;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int t = tid; t < epb * m * D4; t += NTHR) {
-    const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
-    const int64_t b = b0 + bl;
-    const float4 v = b < B ? *reinterpret_cast<const float4 *>(X0 + (b * m + i) * D + 4 * d4) : z4;
-    *reinterpret_cast<float4 *>(X0s + i * kRowsX + bl * D + 4 * d4) = v;
-  }
-  for (int t = tid; t < epb * Hp * D4; t += NTHR) {
-    const int d4 = t % D4, j = (t / D4) % Hp, bl = t / (D4 * Hp);
-    const int64_t b = b0 + bl;
-    const float4 v = (b < B && j < H)
-        ? *reinterpret_cast<const float4 *>(Xk + b * xk_bstride + (int64_t)j * D + 4 * d4) : z4;
-    *reinterpret_cast<float4 *>(Xks + j * kRowsX + bl * D + 4 * d4) = v;
-  }
+  cin_stage<NTHR, 4>(
+      epb * m * D4, tid,
+      [&](int t) {
+        const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+        const int64_t b = b0 + bl;
+        const float4 v = *reinterpret_cast<const float4 *>(X0 + ((b < B ? b : B - 1) * m + i) * D + 4 * d4);
+        return b < B ? v : z4;
+      },
+      [&](int t) {
+        const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+        return X0s + i * kRowsX + bl * D + 4 * d4;
+      });
+  cin_stage<NTHR, 8>(
+      epb * Hp * D4, tid,
+      [&](int t) {
+        const int d4 = t % D4, j = (t / D4) % Hp, bl = t / (D4 * Hp);
+        const int64_t b = b0 + bl;
+        const float4 v = *reinterpret_cast<const float4 *>(Xk + (b < B ? b : B - 1) * xk_bstride +
+                                                           (int64_t)(j < H ? j : H - 1) * D + 4 * d4);
+        return (b < B && j < H) ? v : z4;
+      },
+      [&](int t) {
+        const int d4 = t % D4, j = (t / D4) % Hp, bl = t / (D4 * Hp);
+        return Xks + j * kRowsX + bl * D + 4 * d4;
+      });
   // the lane's own dM row, in MFMA B-operand order: step s=4u+q <-> n = 8u + 4h + q
   const int prow = wave * 32 + c;
   const int64_t pg = b0 * D + prow;  // global row
