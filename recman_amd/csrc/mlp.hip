@@ -1061,10 +1061,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
   // on every tile's critical path: profiles/r01_p9_mlp_bwd.md.)
   float4 dn[4];
   float gn;
-  // D == 16 (block-uniform): the tile's S rows are prefetched with them - lane (c, h) holds pieces 2h and
-  // 2h + 1 of example c's S - and g*S goes to LDS from registers.  (The generic staging loop below loads
-  // g and S and stores g*S inside the tile: two exposed round trips per tile on every wave; with all x
-  // loads, MFMAs and stores compiled out the kernel still took 30 of its 75 us, profiles/r02_front_fusion.md.)
+  // D == 16 (block-uniform): the tile's S rows are prefetched with them - lane (c, h) holds S[c][4h .. 4h+3]
+  // and S[c][8+4h .. 8+4h+3], exactly the columns (k mod 16) of the 16 dX values it gets from the MFMA - and the
+  // FM term g (S - E) is applied in the accumulator layout, from registers: no g*S image in LDS, no second
+  // LDS read per stored piece (the epilogue was the largest part of a k-tile: 15 of a wave's 57 us,
+  // tools/probe/bwd_stamps.py).  (The generic staging loop below loads g and S and stores g*S inside the
+  // tile: two exposed round trips per tile on every wave.)
   const bool s_pf = s_lds && D == 16;
   float4 sn0 = make_float4(0.f, 0.f, 0.f, 0.f), sn1 = sn0;
   {
@@ -1075,8 +1077,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
     for (int gq = 0; gq < 4; ++gq)
       dn[gq] = *reinterpret_cast<const float4 *>(dh0 + bn * 32 + 8 * gq + 4 * h);
     if (s_pf) {
-      sn0 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 8 * h);
-      sn1 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 8 * h + 4);
+      sn0 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 4 * h);
+      sn1 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 8 + 4 * h);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -1100,10 +1102,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
       dh[4 * gq + 0] = dn[gq].x; dh[4 * gq + 1] = dn[gq].y;
       dh[4 * gq + 2] = dn[gq].z; dh[4 * gq + 3] = dn[gq].w;
     }
-    if (s_pf) {  // g*S of this tile from the prefetched registers (rows past B: gb = 0)
-      *reinterpret_cast<float4 *>(gS + c * 16 + 8 * h) = make_float4(gb * sn0.x, gb * sn0.y, gb * sn0.z, gb * sn0.w);
-      *reinterpret_cast<float4 *>(gS + c * 16 + 8 * h + 4) = make_float4(gb * sn1.x, gb * sn1.y, gb * sn1.z, gb * sn1.w);
-    }
+    const float4 sa = sn0, sb = sn1;  // this tile's S pieces (the next tile's are requested below)
     {  // next tile's values (the last tile re-loads its own)
       int64_t bn = ex_next + c;
       bn = bn < B ? bn : B - 1;
@@ -1112,8 +1111,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
       for (int gq = 0; gq < 4; ++gq)
         dn[gq] = *reinterpret_cast<const float4 *>(dh0 + bn * 32 + 8 * gq + 4 * h);
       if (s_pf) {
-        sn0 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 8 * h);
-        sn1 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 8 * h + 4);
+        sn0 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 4 * h);
+        sn1 = *reinterpret_cast<const float4 *>(fm_sum + bn * 16 + 8 + 4 * h);
       }
     }
     if (s_lds && !s_pf) {
@@ -1184,7 +1183,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
           float4 o = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
           if (fm) {
             const float4 e = *p4;
-            o.x -= gb * e.x; o.y -= gb * e.y; o.z -= gb * e.z; o.w -= gb * e.w;
+            if (s_pf) {  // + g (S - E): column (8 gq + 4 h + e) mod 16 of S
+              const float4 sv = (gq & 1) ? sb : sa;
+              o.x += gb * (sv.x - e.x); o.y += gb * (sv.y - e.y); o.z += gb * (sv.z - e.z); o.w += gb * (sv.w - e.w);
+            } else {
+              o.x -= gb * e.x; o.y -= gb * e.y; o.z -= gb * e.z; o.w -= gb * e.w;
+            }
           }
           *p4 = o;
         }
@@ -1196,8 +1200,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(
             const int row = (lane >> 3) + 8 * q;
             const int64_t br = ex0 + row;
             float4 o = *reinterpret_cast<const float4 *>(xb + row * kLDT + 4 * piece);
-            const float4 s4 = *reinterpret_cast<const float4 *>(gS + row * D + (k % D));
-            o.x += s4.x; o.y += s4.y; o.z += s4.z; o.w += s4.w;
+            if (!s_pf) {
+              const float4 s4 = *reinterpret_cast<const float4 *>(gS + row * D + (k % D));
+              o.x += s4.x; o.y += s4.y; o.z += s4.z; o.w += s4.w;
+            }
             if (NT_OUT) {
               if (br < B && k < FD) store4_stream(d_rows + br * FD + k, o);
             } else {
