@@ -207,7 +207,8 @@ int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int NL, const i
 /* Gather + FM + linear term + skinny MLP (+ training head) in ONE kernel: rm_embed_fwd followed by rm_mlp_fwd
  * on E without the round trip of x through HBM (FeatEmbeddingLayer + FMLayer + LinearLayer + DNNCombiner + DNN of
  * DeepFM._init_graph, recman/tf/core/DeepFM.py:96-150 over layers.py:238-261,457-478,330-347,494-501,576-609).
- * Fused-row layout only: table rows [16 embedding | bias | linear weight | ...] with table_ld = 32, D = 16;
+ * Fused-row layout only: table rows [16 embedding | bias | linear weight | ...] with table_ld = 32 (or 20: the
+ * rows a row-sharded table exchanges, idx = positions in the received buffer, field_off = 0), D = 16;
  * Dn <= 16, 16 F + Dn <= 448, hidden widths <= 32 (rm_embed_mlp_fwd_supported).  want_bias / want_lin: the FM
  * bias sum / the sparse part of the linear term are wanted; lin_w_dense [Dn] (NULL: the linear term has no
  * dense part), lin_w0 [1] or NULL; xd [B,Dn] feeds the MLP (and the linear term).  Outputs as the two calls':

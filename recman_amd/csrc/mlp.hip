@@ -409,7 +409,8 @@ __device__ unsigned long long rm_emf_stamp_buf[8 * 8 * 256];
 #endif
 struct EmbFront {
   const int64_t *idx;        // [B, F]
-  const float *table;        // fused rows, stride 32 floats
+  const float *table;        // fused rows [16 emb | bias | lin | ...], stride table_ld floats (32, or 20 for exchanged rows)
+  int table_ld;
   const int64_t *field_off;  // [F]
   const float *lin_w_dense, *lin_w0, *dense;  // linear term's dense part (NULL: none); dense = xd
   int F, want_bias, want_lin;
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(64 * RM_MLP_FWD_WAVES) void embed_mlp_fwd_kernel(
       if (emb || side) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const float *p = ef.table + rows[q] * 32 + sub * 4;
+          const float *p = ef.table + rows[q] * ef.table_ld + sub * 4;
           v[q] = NT ? load4_stream(p) : *reinterpret_cast<const float4 *>(p);
         }
       }
@@ -1527,7 +1528,9 @@ extern "C" int rm_mlp_fwd(const float *xe, const float *xd, int FD, int Dn, int 
 }
 
 extern "C" int rm_embed_mlp_fwd_supported(int F, int D, int64_t table_ld, int Dn, int NL, const int *H) {
-  if (D != 16 || table_ld != 32 || F < 1 || Dn < 0 || Dn > 16 || 16 * F + Dn > 448) return 0;
+  // rows of 32 floats (the engines' table: one 128-byte line per row) or of D + 4 = 20 (the rows a row-sharded
+  // table exchanges, recman_amd/dist.py: idx = positions in the received buffer, field_off = 0)
+  if (D != 16 || (table_ld != 32 && table_ld != 20) || F < 1 || Dn < 0 || Dn > 16 || 16 * F + Dn > 448) return 0;
   return rm_mlp_supported(16 * F, Dn, NL, H);
 }
 
@@ -1540,7 +1543,7 @@ extern "C" int rm_embed_mlp_fwd(const int64_t *idx, const float *table, int64_t 
                                 float *const *h_out, float *logit, const rm_mlp_tail *tail,
                                 rm_stream_t stream) {
   RM_REQUIRE(H && rm_embed_mlp_fwd_supported(F, D, table_ld, Dn, NL, H),
-             "rm_embed_mlp_fwd: needs D = 16, table_ld = 32, Dn <= 16, 16 F + Dn <= 448 and hidden widths <= 32");
+             "rm_embed_mlp_fwd: needs D = 16, table_ld = 32 or 20, Dn <= 16, 16 F + Dn <= 448 and hidden widths <= 32");
   int rc = mlp_check("rm_embed_mlp_fwd", 16 * F, Dn, NL, H);
   if (rc != RM_OK) return rc;
   RM_REQUIRE(B >= 0, "rm_embed_mlp_fwd: B < 0");
@@ -1564,7 +1567,7 @@ extern "C" int rm_embed_mlp_fwd(const int64_t *idx, const float *table, int64_t 
     w.b[l] = l < NL ? bias[l] : nullptr;
     w.H[l] = l < NL ? H[l] : 0;
   }
-  const EmbFront ef{idx, table, field_off, lin_w_dense, lin_w0, xd, F, want_bias, want_lin, E, fm_sum, fm_logit, lin_logit};
+  const EmbFront ef{idx, table, (int)table_ld, field_off, lin_w_dense, lin_w0, xd, F, want_bias, want_lin, E, fm_sum, fm_logit, lin_logit};
   const size_t smem = mlp_fwd_smem(16 * F + Dn, NL, tail != nullptr);
   const int64_t ntiles = (B + 31) / 32;
   dim3 grid((unsigned)rm_grid_cap((ntiles + RM_MLP_FWD_WAVES - 1) / RM_MLP_FWD_WAVES, 256));

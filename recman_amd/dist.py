@@ -439,15 +439,21 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                                                        for _ in range(self.micro_batches - 1)]
 
         def _front_fused(self, m, lin_w):
-            return False  # the rows arrive through the exchange: no local table for rm_embed_mlp_fwd to gather from
+            # the one-kernel front gathers from the RECEIVED rows (stride D + 4) through their positions;
+            # scratch-row features keep the two-kernel path (their pooled rows are built in between)
+            return not self.mv_fields and base._front_fused(self, m, lin_w)
 
-        def _embed(self, idx, dense, want_fm, masks, lin_w=None):
-            from . import ops
+        def _front_ld(self):
+            return self.D + PAD
 
-            m = masks or {}
-            fm_masks = m.get("fm", (None, None))
+        def _front_table(self, idx):
+            pos = self._lookup(idx)
+            return pos, self.rows, self._zoff, self.D + PAD, False
+
+        def _lookup(self, idx):
+            """Runs / finishes this (micro-)batch's row exchange; sets self.ex / self.rows and returns pos [B, F]:
+            occurrence (b, f) is row pos[b, f] of self.rows."""
             B = idx.shape[0]
-            # rows arrive owner-bucketed; the gather kernel reads occurrence (b,f) at row pos[b,f]
             if self.mv_fields:
                 pos = self._lookup_mv(idx)
             elif self._slot is not None:      # captured segment: static buffers, exchange done by the caller
@@ -461,6 +467,16 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 self.rows, self.ex = self.st.lookup(idx, self.field_off)
                 pos = self.ex.pos.view(B, self.F)
             self._pos = pos
+            return pos
+
+        def _embed(self, idx, dense, want_fm, masks, lin_w=None):
+            from . import ops
+
+            m = masks or {}
+            fm_masks = m.get("fm", (None, None))
+            B = idx.shape[0]
+            # rows arrive owner-bucketed; the gather kernel reads occurrence (b,f) at row pos[b,f]
+            pos = self._lookup(idx)
             W = self.D + PAD
             flat = self.rows.view(-1)
             ops.embed_fwd(

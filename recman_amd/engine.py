@@ -877,8 +877,15 @@ class DeepFMEngine(Engine):
             return False
         if getattr(self, "_front_ok", None) is None:
             self._front_ok = bool(self.mlp.fused_ok and ops.embed_mlp_fwd_supported(
-                self.F, self.D, self.LD, self.Dn, self.mlp.hidden))
+                self.F, self.D, self._front_ld(), self.Dn, self.mlp.hidden))
         return self._front_ok
+
+    def _front_ld(self):
+        return self.LD
+
+    def _front_table(self, idx):
+        """(ids, rows, field offsets, row stride, non-temporal row loads) the one-kernel front gathers from."""
+        return idx, self.rows, self.field_off, self.LD, self.hp.get("table_row_reuse", "stream") == "stream"
 
     def _front_fwd(self, idx, dense, branches):
         mlp, p = self.mlp, self.params
@@ -891,15 +898,15 @@ class DeepFMEngine(Engine):
         mlp.tail = ops.mlp_tail(B, dh=mlp.dhb, **head) if head is not None else None
         mlp.head_done = head is not None
         pre = mlp.prefix
+        ids, rows, foff, ld, stream_rows = self._front_table(idx)
         ops.embed_mlp_fwd(
-            idx, self.rows, self.field_off, self.D, self.LD, dense if self.Dn else None,
+            ids, rows, foff, self.D, ld, dense if self.Dn else None,
             [p[f"{pre}dnn_layer_{i}_weights"] for i in range(n)], [p[f"{pre}dnn_layer_{i}_bias"] for i in range(n)],
             p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"], mlp.act, self.E, mlp.hb, mlp.out.view(B),
             want_bias=self.use_fm and self.use_bias_tables, want_lin=True,
             lin_w_dense=self.linear_w_dense if self.Dn else None, lin_w0=p["linear_w0"],
             fm_sum=self.fm_sum if self.use_fm else None, fm_logit=self.fm_logit if self.use_fm else None,
-            lin_logit=self.lin_logit, stream_rows=self.hp.get("table_row_reuse", "stream") == "stream",
-            tail=mlp.tail)
+            lin_logit=self.lin_logit, stream_rows=stream_rows, tail=mlp.tail)
         self._head_done = mlp.head_done
         return mlp.out.view(B)
 
