@@ -205,12 +205,6 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
     }
     return make_float4(t[0], t[1], t[2], t[3]);
   };
-  auto load_group = [&](int g, int i) -> float4 {  // prologue only (waits right away)
-    if (g < gfast) return load_fast(g, i);
-    float4 x1, x2;
-    load_slow(g, i, x1, x2);
-    return pick_slow(g, x1, x2);
-  };
   const int a_lds = arow * ALD + 4 * piece;  // float4 slot i: + 32 i rows
 
   // prologue: weight chunk 0 and A group 0 to LDS
@@ -220,8 +214,22 @@ __device__ __forceinline__ void nn_wave(const NNArgs &a, float *Ws, int tid, int
   for (int q = 0; q < WQ; ++q)
     *reinterpret_cast<float4 *>(Ws + (tid + q * kNNThreads) * 4) =
         *reinterpret_cast<const float4 *>(Wp + (tid + q * kNNThreads) * 4);
+  if (gfast > 0) {
+    // (all four loads before the first LDS write: through load_group's run-time choice they compiled to
+    // load -> s_waitcnt vmcnt(0) -> ds_write four times over - four dependent HBM round trips, most of the
+    // 8.7 us a block spent in its prologue, tools/probe/nn_stamps.py)
+    const float4 t0 = load_fast(0, 0), t1 = load_fast(0, 1), t2 = load_fast(0, 2), t3 = load_fast(0, 3);
+    *reinterpret_cast<float4 *>(As + a_lds) = t0;
+    *reinterpret_cast<float4 *>(As + a_lds + 32 * ALD) = t1;
+    *reinterpret_cast<float4 *>(As + a_lds + 64 * ALD) = t2;
+    *reinterpret_cast<float4 *>(As + a_lds + 96 * ALD) = t3;
+  } else {
+    float4 x1[4], x2[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(As + a_lds + 32 * i * ALD) = load_group(0, i);
+    for (int i = 0; i < 4; ++i) load_slow(0, i, x1[i], x2[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(As + a_lds + 32 * i * ALD) = pick_slow(0, x1[i], x2[i]);
+  }
   __syncthreads();
   RM_STAMP(1);
 #ifdef RM_NN_STAMP
