@@ -232,6 +232,33 @@ int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const i
                float *d_w0_out, float *d_xd_wsum, float *d_g_sum, float *workspace,
                const rm_mlp_tail *tail, int flags, rm_stream_t stream);
 
+/* DeepFM's WHOLE training step in one kernel + one finishing launch: DeepFM._init_graph forward and the gradient
+ * of every variable (recman/tf/core/DeepFM.py:107-180; FeatEmbeddingLayer layers.py:238-261, LinearLayer :330-347,
+ * FMLayer :457-478, DNN :576-609, PredictionLayer :796-808, create_loss utils.py:192-198) - what rm_embed_mlp_fwd
+ * followed by rm_mlp_bwd compute, without E, S, h_l or dh_l ever reaching HBM (every DeepFM gradient except the
+ * parameter reductions is local to the example).  Shapes: fused-row table [R, table_ld] (rows [16 embedding | bias
+ * entry | linear weight | ...], table_ld a multiple of 4, >= 20), D = 16, F <= 26, Dn <= 16, NL = 2 hidden layers
+ * of width <= 32 (rm_deepfm_step_supported); FM, bias tables, linear term and DNN all on, no dropout masks - the
+ * callers use the separate entry points for anything else.
+ * In: idx [B,F] int64, field_off [F], dense [B,Dn] (NULL when Dn = 0), labels y (int64) or y_f (float),
+ *   W[l] / bias[l] (l < 2), w_out [H1], w0_out [1], lin_w_dense [Dn], lin_w0 [1], act, task (0 classification,
+ *   1 regression), grad_scale (dlogit multiplier: micro-batches / ranks; 1 = plain mean over B).
+ * Out: d_rows [B,F,16] = dLoss/dE (IndexedSlices form, duplicates not merged), logit / pred / dlogit [B] (dlogit =
+ *   dLoss/dlogit: the per-occurrence gradient of the bias-table and sparse linear entries), loss [1] (mean over B,
+ *   no l2 terms), dW[l] / db[l] (db may be NULL), d_w_out [H1], d_w0_out [1], d_lin_w_dense [Dn], d_lin_w0 [1].
+ * workspace: rm_deepfm_step_workspace(F, Dn) floats.  flags: bit 0 = non-temporal row loads
+ *   (RM_EMBED_STREAM_ROWS), bit 1 = non-temporal d_rows stores (only when nothing re-reads them soon).
+ * Deterministic (fixed summation orders, no float atomics). */
+int rm_deepfm_step_supported(int F, int D, int64_t table_ld, int Dn, int NL, const int *H);
+int64_t rm_deepfm_step_workspace(int F, int Dn);
+int rm_deepfm_step(const int64_t *idx, const float *table, int64_t table_ld, const int64_t *field_off,
+                   const float *dense, int Dn, const int64_t *y, const float *y_f, int64_t B, int F, int D,
+                   int NL, const int *H, const float *const *W, const float *const *bias, const float *w_out,
+                   const float *w0_out, const float *lin_w_dense, const float *lin_w0, int act, int task,
+                   float grad_scale, float *d_rows, float *logit, float *pred, float *dlogit, float *loss,
+                   float *const *dW, float *const *db, float *d_w_out, float *d_w0_out, float *d_lin_w_dense,
+                   float *d_lin_w0, float *workspace, int flags, rm_stream_t stream);
+
 /* Epilogues of the library-GEMM DNN path (wide hidden layers, layers.py:593-601):
  * rm_bias_act: x[b,j] = act(x[b,j] + bias[j]) in place (bias may be NULL);
  * rm_act_bwd:  da[b,j] *= act'(a[b,j]) in place, act' read off the post-activation a. */

@@ -48,6 +48,9 @@ SIGNATURES = {
                          c_int, P, P, P, P, P, c_int, P, P, P, P],
     "rm_mlp_bwd": [P, P, c_int, c_int, c_int, P, P, P, c_int, I64, P, P, P, c_int, P, P, P, P, P, P,
                    P, P, P, P, c_int, P],
+    "rm_deepfm_step_supported": [c_int, c_int, I64, c_int, c_int, P],
+    "rm_deepfm_step": [P, P, I64, P, P, c_int, P, P, I64, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, c_int,
+                       c_float, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P],
     "rm_bias_act": [P, P, I64, c_int, c_int, P],
     "rm_act_bwd": [P, P, I64, c_int, c_int, P],
     "rm_outer_actgrad": [P, P, P, I64, c_int, c_int, P, P],
@@ -84,6 +87,7 @@ SIGNATURES_I64 = {
     "rm_cin_filter_workspace": [c_int, c_int, c_int],
     "rm_cin_bwd_workspace": [I64, c_int, c_int, c_int, c_int],
     "rm_mlp_bwd_workspace": [c_int, c_int],
+    "rm_deepfm_step_workspace": [c_int, c_int],
     "rm_outer_actgrad_sums_workspace": [I64, c_int],
     "rm_shard_route_workspace": [c_int],
     "rm_dense_filter_workspace": [c_int, c_int],

@@ -10,6 +10,7 @@
 // registers.  x = [xe | xd] (never concatenated in memory) is staged per wave through a
 // private LDS chunk of 32 examples x 64 k (full 256-byte lines from HBM); W0 sits in LDS.
 #include "rm_common.h"
+#include "mlp_internal.h"
 
 namespace {
 
@@ -1301,8 +1302,8 @@ __device__ __forceinline__ void mlp_dw0_reduce_body(float (*sm)[64], int blk,
 // Every remaining (tiny) gradient of the MLP in ONE pass over h_l / dh_l / g:
 //   dW_l = h_{l-1}^T dh_l (l >= 1), db_l = colsum(dh_l), d w_out = h_last^T g, d w0 = sum g.
 // Per-block partial layout: [2 x 1024 dW_l | 3 x 32 db_l | 32 d w_out | 1 sum g (+31 pad) | 32 g^T xd].
-constexpr int kSgDense = 2 * 1024 + 3 * 32 + 32 + 32;  // offset of the g^T xd slots
-constexpr int kSgStride = kSgDense + 32;
+constexpr int kSgDense = kRmSgDense;  // offset of the g^T xd slots (mlp_internal.h)
+constexpr int kSgStride = kRmSgStride;
 // Stage 1 on the matrix pipe (the first version was a VALU kernel behind LDS staging, 20 us): a wave walks
 // 32-example chunks, loads h_l / dh_l straight in MFMA operand layout (lane = unit, the two lane
 // halves = the two examples of a k-step: coalesced 128-byte rows, no LDS staging),
@@ -1471,6 +1472,30 @@ int mlp_check(const char *fn, int FD, int Dn, int NL, const int *H) {
 }
 
 }  // namespace
+
+int rm_internal_mlp_finish(const float *dw0_part, int nslab, int K, int Kp, int H0, float *dW0, const float *sg_part,
+                           int nblk2, int NL, const int *H, float *const *dW, float *const *db, float *d_w_out,
+                           float *d_w0_out, float *d_xd_wsum, float *d_g_sum, int Dn, const float *loss_partial,
+                           int64_t n_loss, int64_t B, float *loss, hipStream_t st) {
+  SgOut o;
+  for (int l = 0; l < kMaxNL; ++l) {
+    o.dW[l] = (l >= 1 && l < NL && dW) ? dW[l] : nullptr;
+    o.db[l] = (l < NL && db) ? db[l] : nullptr;
+    o.H[l] = l < NL ? H[l] : 0;
+  }
+  o.dw_out = d_w_out;
+  o.dw0 = d_w0_out;
+  o.dxd = d_xd_wsum;
+  o.gsum = d_g_sum;
+  o.Dn = Dn;
+  const int n_dw0 = Kp * 32 / 64, n_sg = (kSgStride + 63) / 64;
+  const bool with_loss = loss != nullptr && loss_partial != nullptr;
+  hipLaunchKernelGGL(mlp_finish_kernel, dim3(n_dw0 + n_sg + (with_loss ? 1 : 0)), dim3(64 * kFinG), 0, st, dw0_part,
+                     nslab, K, Kp, H0, dW0, n_dw0, sg_part, nblk2, NL, o, n_sg, with_loss ? loss_partial : nullptr,
+                     n_loss, 1.0f / (float)B, with_loss ? loss : nullptr);
+  RM_CHECK_LAUNCH("rm_internal_mlp_finish");
+  return RM_OK;
+}
 
 extern "C" int rm_mlp_supported(int FD, int Dn, int NL, const int *H) {
   if (NL < 1 || NL > kMaxNL || FD % 4 != 0 || FD + Dn < 1 || FD + Dn > 448) return 0;

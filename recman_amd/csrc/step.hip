@@ -1,0 +1,652 @@
+// DeepFM's whole training step in ONE kernel (rm_deepfm_step): embedding gather, FM, linear term, the skinny MLP,
+// PredictionLayer + loss, and EVERY gradient of the step (row gradients d_rows, dlogit, dW0, dW1, biases, output
+// projection, the linear term's dense weights) - recman/tf/core/DeepFM.py:107-180 with layers.py:117-128,
+// 238-261 (gather), 281-347 (linear), 457-478 (FM), 576-609 (DNN), 796-808 (prediction), utils.py:192-198 (loss).
+//
+// Why one kernel: every gradient of DeepFM except the parameter reductions is local to the example, so E [B,F,D],
+// S, h_l and dh_l never need to reach HBM.  The two-kernel path (rm_embed_mlp_fwd + rm_mlp_bwd) moves 844 MB per
+// step at configs[1] (profiles/r02_deepfm_step_bytes.md); this one moves the rows in (one 128-byte line per lookup),
+// the row gradients out, and the ids / dense inputs / labels: ~350 MB.
+//
+// Structure (one 512-thread workgroup per CU, 16-example tiles, v_mfma_f32_16x16x4_f32):
+//  * waves 0..6 are WORKERS.  A worker owns up to 4 of the 27 "field slots" (26 embedding fields of 16 k each + the
+//    dense inputs as a 16-k pseudo-field), i.e. a k-slice of layer 0: it keeps its slices of W0 in registers in both
+//    operand layouts (forward and dX: 2 x 8 registers per slot), keeps its rows of dW0 in accumulators for the whole
+//    kernel (8 registers per slot), and ONLY EVER touches its own fields of x.  x never crosses waves; what does is
+//    small: the partial h0 of a tile (2 KB per worker) and the tile's dh0 / g / g*S (5.6 KB).
+//  * the rows arrive by LDS-DMA (global_load_lds_dwordx4 with a per-lane source address: one instruction = the 16
+//    examples of one field, 64 bytes each), straight into a ring of 4 tile buffers, three tiles ahead of their use:
+//    no register is held by a row in flight and ~100 KB of lines are in flight per CU.  Lane (example r, piece p)
+//    fetches slice p ^ (r >> 2) of its row, which makes every later ds_read_b128 of "slice q of example n"
+//    conflict-free (position q ^ (n >> 2)) without padding the 64-byte rows.
+//  * wave 7 is the HEAD: per tile it sums the 7 partial h0, adds the FM sums (it reads the whole x tile from LDS),
+//    runs layer 1, the output projection, the FM / linear logits, PredictionLayer, the loss term, dLoss/dlogit and
+//    the dh chain, publishes dh0 (two layouts), g and g*S for the workers' backward, and accumulates every small
+//    gradient (dW1 on the matrix pipe, db0, db1, d w_out, sum g, g^T xd) in registers.  It also turns the tile's
+//    ids into row numbers three tiles ahead (the workers' DMA addresses) and gathers the bias / linear entries.
+//  * one workgroup barrier per tile.  Segment s (between barriers s-1 and s): workers run backward(s-2),
+//    issue the DMA of tile s+2 into the buffer backward(s-2) has just freed, then forward(s); the head runs
+//    epilogue(s-1) meanwhile.  forward(s) -> [barrier] -> epilogue(s) -> [barrier] -> backward(s): the head's serial
+//    chain (32 dependent MFMAs + the loss) always overlaps the workers' matrix work of the neighbouring tiles.
+//  * per-block partial sums (dW0 slab, small gradients, loss) go to the same finishing launch as rm_mlp_bwd's
+//    (mlp_finish_kernel): fixed order, deterministic.
+#include "mlp_internal.h"
+#include "rm_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+constexpr int kWorkers = 7;   // waves 0..6; wave 7 is the head
+constexpr int kSlots = 4;     // field slots per worker
+constexpr int kXSlots = 27;   // 26 fields + the dense pseudo-field
+constexpr int kRing = 4;      // x tile buffers
+constexpr int kSlotB = 1024;  // 16 examples x 64 bytes
+constexpr int kXBufB = kXSlots * kSlotB;
+constexpr int kPartB = 2048;  // one worker's partial h0 of a tile: [2 unit halves][64 lanes][4]
+constexpr int kLDT = 36;      // row stride (floats) of the [example][unit] images
+// published per tile by the head: dh0 in B-operand layout | dh0 as [example][unit] | g*S | g
+constexpr int kPubDh = 0, kPubDT = 2048, kPubGS = kPubDT + 16 * kLDT * 4, kPubG = kPubGS + 1024, kPubB = kPubG + 256;
+// LDS map (bytes)
+constexpr int oX = 0;                                 // [kRing][27][1024]
+constexpr int oJunk = oX + kRing * kXBufB;            // sink of the dummy DMAs of empty slots
+constexpr int oPart = oJunk + 1024;                   // [2][7][2048]
+constexpr int oPub = oPart + 2 * kWorkers * kPartB;   // [2][kPubB]
+constexpr int oRow = oPub + 2 * kPubB;                // [2][27][16] row numbers (u32)
+constexpr int oHT = oRow + 2 * kXSlots * 64;          // [16][36] h0 as [example][unit]
+constexpr int oD1T = oHT + 16 * kLDT * 4;             // [16][36] dh1 as [example][unit]
+constexpr int oSide = oD1T + 16 * kLDT * 4;           // [8][16][2] (sum of bias entries, sum of linear entries)
+constexpr int oY = oSide + 8 * 16 * 2 * 4;            // [8][16] labels
+constexpr int kLdsBytes = oY + 8 * 16 * 4;
+static_assert(kLdsBytes <= 160 * 1024, "LDS map exceeds a CU");
+
+struct StepArgs {
+  const int64_t *idx, *field_off;
+  const char *table;
+  int64_t row_bytes;
+  const float *dense;
+  const int64_t *y;
+  const float *y_f;
+  const float *W0, *b0, *W1, *b1, *w_out, *w0_out, *lin_wd, *lin_w0;
+  int F, Dn, H0, H1, act, task, Kp;
+  float grad_scale;
+  int64_t B;
+  float *d_rows, *logit, *pred, *dlogit, *dW0_part, *sg_part, *loss_part;
+};
+
+__device__ __forceinline__ float actf(float v, int act) {
+  if (act == RM_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ float actg(float o, int act) {
+  if (act == RM_ACT_RELU) return o > 0.f ? 1.f : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return o > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+
+// field slot j of worker w: fields 7 j + w for j < 3; the last round skips worker 3, the head's SIMD partner
+// (27 slots over 7 workers: 4 4 4 3 4 4 4).  Slot field == F is the dense pseudo-field.
+__device__ __forceinline__ int slot_field(int w, int j) {
+  return j < 3 ? 7 * j + w : (w < 3 ? 21 + w : (w > 3 ? 20 + w : -1));
+}
+
+// v_mfma_f32_16x16x4_f32: lane (n = lane & 15, q = lane >> 4) supplies A[m = n][k = q] and B[k = q][n]; D[m = 4 q + i][n]
+// comes back in register i of lane (n, q).
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+
+// One LDS-DMA piece: lane l's 16 bytes at src land at LDS byte lds_dst + 16 l (lds_dst wave-uniform).  Invisible to
+// hipcc's s_waitcnt bookkeeping: the waits are the hand-counted WAIT_VM below.
+template <bool NT>
+__device__ __forceinline__ void glds16(const void *src, unsigned lds_dst) {
+  unsigned keep;
+  if (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+
+// waits until at most `younger` of this wave's vector-memory operations are outstanding (a multiple of 4 here)
+__device__ __forceinline__ void wait_vm(int younger) {
+  switch (younger) {
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+__device__ __forceinline__ float sum_q(float v) {  // over the 4 lanes (n, 0..3) of an example
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float sum_n(float v) {  // over the 16 lanes (0..15, q)
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------- worker
+template <bool NT, bool NT_OUT>
+__device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const unsigned lds0, const int w,
+                                            const int lane, const int T) {
+  const int n = lane & 15, q = lane >> 4;
+  const int F = a.F, H0 = a.H0, K = 16 * F + a.Dn;
+  int fld[kSlots];
+  bool sv[kSlots], sx[kSlots];  // slot in use; slot is an embedding field (has rows to fetch and a dX)
+  float w0f[kSlots][2][4];      // forward A operand: W0[kb + 4 q + ks][16 uh + n]
+  float w0x[kSlots][2][4];      // dX A operand:      W0[kb + n][16 uh + 4 q + i]
+  f32x4 dw[kSlots][2];          // dW0[kb + 4 q + i][16 uh + n]
+#pragma unroll
+  for (int j = 0; j < kSlots; ++j) {
+    const int f = slot_field(w, j);
+    sv[j] = f >= 0 && (f < F || (f == F && a.Dn > 0));
+    sx[j] = f >= 0 && f < F;
+    fld[j] = sv[j] ? f : 0;
+    const int kb = 16 * fld[j];
+#pragma unroll
+    for (int uh = 0; uh < 2; ++uh) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kf = kb + 4 * q + e, uf = 16 * uh + n;
+        const bool okf = sv[j] && kf < K && uf < H0;
+        const float vf = a.W0[okf ? (int64_t)kf * H0 + uf : 0];
+        w0f[j][uh][e] = okf ? vf : 0.f;
+        const int kx = kb + n, ux = 16 * uh + 4 * q + e;
+        const bool okx = sx[j] && kx < K && ux < H0;
+        const float vx = a.W0[okx ? (int64_t)kx * H0 + ux : 0];
+        w0x[j][uh][e] = okx ? vx : 0.f;
+      }
+      dw[j][uh] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const int64_t tstride = gridDim.x;
+
+  for (int s = -3; s <= T + 1; ++s) {
+    // ------------------------------------------------------------ backward of tile s - 2
+    if (s - 2 >= 0 && s - 2 < T) {
+      const int t = s - 2;
+      const int64_t ex0 = ((int64_t)blockIdx.x + t * tstride) * 16;
+      const char *pub = smem + oPub + (t & 1) * kPubB;
+      const char *xb = smem + oX + (t & 3) * kXBufB;
+      f32x4 dhB[2];
+      float dT[2][4];
+#pragma unroll
+      for (int uh = 0; uh < 2; ++uh) {
+        dhB[uh] = *reinterpret_cast<const f32x4 *>(pub + kPubDh + (uh * 64 + lane) * 16);
+#pragma unroll
+        for (int es = 0; es < 4; ++es)
+          dT[uh][es] = *reinterpret_cast<const float *>(pub + kPubDT + ((4 * es + q) * kLDT + 16 * uh + n) * 4);
+      }
+      const f32x4 gS = *reinterpret_cast<const f32x4 *>(pub + kPubGS + lane * 16);
+      const float g = *reinterpret_cast<const float *>(pub + kPubG + lane * 4);
+      const int64_t left = a.B - ex0;
+      const int rows_t = left < 16 ? (int)left : 16;
+      const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.d_rows + ex0 * F * 16, 0, rows_t * F * 64, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < kSlots; ++j) {
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+        int off = 0x7ffffff0;  // out of range: the store is dropped (every tile issues the same number of them)
+        if (sv[j]) {           // wave-uniform
+          const char *xs = xb + fld[j] * kSlotB;
+          float col[4];
+#pragma unroll
+          for (int es = 0; es < 4; ++es)  // x[example 4 es + q][k = n]: position (n >> 2) ^ es of that row
+            col[es] = *reinterpret_cast<const float *>(xs + (4 * es + q) * 64 + 16 * ((n >> 2) ^ es) + 4 * (n & 3));
+#pragma unroll
+          for (int es = 0; es < 4; ++es) {
+            dw[j][0] = mfma16(col[es], dT[0][es], dw[j][0]);
+            dw[j][1] = mfma16(col[es], dT[1][es], dw[j][1]);
+          }
+          if (sx[j]) {
+            const f32x4 e4 = *reinterpret_cast<const f32x4 *>(xs + n * 64 + 16 * (q ^ (n >> 2)));
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc = mfma16(w0x[j][uh][i], dhB[uh][i], acc);
+            // dLoss/dE = dX + g (S - E)   (FM second order, layers.py:468-476)
+            o.x = acc.x + (gS.x - g * e4.x);
+            o.y = acc.y + (gS.y - g * e4.y);
+            o.z = acc.z + (gS.z - g * e4.z);
+            o.w = acc.w + (gS.w - g * e4.w);
+            off = (n * F + fld[j]) * 64 + 16 * q;
+          }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, off, 0, NT_OUT ? 2 : 0);
+      }
+    }
+    // ------------------------------------------------------------ rows of tile s + 2 (into the buffer just freed)
+    if (s + 2 >= 0 && s + 2 < T) {
+      const int t = s + 2;
+      const unsigned *rowid = reinterpret_cast<const unsigned *>(smem + oRow + (t & 1) * kXSlots * 64);
+      const unsigned xdst = lds0 + oX + (t & 3) * kXBufB;
+      const int piece = 16 * ((lane & 3) ^ ((lane >> 4) & 3));
+#pragma unroll
+      for (int j = 0; j < kSlots; ++j) {
+        const char *src = a.table;
+        unsigned dst = lds0 + oJunk;
+        if (sx[j]) {
+          const unsigned rid = rowid[fld[j] * 16 + (lane >> 2)];
+          src = a.table + (int64_t)rid * a.row_bytes + piece;
+          dst = xdst + fld[j] * kSlotB;
+        }
+        glds16<NT>(src, dst);
+      }
+    }
+    // ------------------------------------------------------------ forward of tile s
+    if (s >= 0 && s < T) {
+      // the tile's DMAs were the last vector-memory operations of segment s - 2; younger: segment s - 1's and this
+      // segment's 4 stores + 4 DMAs each, where they exist
+      const int younger = 4 * ((s - 3 >= 0 ? 1 : 0) + (s + 1 < T ? 1 : 0) + (s - 2 >= 0 ? 1 : 0) + (s + 2 < T ? 1 : 0));
+      wait_vm(younger);
+      const char *xb = smem + oX + (s & 3) * kXBufB;
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int j = 0; j < kSlots; ++j)
+        if (sv[j]) {
+          const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xb + fld[j] * kSlotB + n * 64 + 16 * (q ^ (n >> 2)));
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            acc0 = mfma16(w0f[j][0][ks], x4[ks], acc0);
+            acc1 = mfma16(w0f[j][1][ks], x4[ks], acc1);
+          }
+        }
+      char *part = smem + oPart + ((s & 1) * kWorkers + w) * kPartB;
+      *reinterpret_cast<f32x4 *>(part + lane * 16) = acc0;
+      *reinterpret_cast<f32x4 *>(part + (64 + lane) * 16) = acc1;
+    }
+    __syncthreads();
+  }
+  // ---- this block's dW0 slab: every worker owns the rows of its fields
+#pragma unroll
+  for (int j = 0; j < kSlots; ++j)
+    if (sv[j]) {
+#pragma unroll
+      for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          a.dW0_part[((int64_t)blockIdx.x * a.Kp + 16 * fld[j] + 4 * q + i) * 32 + 16 * uh + n] = dw[j][uh][i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- head
+__device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const int lane, const int T) {
+  const int n = lane & 15, q = lane >> 4;
+  const int F = a.F, Dn = a.Dn, H0 = a.H0, H1 = a.H1, act = a.act;
+  const int64_t B = a.B, tstride = gridDim.x;
+  // ---- parameters in registers (unit index of register (h, i): 16 h + 4 q + i)
+  float w1a[2][2][4], w1b[2][2][4], b0r[2][4], b1r[2][4], wo[2][4], wd[4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // layer 1 forward, A operand of output half vh = x, k-step (uh = z, i): W1[16 z + 4 q + i][16 x + n]
+        const int ua = 16 * z + 4 * q + i, va = 16 * x + n;
+        const bool oka = ua < H0 && va < H1;
+        const float fa = a.W1[oka ? ua * H1 + va : 0];
+        w1a[x][z][i] = oka ? fa : 0.f;
+        // chain, A operand of output half uh = x, k-step (vh = z, i): W1[16 x + n][16 z + 4 q + i]
+        const int ub = 16 * x + n, vb = 16 * z + 4 * q + i;
+        const bool okb = ub < H0 && vb < H1;
+        const float fb = a.W1[okb ? ub * H1 + vb : 0];
+        w1b[x][z][i] = okb ? fb : 0.f;
+      }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = 16 * h + 4 * q + i;
+      const float f0 = a.b0[u < H0 ? u : 0], f1 = a.b1[u < H1 ? u : 0], f2 = a.w_out[u < H1 ? u : 0];
+      b0r[h][i] = u < H0 ? f0 : 0.f;
+      b1r[h][i] = u < H1 ? f1 : 0.f;
+      wo[h][i] = u < H1 ? f2 : 0.f;
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 * q + i;
+    const float f = a.lin_wd[c < Dn ? c : 0];
+    wd[i] = c < Dn ? f : 0.f;
+  }
+  const float w0o = a.w0_out[0], lw0 = a.lin_w0[0];
+  // this lane's fields q + 4 j (ids -> row numbers, bias / linear entries)
+  int64_t foff[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) foff[j] = a.field_off[q + 4 * j < F ? q + 4 * j : 0];
+
+  // ---- accumulators of the small gradients
+  f32x4 dW1[2][2];
+  float db0[2][4], db1[2][4], dwo[2][4], dxd[4], sg = 0.f, loss_acc = 0.f;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dW1[x][0][i] = dW1[x][1][i] = 0.f;
+      db0[x][i] = db1[x][i] = dwo[x][i] = 0.f;
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dxd[i] = 0.f;
+
+  auto ex_of = [&](int t) {  // this lane's example of tile t, clamped into the batch
+    const int64_t b = ((int64_t)blockIdx.x + t * tstride) * 16 + n;
+    return b < B ? b : B - 1;
+  };
+  // prefetch registers
+  int64_t idr[7];   // ids of tile s + 3 (loaded one segment earlier)
+  float2 sdr[7];    // (bias, linear) entries of tile s + 2
+  float dnr[4], yr = 0.f;  // dense columns 4 q .. 4 q + 3 and label of tile s + 1
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    idr[j] = 0;
+    sdr[j] = make_float2(0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dnr[i] = 0.f;
+  auto load_ids = [&](int t) {
+    const int64_t b = ex_of(t);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) idr[j] = a.idx[b * F + (q + 4 * j < F ? q + 4 * j : 0)];
+  };
+  if (T > 0) load_ids(0);
+
+  for (int s = -3; s <= T + 1; ++s) {
+    // ------------------------------------------------------------ epilogue of tile s - 1
+    if (s - 1 >= 0 && s - 1 < T) {
+      const int t = s - 1;
+      const int64_t bex = ((int64_t)blockIdx.x + t * tstride) * 16 + n;
+      const bool valid = bex < B;
+      const char *xb = smem + oX + (t & 3) * kXBufB;
+      // partial h0 of the 7 workers, fixed order
+      f32x4 pre[2];
+      pre[0] = pre[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < kWorkers; ++w) {
+        const char *part = smem + oPart + ((t & 1) * kWorkers + w) * kPartB;
+        pre[0] += *reinterpret_cast<const f32x4 *>(part + lane * 16);
+        pre[1] += *reinterpret_cast<const f32x4 *>(part + (64 + lane) * 16);
+      }
+      // FM sums over the fields: this lane's slice q of example n
+      f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f};
+      float ss = 0.f;
+      const int xo = n * 64 + 16 * (q ^ (n >> 2));
+      for (int f = 0; f < F; ++f) {
+        const f32x4 e = *reinterpret_cast<const f32x4 *>(xb + f * kSlotB + xo);
+        S += e;
+        ss += e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+      }
+      f32x4 dn4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (Dn > 0) dn4 = *reinterpret_cast<const f32x4 *>(xb + F * kSlotB + xo);
+      // layer 0 activation; h0 as [example][unit] for dW1
+      float h0[2][4], h1[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h0[h][i] = actf(pre[h][i] + b0r[h][i], act);
+        *reinterpret_cast<f32x4 *>(smem + oHT + (n * kLDT + 16 * h + 4 * q) * 4) =
+            f32x4{h0[h][0], h0[h][1], h0[h][2], h0[h][3]};
+      }
+      // layer 1
+      f32x4 acc[2];
+      acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[0] = mfma16(w1a[0][uh][i], h0[uh][i], acc[0]);
+          acc[1] = mfma16(w1a[1][uh][i], h0[uh][i], acc[1]);
+        }
+      float dnn = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          h1[h][i] = actf(acc[h][i] + b1r[h][i], act);
+          dnn += h1[h][i] * wo[h][i];
+        }
+      dnn = sum_q(dnn) + w0o;
+      // FM and linear logits
+      const float fmq = sum_q(S.x * S.x + S.y * S.y + S.z * S.z + S.w * S.w - ss);
+      const float2 sd = *reinterpret_cast<const float2 *>(smem + oSide + ((t & 7) * 16 + n) * 8);
+      const float fm = sd.x + 0.5f * fmq;
+      const float lin = sd.y + sum_q(dn4.x * wd[0] + dn4.y * wd[1] + dn4.z * wd[2] + dn4.w * wd[3]) + lw0;
+      const float ty = *reinterpret_cast<const float *>(smem + oY + ((t & 7) * 16 + n) * 4);
+      // PredictionLayer + loss (rm_logit_loss's arithmetic, same order of the branch sum)
+      float z = 0.f;
+      z += lin;
+      z += fm;
+      z += dnn;
+      float p, dz;
+      const float lt = rm_loss_point(z, ty, a.task, &p, &dz);
+      float gb = dz * (1.0f / (float)B);
+      gb *= a.grad_scale;
+      gb = valid ? gb : 0.f;
+      if (valid && q == 0) {
+        a.logit[bex] = z;
+        a.pred[bex] = p;
+        a.dlogit[bex] = gb;
+        loss_acc += lt;
+      }
+      // dh chain
+      float dh1[2][4], dh0[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh1[h][i] = gb * wo[h][i] * actg(h1[h][i], act);
+        *reinterpret_cast<f32x4 *>(smem + oD1T + (n * kLDT + 16 * h + 4 * q) * 4) =
+            f32x4{dh1[h][0], dh1[h][1], dh1[h][2], dh1[h][3]};
+      }
+      acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int vh = 0; vh < 2; ++vh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[0] = mfma16(w1b[0][vh][i], dh1[vh][i], acc[0]);
+          acc[1] = mfma16(w1b[1][vh][i], dh1[vh][i], acc[1]);
+        }
+      char *pub = smem + oPub + (t & 1) * kPubB;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh0[h][i] = acc[h][i] * actg(h0[h][i], act);
+        const f32x4 d4 = f32x4{dh0[h][0], dh0[h][1], dh0[h][2], dh0[h][3]};
+        *reinterpret_cast<f32x4 *>(pub + kPubDh + (h * 64 + lane) * 16) = d4;
+        *reinterpret_cast<f32x4 *>(pub + kPubDT + (n * kLDT + 16 * h + 4 * q) * 4) = d4;
+      }
+      *reinterpret_cast<f32x4 *>(pub + kPubGS + lane * 16) = f32x4{gb * S.x, gb * S.y, gb * S.z, gb * S.w};
+      *reinterpret_cast<float *>(pub + kPubG + lane * 4) = gb;
+      // small gradients: dW1 += h0^T dh1 on the matrix pipe, the rest per lane
+#pragma unroll
+      for (int es = 0; es < 4; ++es) {
+        float av[2], bv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          av[h] = *reinterpret_cast<const float *>(smem + oHT + ((4 * es + q) * kLDT + 16 * h + n) * 4);
+          bv[h] = *reinterpret_cast<const float *>(smem + oD1T + ((4 * es + q) * kLDT + 16 * h + n) * 4);
+        }
+#pragma unroll
+        for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+          for (int vh = 0; vh < 2; ++vh) dW1[uh][vh] = mfma16(av[uh], bv[vh], dW1[uh][vh]);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          db0[h][i] += dh0[h][i];
+          db1[h][i] += dh1[h][i];
+          dwo[h][i] += gb * h1[h][i];
+        }
+      sg += q == 0 ? gb : 0.f;
+      dxd[0] += gb * dn4.x;
+      dxd[1] += gb * dn4.y;
+      dxd[2] += gb * dn4.z;
+      dxd[3] += gb * dn4.w;
+    }
+    // ------------------------------------------------------------ bias / linear entries of tile s + 2 -> LDS
+    if (s + 2 >= 0 && s + 2 < T) {
+      float y1 = 0.f, ls = 0.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+        if (q + 4 * j < F) {
+          y1 += sdr[j].x;
+          ls += sdr[j].y;
+        }
+      y1 = sum_q(y1);
+      ls = sum_q(ls);
+      if (q == 0) *reinterpret_cast<float2 *>(smem + oSide + (((s + 2) & 7) * 16 + n) * 8) = make_float2(y1, ls);
+    }
+    // ------------------------------------------------------------ row numbers of tile s + 3 (+ its side loads)
+    if (s + 3 < T) {
+      const int t = s + 3;
+      unsigned *rowid = reinterpret_cast<unsigned *>(smem + oRow + (t & 1) * kXSlots * 64);
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+        if (q + 4 * j < F) {
+          const int64_t rid = idr[j] + foff[j];
+          rowid[(q + 4 * j) * 16 + n] = (unsigned)rid;
+          sdr[j] = *reinterpret_cast<const float2 *>(a.table + rid * a.row_bytes + 64);
+        }
+    }
+    if (s + 4 < T) load_ids(s + 4);
+    // ------------------------------------------------------------ dense inputs / label of tile s + 1 -> LDS
+    if (s + 1 >= 0 && s + 1 < T) {
+      const int t = s + 1;
+      if (Dn > 0)
+        *reinterpret_cast<f32x4 *>(smem + oX + (t & 3) * kXBufB + F * kSlotB + n * 64 + 16 * (q ^ (n >> 2))) =
+            f32x4{dnr[0], dnr[1], dnr[2], dnr[3]};
+      if (q == 0) *reinterpret_cast<float *>(smem + oY + ((t & 7) * 16 + n) * 4) = yr;
+    }
+    if (s + 2 >= 0 && s + 2 < T) {
+      const int64_t b = ex_of(s + 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * q + i;
+        const float f = Dn > 0 ? a.dense[b * Dn + (c < Dn ? c : 0)] : 0.f;
+        dnr[i] = c < Dn ? f : 0.f;
+      }
+      yr = a.y ? (float)a.y[b] : a.y_f[b];
+    }
+    __syncthreads();
+  }
+
+  // ---- this block's partial of the small gradients and the loss
+  float *sgp = a.sg_part + (int64_t)blockIdx.x * kRmSgStride;
+#pragma unroll
+  for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+    for (int vh = 0; vh < 2; ++vh)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sgp[(16 * uh + 4 * q + i) * 32 + 16 * vh + n] = dW1[uh][vh][i];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float s0 = sum_n(db0[h][i]), s1 = sum_n(db1[h][i]), s2 = sum_n(dwo[h][i]);
+      if (n == 0) {
+        const int u = 16 * h + 4 * q + i;
+        sgp[2 * 1024 + u] = s0;
+        sgp[2 * 1024 + 32 + u] = s1;
+        sgp[2 * 1024 + 64 + u] = s2;  // NL = 2: d w_out behind the two db_l
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float sx = sum_n(dxd[i]);
+    if (n == 0) sgp[kRmSgDense + 4 * q + i] = sx;
+  }
+  const float sgt = rm_wave_sum(sg), lst = rm_wave_sum(loss_acc);
+  if (lane == 0) {
+    sgp[2 * 1024 + 64 + 32] = sgt;
+    a.loss_part[blockIdx.x] = lst;
+  }
+}
+
+template <bool NT, bool NT_OUT>
+__global__ __launch_bounds__(512) void deepfm_step_kernel(StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ntiles = (a.B + 15) / 16;
+  const int T = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);  // tiles blockIdx.x + i gridDim.x
+  if (wave < kWorkers)
+    step_worker<NT, NT_OUT>(a, smem, lds_addr(smem), wave, lane, T);
+  else
+    step_head(a, smem, lane, T);
+}
+
+}  // namespace
+
+extern "C" int64_t rm_deepfm_step_workspace(int F, int Dn) {
+  const int Kp = ((16 * F + Dn + 63) / 64) * 64;
+  return (int64_t)256 * Kp * 32 + (int64_t)256 * kRmSgStride + 256;
+}
+
+extern "C" int rm_deepfm_step_supported(int F, int D, int64_t table_ld, int Dn, int NL, const int *H) {
+  if (D != 16 || table_ld < 20 || table_ld % 4 != 0 || F < 1 || F > 26 || Dn < 0 || Dn > 16 || NL != 2 || !H) return 0;
+  return H[0] >= 1 && H[0] <= 32 && H[1] >= 1 && H[1] <= 32;
+}
+
+extern "C" int rm_deepfm_step(const int64_t *idx, const float *table, int64_t table_ld, const int64_t *field_off,
+                              const float *dense, int Dn, const int64_t *y, const float *y_f, int64_t B, int F,
+                              int D, int NL, const int *H, const float *const *W, const float *const *bias,
+                              const float *w_out, const float *w0_out, const float *lin_w_dense,
+                              const float *lin_w0, int act, int task, float grad_scale, float *d_rows,
+                              float *logit, float *pred, float *dlogit, float *loss, float *const *dW,
+                              float *const *db, float *d_w_out, float *d_w0_out, float *d_lin_w_dense,
+                              float *d_lin_w0, float *workspace, int flags, rm_stream_t stream) {
+  RM_REQUIRE(H && rm_deepfm_step_supported(F, D, table_ld, Dn, NL, H),
+             "rm_deepfm_step: needs D = 16, fused rows (table_ld >= 20, a multiple of 4), F <= 26, Dn <= 16 and two "
+             "hidden layers of width <= 32");
+  RM_REQUIRE(B >= 0, "rm_deepfm_step: B < 0");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(idx && table && field_off && (Dn == 0 || (dense && lin_w_dense)) && W && bias && W[0] && W[1] &&
+                 bias[0] && bias[1] && w_out && w0_out && lin_w0 && d_rows && logit && pred && dlogit && loss && dW &&
+                 dW[0] && dW[1] && workspace,
+             "rm_deepfm_step: NULL argument");
+  RM_REQUIRE((y != nullptr) != (y_f != nullptr), "rm_deepfm_step: exactly one of y / y_f");
+  RM_REQUIRE(task == 0 || task == 1, "rm_deepfm_step: task must be 0 or 1");
+  RM_REQUIRE(rm_aligned16(table) && rm_aligned16(d_rows), "rm_deepfm_step: table / d_rows must be 16-byte aligned");
+  const int K = 16 * F + Dn, Kp = ((K + 63) / 64) * 64;
+  const int64_t ntiles = (B + 15) / 16;
+  const int nblk = rm_grid_cap(ntiles, 256);  // one 8-wave workgroup per CU
+  StepArgs a;
+  a.idx = idx; a.field_off = field_off; a.table = reinterpret_cast<const char *>(table); a.row_bytes = table_ld * 4;
+  a.dense = dense; a.y = y; a.y_f = y_f;
+  a.W0 = W[0]; a.b0 = bias[0]; a.W1 = W[1]; a.b1 = bias[1]; a.w_out = w_out; a.w0_out = w0_out;
+  a.lin_wd = Dn > 0 ? lin_w_dense : w_out; a.lin_w0 = lin_w0;
+  a.F = F; a.Dn = Dn; a.H0 = H[0]; a.H1 = H[1]; a.act = act; a.task = task; a.Kp = Kp;
+  a.grad_scale = grad_scale; a.B = B;
+  a.d_rows = d_rows; a.logit = logit; a.pred = pred; a.dlogit = dlogit;
+  a.dW0_part = workspace;
+  a.sg_part = workspace + (int64_t)256 * Kp * 32;
+  a.loss_part = a.sg_part + (int64_t)256 * kRmSgStride;
+  hipStream_t st = (hipStream_t)stream;
+  const bool nt = (flags & 1) != 0, nt_out = (flags & 2) != 0;
+#define RM_STEP(NT_, NTO_)                                                                                   \
+  {                                                                                                          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deepfm_step_kernel<NT_, NTO_>),                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);                        \
+    hipLaunchKernelGGL((deepfm_step_kernel<NT_, NTO_>), dim3(nblk), dim3(512), kLdsBytes, st, a);            \
+  }
+  if (nt) { if (nt_out) RM_STEP(true, true) else RM_STEP(true, false) }
+  else { if (nt_out) RM_STEP(false, true) else RM_STEP(false, false) }
+#undef RM_STEP
+  RM_CHECK_LAUNCH("rm_deepfm_step");
+  return rm_internal_mlp_finish(a.dW0_part, nblk, K, Kp, H[0], dW[0], a.sg_part, nblk, 2, H, dW, db, d_w_out,
+                                d_w0_out, Dn > 0 ? d_lin_w_dense : nullptr, d_lin_w0, Dn, a.loss_part, nblk, B, loss,
+                                st);
+}

@@ -389,6 +389,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
 
     class Sharded(base):
         sharded = True
+        step_fusable = False  # (DeepFM's one-kernel step reads a LOCAL table; here the rows arrive by exchange)
 
         def __init__(self):
             if spec.scratch_names and (capacity_factor or int(micro_batches) > 1):

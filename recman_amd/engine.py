@@ -847,6 +847,10 @@ class Engine:
         return False
 
 
+# DeepFM's fwd_bwd through rm_deepfm_step (one kernel) where it applies; False = rm_embed_mlp_fwd + rm_mlp_bwd
+STEP_FUSION_DEFAULT = False
+
+
 class DeepFMEngine(Engine):
     """DeepFM._init_graph (DeepFM.py:107-158): final = linear + fm + dnn."""
 
@@ -909,6 +913,49 @@ class DeepFMEngine(Engine):
             lin_logit=self.lin_logit, stream_rows=stream_rows, tail=mlp.tail)
         self._head_done = mlp.head_done
         return mlp.out.view(B)
+
+    # ---- the whole step in one kernel (rm_deepfm_step)
+    step_fusable = True  # the row-sharded subclass keeps its own fwd_bwd (recman_amd/dist.py)
+
+    def _step_fused(self, masks, mv):
+        """rm_deepfm_step covers this call: everything _front_fused asks for, plus FM + bias tables on, two
+        hidden layers, no dropout masks.  hp["step_fusion"] overrides STEP_FUSION_DEFAULT."""
+        if not (self.step_fusable and self.hp.get("step_fusion", STEP_FUSION_DEFAULT)) or masks or mv is not None:
+            return False
+        if not (self.use_fm and self.use_bias_tables and self._front_fused({}, None)):
+            return False
+        if getattr(self, "_step_ok", None) is None:
+            self._step_ok = bool(ops.deepfm_step_supported(self.F, self.D, self.LD, self.Dn, self.mlp.hidden))
+        return self._step_ok
+
+    def fwd_bwd(self, idx, dense, y, masks=None, mv=None):
+        B = idx.shape[0]
+        self._alloc(B)
+        if not self._step_fused(masks, mv):
+            return super().fwd_bwd(idx, dense, y, masks=masks, mv=mv)
+        self._mv = None
+        mlp, p, g = self.mlp, self.params, self.grads
+        if getattr(self, "_step_ws", None) is None:
+            self._step_ws = torch.zeros(ops.deepfm_step_workspace(self.F, self.Dn), dtype=F32, device=self.device)
+        pre, n = mlp.prefix, len(mlp.hidden)
+        ops.deepfm_step(
+            idx, self.rows, self.field_off, self.D, self.LD, dense if self.Dn else None, y,
+            [p[f"{pre}dnn_layer_{i}_weights"] for i in range(n)], [p[f"{pre}dnn_layer_{i}_bias"] for i in range(n)],
+            p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"], self.linear_w_dense if self.Dn else None, p["linear_w0"],
+            mlp.act, self.task, self.d_rows, self.logit, self.pred, self.dlogit, self.loss,
+            [g[f"{pre}dnn_layer_{i}_weights"] for i in range(n)], [g[f"{pre}dnn_layer_{i}_bias"] for i in range(n)],
+            g[f"{pre}dnn_w"].view(-1), g[f"{pre}dnn_w0"], g["linear_w_dense"] if self.Dn else None, g["linear_w0"],
+            self._step_ws, grad_scale=getattr(self, "grad_scale", 1.0),
+            stream_rows=self.hp.get("table_row_reuse", "stream") == "stream",
+            stream_d_rows=self.hp.get("d_rows_reuse", "cache") == "stream")
+        self.d_bias = None
+        self._head_done = self._lin_done = True
+        if self.Dn and self.lin_dense_mask is not None:
+            g["linear_w_dense"].mul_(self.lin_dense_mask)  # linear_features subset
+        reg = self.hp.get("deep_l2_reg", 0.0)
+        if reg:
+            mlp.add_l2_grads(reg)
+        return self._add_l2(self.loss)
 
     def roofline_probes(self, idx, dense, y):
         probes = super().roofline_probes(idx, dense, y)

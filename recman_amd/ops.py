@@ -395,6 +395,49 @@ def mlp_bwd(xe, xd, Ws, w_out, act, g, h, d_rows, dh, dW, workspace, fm_sum=None
               _chk(workspace, "workspace", F32), _tail_ref(tail), 1 if stream_d_rows else 0, _stream())
 
 
+def deepfm_step_supported(F, D, table_ld, Dn, hidden):
+    """rm_deepfm_step_supported: the one-kernel DeepFM training step covers this shape."""
+    return bool(_lib.lib().rm_deepfm_step_supported(int(F), int(D), int(table_ld), int(Dn), len(hidden),
+                                                    _int_array(list(hidden))))
+
+
+def deepfm_step_workspace(F, Dn):
+    return int(_lib.lib().rm_deepfm_step_workspace(int(F), int(Dn)))
+
+
+def deepfm_step(idx, rows, field_off, D, table_ld, dense, y, Ws, bs, w_out, w0_out, lin_w_dense, lin_w0, act, task,
+                d_rows, logit, pred, dlogit, loss, dW, db, d_w_out, d_w0_out, d_lin_w_dense, d_lin_w0, workspace,
+                grad_scale=1.0, stream_rows=False, stream_d_rows=False):
+    """rm_deepfm_step: DeepFM's forward + every gradient in one kernel (+ the finishing reduction)."""
+    B, F = idx.shape
+    Dn = 0 if dense is None else dense.shape[1]
+    H = [W.shape[1] for W in Ws]
+    for l, W in enumerate(Ws):
+        _chk(W, f"W[{l}]", F32, (F * D + Dn if l == 0 else H[l - 1], H[l]))
+        _chk(bs[l], f"bias[{l}]", F32, (H[l],))
+        _chk(dW[l], f"dW[{l}]", F32, tuple(W.shape))
+        _chk(db[l], f"db[{l}]", F32, (H[l],))
+    if rows.dim() != 2 or rows.shape[1] != table_ld or not rows.is_contiguous():
+        raise ValueError("deepfm_step: rows must be the contiguous fused table [R, table_ld]")
+    if rows.shape[0] >= 1 << 32:
+        raise ValueError("deepfm_step: the table has more than 2^32 rows")
+    if workspace.numel() < deepfm_step_workspace(F, Dn):
+        raise ValueError("deepfm_step: workspace too small")
+    yk = (_chk(y, "y", I64, (B,)), None) if y.dtype == I64 else (None, _chk(y, "y_f", F32, (B,)))
+    _lib.call("rm_deepfm_step", _chk(idx, "idx", I64), _chk(rows, "rows", F32), int(table_ld),
+              _chk(field_off, "field_off", I64, (F,)), _chk(dense, "dense", F32, (B, Dn), allow_none=True), Dn,
+              yk[0], yk[1], B, F, int(D), len(Ws), _int_array(H), _ptr_array(Ws), _ptr_array(bs),
+              _chk(w_out, "w_out", F32, (H[-1],)), _chk(w0_out, "w0_out", F32, (1,)),
+              _chk(lin_w_dense, "lin_w_dense", F32, (Dn,), allow_none=True), _chk(lin_w0, "lin_w0", F32, (1,)),
+              ACT_IDS[act], 0 if task == "classification" else 1, float(grad_scale),
+              _chk(d_rows, "d_rows", F32), _chk(logit, "logit", F32, (B,)), _chk(pred, "pred", F32, (B,)),
+              _chk(dlogit, "dlogit", F32, (B,)), _chk(loss, "loss", F32, (1,)), _ptr_array(dW), _ptr_array(db),
+              _chk(d_w_out, "d_w_out", F32, (H[-1],)), _chk(d_w0_out, "d_w0_out", F32, (1,)),
+              _chk(d_lin_w_dense, "d_lin_w_dense", F32, (Dn,), allow_none=True),
+              _chk(d_lin_w0, "d_lin_w0", F32, (1,)), _chk(workspace, "workspace", F32),
+              (1 if stream_rows else 0) | (2 if stream_d_rows else 0), _stream())
+
+
 def shard_route(idx, field_off, world, pos, send_ids, counts, workspace):
     B, F = idx.shape
     n = B * F

@@ -28,7 +28,7 @@ def test_one_kernel_front_equals_the_two_kernel_path_and_the_oracle(hip_lib, cas
     spec, p, idx, dense, y, hp = make_case("deepfm", D=16, **case)
     hp = dict(hp, use_fm=use_fm)
     loss_o, logit_o, pred_o, grads_o = T.fwd_bwd("deepfm", p, spec, idx, dense, y, hp)
-    e1 = _engine("deepfm", spec, 16, dict(hp, front_fusion=True), p)
+    e1 = _engine("deepfm", spec, 16, dict(hp, front_fusion=True, step_fusion=False), p)   # (the one-kernel STEP has its own test)
     e2 = _engine("deepfm", spec, 16, dict(hp, front_fusion=False), p)
     idx_d, dense_d, y_d = idx.cuda(), dense.cuda(), y.cuda()
     l1 = e1.fwd_bwd(idx_d, dense_d, y_d)
@@ -57,7 +57,7 @@ def test_one_kernel_front_is_deterministic_and_declines_what_it_does_not_cover(h
     from recman_amd import ops
 
     spec, p, idx, dense, y, hp = make_case("deepfm", D=16, B=200, F=26, Dn=13, hidden=(32, 32))
-    e = _engine("deepfm", spec, 16, hp, p)
+    e = _engine("deepfm", spec, 16, dict(hp, step_fusion=False), p)
     idx_d, dense_d, y_d = idx.cuda(), dense.cuda(), y.cuda()
     e.fwd_bwd(idx_d, dense_d, y_d)
     a = (e.logit.clone(), e.dlogit.clone(), e.d_rows.clone())
