@@ -17,8 +17,8 @@
 //  * the rows arrive by LDS-DMA (global_load_lds_dwordx4 with a per-lane source address: one instruction = the 16
 //    examples of one field, 64 bytes each), straight into a ring of 4 tile buffers, three tiles ahead of their use:
 //    no register is held by a row in flight and ~100 KB of lines are in flight per CU.  Lane (example r, piece p)
-//    fetches slice p ^ (r >> 2) of its row, which makes every later ds_read_b128 of "slice q of example n"
-//    conflict-free (position q ^ (n >> 2)) without padding the 64-byte rows.
+//    fetches slice p ^ swz(r) of its row, which makes every later ds_read_b128 of "slice q of example n"
+//    conflict-free (position q ^ swz(n)) without padding the 64-byte rows.
 //  * wave 7 is the HEAD: per tile it sums the 7 partial h0, adds the FM sums (it reads the whole x tile from LDS),
 //    runs layer 1, the output projection, the FM / linear logits, PredictionLayer, the loss term, dLoss/dlogit and
 //    the dh chain, publishes dh0 (two layouts), g and g*S for the workers' backward, and accumulates every small
@@ -46,21 +46,41 @@ constexpr int kRing = 4;      // x tile buffers
 constexpr int kSlotB = 1024;  // 16 examples x 64 bytes
 constexpr int kXBufB = kXSlots * kSlotB;
 constexpr int kPartB = 2048;  // one worker's partial h0 of a tile: [2 unit halves][64 lanes][4]
-constexpr int kLDT = 36;      // row stride (floats) of the [example][unit] images
+constexpr int kLDT = 36;      // row stride (floats) of the published [example][unit] image of dh0
 // published per tile by the head: dh0 in B-operand layout | dh0 as [example][unit] | g*S | g
 constexpr int kPubDh = 0, kPubDT = 2048, kPubGS = kPubDT + 16 * kLDT * 4, kPubG = kPubGS + 1024, kPubB = kPubG + 256;
 // LDS map (bytes)
 constexpr int oX = 0;                                 // [kRing][27][1024]
-constexpr int oJunk = oX + kRing * kXBufB;            // sink of the dummy DMAs of empty slots
-constexpr int oPart = oJunk + 1024;                   // [2][7][2048]
+constexpr int oPart = oX + kRing * kXBufB;            // [2][7][2048]
 constexpr int oPub = oPart + 2 * kWorkers * kPartB;   // [2][kPubB]
-constexpr int oRow = oPub + 2 * kPubB;                // [2][27][16] row numbers (u32)
-constexpr int oHT = oRow + 2 * kXSlots * 64;          // [16][36] h0 as [example][unit]
-constexpr int oD1T = oHT + 16 * kLDT * 4;             // [16][36] dh1 as [example][unit]
-constexpr int oSide = oD1T + 16 * kLDT * 4;           // [8][16][2] (sum of bias entries, sum of linear entries)
-constexpr int oY = oSide + 8 * 16 * 2 * 4;            // [8][16] labels
-constexpr int kLdsBytes = oY + 8 * 16 * 4;
+constexpr int kRowB = 28 * 64;                        // row numbers of a tile: [28 field slots][16] u32 (the head writes 7 per lane)
+constexpr int oRow = oPub + 2 * kPubB;                // [2][kRowB]
+constexpr int oHT = oRow + 2 * kRowB;                 // [16][32] h0 as [example][unit]   (head only)
+constexpr int oD1T = oHT + 16 * 32 * 4;               // [16][32] dh1 as [example][unit]  (head only)
+constexpr int oSide = oD1T + 16 * 32 * 4;             // [4][16][2] (sum of bias entries, sum of linear entries)
+constexpr int oY = oSide + 4 * 16 * 2 * 4;            // [4][16] labels
+constexpr int oW1 = oY + 4 * 16 * 4;                  // [32][32] W1[u][v], 16-byte block c of row u at position c ^ (u & 7)
+constexpr int oPar = oW1 + 32 * 32 * 4;               // b0 [32] | b1 [32] | w_out [32] | lin_w_dense [16] | field_off [28] (u32)
+constexpr int kParB0 = 0, kParB1 = 128, kParWo = 256, kParWd = 384, kParFo = 448;
+constexpr int kLdsBytes = oPar + 448 + 28 * 4;
 static_assert(kLdsBytes <= 160 * 1024, "LDS map exceeds a CU");
+
+#ifndef RM_STEP_ABL
+#define RM_STEP_ABL 0  // ablation builds (wrong results): 1 no bias / linear entry loads, 2 no d_rows stores, 4 every row = row 0
+#endif
+// diagnostic build (-DRM_STEP_STAMP, never in the product library): every wave adds up the shader-clock ticks it spends
+// in its phases; rm_debug_step_stamps reads them (tools/probe/step_stamps.py).
+#ifdef RM_STEP_STAMP
+__device__ unsigned long long rm_step_stamp_buf[256 * 8 * 8];
+#define ST_NOW() __builtin_amdgcn_s_memtime()
+#define ST_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = ST_NOW(), st_t0 = st_t
+#define ST_ADD(i) { const unsigned long long st_n = ST_NOW(); st_acc[i] += st_n - st_t; st_t = st_n; }
+#define ST_FLUSH(wv) if (lane == 0 && blockIdx.x < 256) { st_acc[7] = ST_NOW() - st_t0; for (int i_ = 0; i_ < 8; ++i_) rm_step_stamp_buf[(blockIdx.x * 8 + (wv)) * 8 + i_] = st_acc[i_]; }
+#else
+#define ST_DECL
+#define ST_ADD(i)
+#define ST_FLUSH(wv)
+#endif
 
 struct StepArgs {
   const int64_t *idx, *field_off;
@@ -76,16 +96,14 @@ struct StepArgs {
   float *d_rows, *logit, *pred, *dlogit, *dW0_part, *sg_part, *loss_part;
 };
 
-__device__ __forceinline__ float actf(float v, int act) {
-  if (act == RM_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == RM_ACT_LEAKY_RELU) return v > 0.f ? v : 0.2f * v;
-  return v;
+// activation and its derivative off the post-activation value, branch-free: slope = 0 (relu), 0.2 (leaky_relu,
+// tf.nn.leaky_relu's alpha), 1 (identity).  (A runtime `switch (act)` per element compiled to two scalar branches per
+// value: ~100 of them per tile in the head wave.)
+__device__ __forceinline__ float act_slope(int act) {
+  return act == RM_ACT_RELU ? 0.f : (act == RM_ACT_LEAKY_RELU ? 0.2f : 1.f);
 }
-__device__ __forceinline__ float actg(float o, int act) {
-  if (act == RM_ACT_RELU) return o > 0.f ? 1.f : 0.f;
-  if (act == RM_ACT_LEAKY_RELU) return o > 0.f ? 1.f : 0.2f;
-  return 1.f;
-}
+__device__ __forceinline__ float actf(float v, float slope) { return v > 0.f ? v : slope * v; }
+__device__ __forceinline__ float actg(float o, float slope) { return o > 0.f ? 1.f : slope; }
 
 // field slot j of worker w: fields 7 j + w for j < 3; the last round skips worker 3, the head's SIMD partner
 // (27 slots over 7 workers: 4 4 4 3 4 4 4).  Slot field == F is the dense pseudo-field.
@@ -98,6 +116,12 @@ __device__ __forceinline__ int slot_field(int w, int j) {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// Position of 16-byte slice j of example r's 64-byte row in LDS: j ^ swz(r).  ds_read_b128 serves a wave in the lane
+// groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with lane = (example n = lane & 15, slice q = lane >> 4) a
+// group holds every example once, examples 4..11 with the other slice parity - swz = 3 for examples 8..15 gives the
+// four rows that share a bank window (n mod 4 equal) four different positions in either group.
+__device__ __forceinline__ int swz(int r) { return ((r >> 3) & 1) * 3; }
 
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
@@ -116,20 +140,33 @@ __device__ __forceinline__ void glds16(const void *src, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
 
-// waits until at most `younger` of this wave's vector-memory operations are outstanding (a multiple of 4 here)
+// waits until at most `younger` (0..16) of this wave's vector-memory operations are outstanding
 __device__ __forceinline__ void wait_vm(int younger) {
+#define RM_WV(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
   switch (younger) {
-    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    RM_WV(16) RM_WV(15) RM_WV(14) RM_WV(13) RM_WV(12) RM_WV(11) RM_WV(10) RM_WV(9) RM_WV(8) RM_WV(7) RM_WV(6)
+    RM_WV(5) RM_WV(4) RM_WV(3) RM_WV(2) RM_WV(1)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
+#undef RM_WV
 }
 
-__device__ __forceinline__ float sum_q(float v) {  // over the 4 lanes (n, 0..3) of an example
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
+// Sum over the 4 lanes (n, 0..3) of an example = the xor-16 / xor-32 butterfly, on the gfx950 permlane swaps (VALU;
+// through ds_bpermute each step is an LDS round trip, and the head wave's epilogue is one dependent chain).
+// v_permlane16_swap / v_permlane32_swap exchange the odd rows (upper half) of the first register with the even rows
+// (lower half) of the second: with two copies of v the sum of the two results crosses the rows (halves).  Inline asm
+// as in cross.hip (hipcc's builtin added the first result to itself); "s_nop 1" = the wait states behind a VALU write.
+__device__ __forceinline__ float sum_q(float v) {
+  {
+    float a = v, c = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+    v = a + c;
+  }
+  {
+    float a = v, c = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+    v = a + c;
+  }
   return v;
 }
 __device__ __forceinline__ float sum_n(float v) {  // over the 16 lanes (0..15, q)
@@ -149,11 +186,13 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
   float w0f[kSlots][2][4];      // forward A operand: W0[kb + 4 q + ks][16 uh + n]
   float w0x[kSlots][2][4];      // dX A operand:      W0[kb + n][16 uh + 4 q + i]
   f32x4 dw[kSlots][2];          // dW0[kb + 4 q + i][16 uh + n]
+  int nd = 0;                   // embedding fields of this worker = LDS-DMA instructions per tile
 #pragma unroll
   for (int j = 0; j < kSlots; ++j) {
     const int f = slot_field(w, j);
     sv[j] = f >= 0 && (f < F || (f == F && a.Dn > 0));
     sx[j] = f >= 0 && f < F;
+    nd += sx[j] ? 1 : 0;
     fld[j] = sv[j] ? f : 0;
     const int kb = 16 * fld[j];
 #pragma unroll
@@ -173,6 +212,8 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
     }
   }
   const int64_t tstride = gridDim.x;
+  ST_DECL;
+  ST_ADD(0);  // prologue
 
   for (int s = -3; s <= T + 1; ++s) {
     // ------------------------------------------------------------ backward of tile s - 2
@@ -203,15 +244,15 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
           const char *xs = xb + fld[j] * kSlotB;
           float col[4];
 #pragma unroll
-          for (int es = 0; es < 4; ++es)  // x[example 4 es + q][k = n]: position (n >> 2) ^ es of that row
-            col[es] = *reinterpret_cast<const float *>(xs + (4 * es + q) * 64 + 16 * ((n >> 2) ^ es) + 4 * (n & 3));
+          for (int es = 0; es < 4; ++es)  // x[example 4 es + q][k = n]: slice n >> 2 of that row
+            col[es] = *reinterpret_cast<const float *>(xs + (4 * es + q) * 64 + 16 * ((n >> 2) ^ swz(4 * es + q)) + 4 * (n & 3));
 #pragma unroll
           for (int es = 0; es < 4; ++es) {
             dw[j][0] = mfma16(col[es], dT[0][es], dw[j][0]);
             dw[j][1] = mfma16(col[es], dT[1][es], dw[j][1]);
           }
           if (sx[j]) {
-            const f32x4 e4 = *reinterpret_cast<const f32x4 *>(xs + n * 64 + 16 * (q ^ (n >> 2)));
+            const f32x4 e4 = *reinterpret_cast<const f32x4 *>(xs + n * 64 + 16 * (q ^ swz(n)));
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int uh = 0; uh < 2; ++uh)
@@ -222,42 +263,43 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
             o.y = acc.y + (gS.y - g * e4.y);
             o.z = acc.z + (gS.z - g * e4.z);
             o.w = acc.w + (gS.w - g * e4.w);
-            off = (n * F + fld[j]) * 64 + 16 * q;
+            if (!(RM_STEP_ABL & 2)) off = (n * F + fld[j]) * 64 + 16 * q;
           }
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, off, 0, NT_OUT ? 2 : 0);
       }
     }
+    ST_ADD(1);  // backward
     // ------------------------------------------------------------ rows of tile s + 2 (into the buffer just freed)
     if (s + 2 >= 0 && s + 2 < T) {
       const int t = s + 2;
-      const unsigned *rowid = reinterpret_cast<const unsigned *>(smem + oRow + (t & 1) * kXSlots * 64);
+      const unsigned *rowid = reinterpret_cast<const unsigned *>(smem + oRow + (t & 1) * kRowB);
       const unsigned xdst = lds0 + oX + (t & 3) * kXBufB;
-      const int piece = 16 * ((lane & 3) ^ ((lane >> 4) & 3));
+      const int piece = 16 * ((lane & 3) ^ swz(lane >> 2));
+      // (all row numbers first, then the DMAs back to back: the asm statements are memory barriers for hipcc, a read
+      // placed between them waits out its LDS round trip before the next piece is issued)
+      unsigned rid[kSlots];
 #pragma unroll
-      for (int j = 0; j < kSlots; ++j) {
-        const char *src = a.table;
-        unsigned dst = lds0 + oJunk;
-        if (sx[j]) {
-          const unsigned rid = rowid[fld[j] * 16 + (lane >> 2)];
-          src = a.table + (int64_t)rid * a.row_bytes + piece;
-          dst = xdst + fld[j] * kSlotB;
-        }
-        glds16<NT>(src, dst);
-      }
+      for (int j = 0; j < kSlots; ++j) rid[j] = rowid[fld[j] * 16 + (lane >> 2)];
+#pragma unroll
+      for (int j = 0; j < kSlots; ++j)
+        if (sx[j])  // wave-uniform
+          glds16<NT>(a.table + ((RM_STEP_ABL & 4) ? 0 : (int64_t)rid[j] * a.row_bytes) + piece, xdst + fld[j] * kSlotB);
     }
+    ST_ADD(2);  // DMA issue
     // ------------------------------------------------------------ forward of tile s
     if (s >= 0 && s < T) {
       // the tile's DMAs were the last vector-memory operations of segment s - 2; younger: segment s - 1's and this
-      // segment's 4 stores + 4 DMAs each, where they exist
-      const int younger = 4 * ((s - 3 >= 0 ? 1 : 0) + (s + 1 < T ? 1 : 0) + (s - 2 >= 0 ? 1 : 0) + (s + 2 < T ? 1 : 0));
+      // segment's 4 stores + nd DMAs each, where they exist
+      const int younger = 4 * ((s - 3 >= 0 ? 1 : 0) + (s - 2 >= 0 ? 1 : 0)) + nd * ((s + 1 < T ? 1 : 0) + (s + 2 < T ? 1 : 0));
       wait_vm(younger);
+      ST_ADD(3);  // wait for the tile's rows
       const char *xb = smem + oX + (s & 3) * kXBufB;
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
       for (int j = 0; j < kSlots; ++j)
         if (sv[j]) {
-          const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xb + fld[j] * kSlotB + n * 64 + 16 * (q ^ (n >> 2)));
+          const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xb + fld[j] * kSlotB + n * 64 + 16 * (q ^ swz(n)));
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             acc0 = mfma16(w0f[j][0][ks], x4[ks], acc0);
@@ -268,7 +310,9 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
       *reinterpret_cast<f32x4 *>(part + lane * 16) = acc0;
       *reinterpret_cast<f32x4 *>(part + (64 + lane) * 16) = acc1;
     }
+    ST_ADD(4);  // forward
     __syncthreads();
+    ST_ADD(5);  // barrier
   }
   // ---- this block's dW0 slab: every worker owns the rows of its fields
 #pragma unroll
@@ -280,53 +324,45 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
         for (int i = 0; i < 4; ++i)
           a.dW0_part[((int64_t)blockIdx.x * a.Kp + 16 * fld[j] + 4 * q + i) * 32 + 16 * uh + n] = dw[j][uh][i];
     }
+  ST_ADD(6);
+  ST_FLUSH(w);
 }
 
 // ---------------------------------------------------------------------------------------------- head
 __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const int lane, const int T) {
   const int n = lane & 15, q = lane >> 4;
-  const int F = a.F, Dn = a.Dn, H0 = a.H0, H1 = a.H1, act = a.act;
+  const int F = a.F, Dn = a.Dn, H0 = a.H0, H1 = a.H1;
+  const float act = act_slope(a.act);
   const int64_t B = a.B, tstride = gridDim.x;
-  // ---- parameters in registers (unit index of register (h, i): 16 h + 4 q + i)
-  float w1a[2][2][4], w1b[2][2][4], b0r[2][4], b1r[2][4], wo[2][4], wd[4];
+  // ---- parameters: in LDS, read per tile (as registers they pushed this wave past 256 VGPRs: W1 in both operand
+  // layouts alone is 32).  W1[u][v] row-major with the 16-byte blocks of a row XOR-swizzled by the row, so that the
+  // forward's column reads (ds_read_b32, lanes along v) and the chain's row reads (ds_read_b128) both spread over the banks.
+  {
+    float *w1s = reinterpret_cast<float *>(smem + oW1);
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int z = 0; z < 2; ++z)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        // layer 1 forward, A operand of output half vh = x, k-step (uh = z, i): W1[16 z + 4 q + i][16 x + n]
-        const int ua = 16 * z + 4 * q + i, va = 16 * x + n;
-        const bool oka = ua < H0 && va < H1;
-        const float fa = a.W1[oka ? ua * H1 + va : 0];
-        w1a[x][z][i] = oka ? fa : 0.f;
-        // chain, A operand of output half uh = x, k-step (vh = z, i): W1[16 x + n][16 z + 4 q + i]
-        const int ub = 16 * x + n, vb = 16 * z + 4 * q + i;
-        const bool okb = ub < H0 && vb < H1;
-        const float fb = a.W1[okb ? ub * H1 + vb : 0];
-        w1b[x][z][i] = okb ? fb : 0.f;
-      }
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int u = 16 * h + 4 * q + i;
-      const float f0 = a.b0[u < H0 ? u : 0], f1 = a.b1[u < H1 ? u : 0], f2 = a.w_out[u < H1 ? u : 0];
-      b0r[h][i] = u < H0 ? f0 : 0.f;
-      b1r[h][i] = u < H1 ? f1 : 0.f;
-      wo[h][i] = u < H1 ? f2 : 0.f;
+    for (int i = 0; i < 16; ++i) {
+      const int e = lane + 64 * i, u = e >> 5, v = e & 31;
+      const bool ok = u < H0 && v < H1;
+      const float f = a.W1[ok ? u * H1 + v : 0];
+      w1s[u * 32 + 4 * ((v >> 2) ^ (u & 7)) + (v & 3)] = ok ? f : 0.f;
     }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = 4 * q + i;
-    const float f = a.lin_wd[c < Dn ? c : 0];
-    wd[i] = c < Dn ? f : 0.f;
+    float *par = reinterpret_cast<float *>(smem + oPar);
+    if (lane < 32) {
+      const float f0 = a.b0[lane < H0 ? lane : 0], f1 = a.b1[lane < H1 ? lane : 0], f2 = a.w_out[lane < H1 ? lane : 0];
+      par[kParB0 / 4 + lane] = lane < H0 ? f0 : 0.f;
+      par[kParB1 / 4 + lane] = lane < H1 ? f1 : 0.f;
+      par[kParWo / 4 + lane] = lane < H1 ? f2 : 0.f;
+      const float f3 = a.lin_wd[lane < Dn ? lane : 0];
+      if (lane < 16) par[kParWd / 4 + lane] = lane < Dn ? f3 : 0.f;
+      if (lane < 28) reinterpret_cast<unsigned *>(par)[kParFo / 4 + lane] = (unsigned)a.field_off[lane < F ? lane : F - 1];
+    }
   }
+  const float *w1s = reinterpret_cast<const float *>(smem + oW1);
+  const char *par = smem + oPar;
   const float w0o = a.w0_out[0], lw0 = a.lin_w0[0];
-  // this lane's fields q + 4 j (ids -> row numbers, bias / linear entries)
-  int64_t foff[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) foff[j] = a.field_off[q + 4 * j < F ? q + 4 * j : 0];
+  // this lane's fields q + 4 j (ids -> row numbers, bias / linear entries).  Everything about them is UNCONDITIONAL:
+  // fields past F read field F - 1 again and are dropped by a select where they are summed (per-lane branches around
+  // the loads made hipcc serialise them behind s_waitcnt vmcnt(0): 7 exposed HBM round trips per tile)
 
   // ---- accumulators of the small gradients
   f32x4 dW1[2][2];
@@ -346,9 +382,11 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
     return b < B ? b : B - 1;
   };
   // prefetch registers
-  int64_t idr[7];   // ids of tile s + 3 (loaded one segment earlier)
+  unsigned idr[7];  // ids (low words) of tile s + 3, loaded one segment earlier
   float2 sdr[7];    // (bias, linear) entries of tile s + 2
-  float dnr[4], yr = 0.f;  // dense columns 4 q .. 4 q + 3 and label of tile s + 1
+  float dnr[4];     // dense columns 4 q .. 4 q + 3 of tile s + 1
+  unsigned yr = 0;  // ... and its label, RAW (low word of the int64 / the float's bits): converting it where it is
+                    // loaded put an s_waitcnt vmcnt(0) behind this segment's loads - 5,000 cycles per tile
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     idr[j] = 0;
@@ -357,11 +395,13 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
 #pragma unroll
   for (int i = 0; i < 4; ++i) dnr[i] = 0.f;
   auto load_ids = [&](int t) {
-    const int64_t b = ex_of(t);
+    const unsigned *p = reinterpret_cast<const unsigned *>(a.idx + ex_of(t) * F);  // low words (row numbers < 2^32)
 #pragma unroll
-    for (int j = 0; j < 7; ++j) idr[j] = a.idx[b * F + (q + 4 * j < F ? q + 4 * j : 0)];
+    for (int j = 0; j < 7; ++j) idr[j] = p[2 * (q + 4 * j < F ? q + 4 * j : F - 1)];
   };
   if (T > 0) load_ids(0);
+  ST_DECL;
+  ST_ADD(0);
 
   for (int s = -3; s <= T + 1; ++s) {
     // ------------------------------------------------------------ epilogue of tile s - 1
@@ -378,25 +418,43 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
         const char *part = smem + oPart + ((t & 1) * kWorkers + w) * kPartB;
         pre[0] += *reinterpret_cast<const f32x4 *>(part + lane * 16);
         pre[1] += *reinterpret_cast<const f32x4 *>(part + (64 + lane) * 16);
+        if (w == 3) __builtin_amdgcn_sched_barrier(0);  // (two batches of reads: 14 in flight cost 56 registers)
       }
+      __builtin_amdgcn_sched_barrier(0);
       // FM sums over the fields: this lane's slice q of example n
       f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f};
       float ss = 0.f;
-      const int xo = n * 64 + 16 * (q ^ (n >> 2));
-      for (int f = 0; f < F; ++f) {
-        const f32x4 e = *reinterpret_cast<const f32x4 *>(xb + f * kSlotB + xo);
-        S += e;
-        ss += e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+      const int xo = n * 64 + 16 * (q ^ swz(n));
+      // (groups of 4 reads in flight, then the remainder)
+      f32x4 Q = f32x4{0.f, 0.f, 0.f, 0.f};  // per-component sums of squares
+      int f0 = 0;
+      for (; f0 + 4 <= F; f0 += 4) {
+        f32x4 e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = *reinterpret_cast<const f32x4 *>(xb + (f0 + i) * kSlotB + xo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          S += e[i];
+          Q += e[i] * e[i];
+        }
       }
+      for (; f0 < F; ++f0) {
+        const f32x4 e = *reinterpret_cast<const f32x4 *>(xb + f0 * kSlotB + xo);
+        S += e;
+        Q += e * e;
+      }
+      ss = (Q.x + Q.y) + (Q.z + Q.w);
       f32x4 dn4 = f32x4{0.f, 0.f, 0.f, 0.f};
       if (Dn > 0) dn4 = *reinterpret_cast<const f32x4 *>(xb + F * kSlotB + xo);
+      ST_ADD(1);  // partial sums + FM sums
       // layer 0 activation; h0 as [example][unit] for dW1
       float h0[2][4], h1[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+        const f32x4 b0v = *reinterpret_cast<const f32x4 *>(par + kParB0 + (16 * h + 4 * q) * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) h0[h][i] = actf(pre[h][i] + b0r[h][i], act);
-        *reinterpret_cast<f32x4 *>(smem + oHT + (n * kLDT + 16 * h + 4 * q) * 4) =
+        for (int i = 0; i < 4; ++i) h0[h][i] = actf(pre[h][i] + b0v[i], act);
+        *reinterpret_cast<f32x4 *>(smem + oHT + (n * 32 + 16 * h + 4 * q) * 4) =
             f32x4{h0[h][0], h0[h][1], h0[h][2], h0[h][3]};
       }
       // layer 1
@@ -406,24 +464,32 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
       for (int uh = 0; uh < 2; ++uh)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          acc[0] = mfma16(w1a[0][uh][i], h0[uh][i], acc[0]);
-          acc[1] = mfma16(w1a[1][uh][i], h0[uh][i], acc[1]);
+          const int u = 16 * uh + 4 * q + i;  // A operand of k-step (uh, i): W1[u][16 vh + n]
+          const float a0 = w1s[u * 32 + 4 * ((n >> 2) ^ (u & 7)) + (n & 3)];
+          const float a1 = w1s[u * 32 + 4 * ((4 + (n >> 2)) ^ (u & 7)) + (n & 3)];
+          acc[0] = mfma16(a0, h0[uh][i], acc[0]);
+          acc[1] = mfma16(a1, h0[uh][i], acc[1]);
         }
       float dnn = 0.f;
+      f32x4 wov[2];
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 b1v = *reinterpret_cast<const f32x4 *>(par + kParB1 + (16 * h + 4 * q) * 4);
+        wov[h] = *reinterpret_cast<const f32x4 *>(par + kParWo + (16 * h + 4 * q) * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          h1[h][i] = actf(acc[h][i] + b1r[h][i], act);
-          dnn += h1[h][i] * wo[h][i];
+          h1[h][i] = actf(acc[h][i] + b1v[i], act);
+          dnn += h1[h][i] * wov[h][i];
         }
+      }
       dnn = sum_q(dnn) + w0o;
       // FM and linear logits
       const float fmq = sum_q(S.x * S.x + S.y * S.y + S.z * S.z + S.w * S.w - ss);
-      const float2 sd = *reinterpret_cast<const float2 *>(smem + oSide + ((t & 7) * 16 + n) * 8);
+      const float2 sd = *reinterpret_cast<const float2 *>(smem + oSide + ((t & 3) * 16 + n) * 8);
       const float fm = sd.x + 0.5f * fmq;
-      const float lin = sd.y + sum_q(dn4.x * wd[0] + dn4.y * wd[1] + dn4.z * wd[2] + dn4.w * wd[3]) + lw0;
-      const float ty = *reinterpret_cast<const float *>(smem + oY + ((t & 7) * 16 + n) * 4);
+      const f32x4 wdv = *reinterpret_cast<const f32x4 *>(par + kParWd + 16 * q);
+      const float lin = sd.y + sum_q(dn4.x * wdv.x + dn4.y * wdv.y + dn4.z * wdv.z + dn4.w * wdv.w) + lw0;
+      const float ty = *reinterpret_cast<const float *>(smem + oY + ((t & 3) * 16 + n) * 4);
       // PredictionLayer + loss (rm_logit_loss's arithmetic, same order of the branch sum)
       float z = 0.f;
       z += lin;
@@ -440,23 +506,28 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
         a.dlogit[bex] = gb;
         loss_acc += lt;
       }
+      ST_ADD(2);  // layer 1, logits, loss
       // dh chain
       float dh1[2][4], dh0[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dh1[h][i] = gb * wo[h][i] * actg(h1[h][i], act);
-        *reinterpret_cast<f32x4 *>(smem + oD1T + (n * kLDT + 16 * h + 4 * q) * 4) =
+        for (int i = 0; i < 4; ++i) dh1[h][i] = gb * wov[h][i] * actg(h1[h][i], act);
+        *reinterpret_cast<f32x4 *>(smem + oD1T + (n * 32 + 16 * h + 4 * q) * 4) =
             f32x4{dh1[h][0], dh1[h][1], dh1[h][2], dh1[h][3]};
       }
       acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int vh = 0; vh < 2; ++vh)
+      for (int vh = 0; vh < 2; ++vh) {
+        // A operands of k-steps (vh, 0..3): W1[16 uh + n][16 vh + 4 q + i], one 16-byte block per output half
+        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(w1s + n * 32 + 4 * ((4 * vh + q) ^ (n & 7)));
+        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(w1s + (16 + n) * 32 + 4 * ((4 * vh + q) ^ (n & 7)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          acc[0] = mfma16(w1b[0][vh][i], dh1[vh][i], acc[0]);
-          acc[1] = mfma16(w1b[1][vh][i], dh1[vh][i], acc[1]);
+          acc[0] = mfma16(c0[i], dh1[vh][i], acc[0]);
+          acc[1] = mfma16(c1[i], dh1[vh][i], acc[1]);
         }
+      }
       char *pub = smem + oPub + (t & 1) * kPubB;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -468,14 +539,15 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
       }
       *reinterpret_cast<f32x4 *>(pub + kPubGS + lane * 16) = f32x4{gb * S.x, gb * S.y, gb * S.z, gb * S.w};
       *reinterpret_cast<float *>(pub + kPubG + lane * 4) = gb;
+      ST_ADD(3);  // chain + publish
       // small gradients: dW1 += h0^T dh1 on the matrix pipe, the rest per lane
 #pragma unroll
       for (int es = 0; es < 4; ++es) {
         float av[2], bv[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          av[h] = *reinterpret_cast<const float *>(smem + oHT + ((4 * es + q) * kLDT + 16 * h + n) * 4);
-          bv[h] = *reinterpret_cast<const float *>(smem + oD1T + ((4 * es + q) * kLDT + 16 * h + n) * 4);
+          av[h] = *reinterpret_cast<const float *>(smem + oHT + ((4 * es + q) * 32 + 16 * h + n) * 4);
+          bv[h] = *reinterpret_cast<const float *>(smem + oD1T + ((4 * es + q) * 32 + 16 * h + n) * 4);
         }
 #pragma unroll
         for (int uh = 0; uh < 2; ++uh)
@@ -496,51 +568,61 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
       dxd[2] += gb * dn4.z;
       dxd[3] += gb * dn4.w;
     }
-    // ------------------------------------------------------------ bias / linear entries of tile s + 2 -> LDS
-    if (s + 2 >= 0 && s + 2 < T) {
+    ST_ADD(4);  // small gradients
+    // ------------------------------------------------------------ the prefetch chain: FIRST everything that consumes
+    // registers loaded one segment ago, THEN this segment's loads (a conservative s_waitcnt vmcnt(0) in front of a
+    // consumer must not find loads that have only just been issued)
+    if (s + 2 >= 0 && s + 2 < T) {  // bias / linear entries of tile s + 2 -> LDS
       float y1 = 0.f, ls = 0.f;
 #pragma unroll
-      for (int j = 0; j < 7; ++j)
-        if (q + 4 * j < F) {
-          y1 += sdr[j].x;
-          ls += sdr[j].y;
-        }
+      for (int j = 0; j < 7; ++j) {
+        y1 += q + 4 * j < F ? sdr[j].x : 0.f;
+        ls += q + 4 * j < F ? sdr[j].y : 0.f;
+      }
       y1 = sum_q(y1);
       ls = sum_q(ls);
-      if (q == 0) *reinterpret_cast<float2 *>(smem + oSide + (((s + 2) & 7) * 16 + n) * 8) = make_float2(y1, ls);
+      if (q == 0) *reinterpret_cast<float2 *>(smem + oSide + (((s + 2) & 3) * 16 + n) * 8) = make_float2(y1, ls);
     }
-    // ------------------------------------------------------------ row numbers of tile s + 3 (+ its side loads)
-    if (s + 3 < T) {
-      const int t = s + 3;
-      unsigned *rowid = reinterpret_cast<unsigned *>(smem + oRow + (t & 1) * kXSlots * 64);
-#pragma unroll
-      for (int j = 0; j < 7; ++j)
-        if (q + 4 * j < F) {
-          const int64_t rid = idr[j] + foff[j];
-          rowid[(q + 4 * j) * 16 + n] = (unsigned)rid;
-          sdr[j] = *reinterpret_cast<const float2 *>(a.table + rid * a.row_bytes + 64);
-        }
-    }
-    if (s + 4 < T) load_ids(s + 4);
-    // ------------------------------------------------------------ dense inputs / label of tile s + 1 -> LDS
-    if (s + 1 >= 0 && s + 1 < T) {
+    if (s + 1 >= 0 && s + 1 < T) {  // dense inputs / label of tile s + 1 -> LDS
       const int t = s + 1;
-      if (Dn > 0)
-        *reinterpret_cast<f32x4 *>(smem + oX + (t & 3) * kXBufB + F * kSlotB + n * 64 + 16 * (q ^ (n >> 2))) =
-            f32x4{dnr[0], dnr[1], dnr[2], dnr[3]};
-      if (q == 0) *reinterpret_cast<float *>(smem + oY + ((t & 7) * 16 + n) * 4) = yr;
+      if (Dn > 0)  // (columns past Dn are masked HERE, a segment after the load: a select next to the load waits for it)
+        *reinterpret_cast<f32x4 *>(smem + oX + (t & 3) * kXBufB + F * kSlotB + n * 64 + 16 * (q ^ swz(n))) =
+            f32x4{4 * q + 0 < Dn ? dnr[0] : 0.f, 4 * q + 1 < Dn ? dnr[1] : 0.f, 4 * q + 2 < Dn ? dnr[2] : 0.f,
+                  4 * q + 3 < Dn ? dnr[3] : 0.f};
+      if (q == 0)
+        *reinterpret_cast<float *>(smem + oY + ((t & 3) * 16 + n) * 4) = a.y ? (float)(int)yr : __uint_as_float(yr);
     }
+    unsigned rid[7];
+    if (s + 3 < T) {  // row numbers of tile s + 3 -> LDS (slots >= F: never read)
+      unsigned *rowid = reinterpret_cast<unsigned *>(smem + oRow + ((s + 3) & 1) * kRowB);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        rid[j] = idr[j] + *reinterpret_cast<const unsigned *>(par + kParFo + (q + 4 * j) * 4);
+        rowid[(q + 4 * j) * 16 + n] = rid[j];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (issue order: the registers whose last consumer sits behind another guard first - hipcc protects their re-load
+    // with a conservative s_waitcnt, which must not find this segment's other loads already in flight)
     if (s + 2 >= 0 && s + 2 < T) {
       const int64_t b = ex_of(s + 2);
+      if (Dn > 0) {
+        const float *dp = a.dense + b * Dn;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = 4 * q + i;
-        const float f = Dn > 0 ? a.dense[b * Dn + (c < Dn ? c : 0)] : 0.f;
-        dnr[i] = c < Dn ? f : 0.f;
+        for (int i = 0; i < 4; ++i) dnr[i] = dp[4 * q + i < Dn ? 4 * q + i : 0];
       }
-      yr = a.y ? (float)a.y[b] : a.y_f[b];
+      const unsigned *yp = a.y ? reinterpret_cast<const unsigned *>(a.y + b) : reinterpret_cast<const unsigned *>(a.y_f + b);
+      yr = *yp;
     }
+    if (s + 4 < T) load_ids(s + 4);
+    if (s + 3 < T) {  // ... and its bias / linear entries
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+        if (!(RM_STEP_ABL & 1)) sdr[j] = *reinterpret_cast<const float2 *>(a.table + (int64_t)rid[j] * a.row_bytes + 64);
+    }
+    ST_ADD(6);  // prefetch chain
     __syncthreads();
+    ST_ADD(5);  // barrier
   }
 
   // ---- this block's partial of the small gradients and the loss
@@ -573,6 +655,8 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
     sgp[2 * 1024 + 64 + 32] = sgt;
     a.loss_part[blockIdx.x] = lst;
   }
+  ST_ADD(0);
+  ST_FLUSH(7);
 }
 
 template <bool NT, bool NT_OUT>
@@ -589,6 +673,12 @@ __global__ __launch_bounds__(512) void deepfm_step_kernel(StepArgs a) {
 }
 
 }  // namespace
+
+#ifdef RM_STEP_STAMP
+extern "C" int rm_debug_step_stamps(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rm_step_stamp_buf), sizeof(unsigned long long) * n);
+}
+#endif
 
 extern "C" int64_t rm_deepfm_step_workspace(int F, int Dn) {
   const int Kp = ((16 * F + Dn + 63) / 64) * 64;
