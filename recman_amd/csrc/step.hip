@@ -12,24 +12,27 @@
 //  * waves 0..6 are WORKERS.  A worker owns up to 4 of the 27 "field slots" (26 embedding fields of 16 k each + the
 //    dense inputs as a 16-k pseudo-field), i.e. a k-slice of layer 0: it keeps its slices of W0 in registers in both
 //    operand layouts (forward and dX: 2 x 8 registers per slot), keeps its rows of dW0 in accumulators for the whole
-//    kernel (8 registers per slot), and ONLY EVER touches its own fields of x.  x never crosses waves; what does is
-//    small: the partial h0 of a tile (2 KB per worker) and the tile's dh0 / g / g*S (5.6 KB).
+//    kernel (8 registers per slot), and ONLY EVER touches its own fields of x - including their part of the FM sums
+//    (S, sum of squares) and of the bias / linear-entry sums.  x never crosses waves; what does is small: a worker's
+//    partial sums of a tile (3.5 KB: h0, S, squares, bias + linear entries) and the tile's dh0 / g / g*S (5.6 KB).
 //  * the rows arrive by LDS-DMA (global_load_lds_dwordx4 with a per-lane source address: one instruction = the 16
-//    examples of one field, 64 bytes each), straight into a ring of 4 tile buffers, three tiles ahead of their use:
-//    no register is held by a row in flight and ~100 KB of lines are in flight per CU.  Lane (example r, piece p)
-//    fetches slice p ^ swz(r) of its row, which makes every later ds_read_b128 of "slice q of example n"
-//    conflict-free (position q ^ swz(n)) without padding the 64-byte rows.
-//  * wave 7 is the HEAD: per tile it sums the 7 partial h0, adds the FM sums (it reads the whole x tile from LDS),
-//    runs layer 1, the output projection, the FM / linear logits, PredictionLayer, the loss term, dLoss/dlogit and
-//    the dh chain, publishes dh0 (two layouts), g and g*S for the workers' backward, and accumulates every small
-//    gradient (dW1 on the matrix pipe, db0, db1, d w_out, sum g, g^T xd) in registers.  It also turns the tile's
-//    ids into row numbers three tiles ahead (the workers' DMA addresses) and gathers the bias / linear entries.
-//  * one workgroup barrier per tile.  Segment s (between barriers s-1 and s): workers run backward(s-2),
-//    issue the DMA of tile s+2 into the buffer backward(s-2) has just freed, then forward(s); the head runs
-//    epilogue(s-1) meanwhile.  forward(s) -> [barrier] -> epilogue(s) -> [barrier] -> backward(s): the head's serial
-//    chain (32 dependent MFMAs + the loss) always overlaps the workers' matrix work of the neighbouring tiles.
+//    examples of one field, 64 bytes each), straight into a ring of 3 tile buffers, more than a tile ahead of their
+//    use: no register is held by a row in flight.  Lane (example r, piece p) fetches slice p ^ swz(r) of its row,
+//    which makes every later ds_read_b128 of "slice q of example n" conflict-free (position q ^ swz(n)) without
+//    padding the 64-byte rows.  A field's DMA for tile s + 1 is issued the moment its backward of tile s - 2 has
+//    freed the slot - one piece at a time between the matrix work, not 27 pieces at once.
+//  * wave 7 is the HEAD: per tile it sums the 7 workers' partial sums, runs layer 1, the output projection, the FM /
+//    linear logits, PredictionLayer, the loss term, dLoss/dlogit and the dh chain, publishes dh0 (two layouts), g and
+//    g*S for the workers' backward, and accumulates every small gradient (dW1 on the matrix pipe, db0, db1, d w_out,
+//    sum g, g^T xd) in registers.  It also turns the ids into row numbers two tiles ahead (the workers' DMA addresses)
+//    and stages the dense inputs / labels.
+//  * one workgroup barrier per tile.  Segment s (between barriers s-1 and s): workers run backward(s-2) + the DMAs
+//    of tile s+1, then forward(s); the head runs epilogue(s-1) meanwhile.  forward(s) -> [barrier] -> epilogue(s) ->
+//    [barrier] -> backward(s): the head's serial chain (32 dependent MFMAs + the loss) always overlaps the workers'
+//    matrix work of the neighbouring tiles.
 //  * per-block partial sums (dW0 slab, small gradients, loss) go to the same finishing launch as rm_mlp_bwd's
 //    (mlp_finish_kernel): fixed order, deterministic.
+// Measured history and the per-wave phase times: profiles/r03_deepfm_step.md.
 #include "mlp_internal.h"
 #include "rm_common.h"
 
@@ -41,24 +44,26 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 constexpr int kWorkers = 7;   // waves 0..6; wave 7 is the head
 constexpr int kSlots = 4;     // field slots per worker
-constexpr int kXSlots = 27;   // 26 fields + the dense pseudo-field
-constexpr int kRing = 4;      // x tile buffers
+constexpr int kMaxF = 26;     // embedding fields (+ the dense pseudo-field = 27 slots over 7 workers: 4 4 4 3 4 4 4)
+constexpr int kRing = 3;      // x tile buffers
 constexpr int kSlotB = 1024;  // 16 examples x 64 bytes
-constexpr int kXBufB = kXSlots * kSlotB;
-constexpr int kPartB = 2048;  // one worker's partial h0 of a tile: [2 unit halves][64 lanes][4]
+constexpr int kXBufB = kMaxF * kSlotB;
+// one worker's partial sums of a tile: h0 [2 unit halves][64 lanes][4] | S [64][4] | squares [64] | bias/linear sums [64]
+constexpr int kPartH = 0, kPartS = 2048, kPartQ = 3072, kPartSd = 3328, kPartB = 3584;
 constexpr int kLDT = 36;      // row stride (floats) of the published [example][unit] image of dh0
 // published per tile by the head: dh0 in B-operand layout | dh0 as [example][unit] | g*S | g
 constexpr int kPubDh = 0, kPubDT = 2048, kPubGS = kPubDT + 16 * kLDT * 4, kPubG = kPubGS + 1024, kPubB = kPubG + 256;
 // LDS map (bytes)
-constexpr int oX = 0;                                 // [kRing][27][1024]
-constexpr int oPart = oX + kRing * kXBufB;            // [2][7][2048]
+constexpr int oX = 0;                                 // [kRing][26][1024] rows of the embedding fields
+constexpr int oDense = oX + kRing * kXBufB;           // [4][1024] the dense pseudo-field (written by the head)
+constexpr int oJunk = oDense + 4 * kSlotB;            // sink of the DMAs of empty slots (every worker issues 4 per tile)
+constexpr int oPart = oJunk + kSlotB;                 // [2][7][kPartB]
 constexpr int oPub = oPart + 2 * kWorkers * kPartB;   // [2][kPubB]
 constexpr int kRowB = 28 * 64;                        // row numbers of a tile: [28 field slots][16] u32 (the head writes 7 per lane)
 constexpr int oRow = oPub + 2 * kPubB;                // [2][kRowB]
 constexpr int oHT = oRow + 2 * kRowB;                 // [16][32] h0 as [example][unit]   (head only)
 constexpr int oD1T = oHT + 16 * 32 * 4;               // [16][32] dh1 as [example][unit]  (head only)
-constexpr int oSide = oD1T + 16 * 32 * 4;             // [4][16][2] (sum of bias entries, sum of linear entries)
-constexpr int oY = oSide + 4 * 16 * 2 * 4;            // [4][16] labels
+constexpr int oY = oD1T + 16 * 32 * 4;                // [4][16] labels
 constexpr int oW1 = oY + 4 * 16 * 4;                  // [32][32] W1[u][v], 16-byte block c of row u at position c ^ (u & 7)
 constexpr int oPar = oW1 + 32 * 32 * 4;               // b0 [32] | b1 [32] | w_out [32] | lin_w_dense [16] | field_off [28] (u32)
 constexpr int kParB0 = 0, kParB1 = 128, kParWo = 256, kParWd = 384, kParFo = 448;
@@ -66,7 +71,7 @@ constexpr int kLdsBytes = oPar + 448 + 28 * 4;
 static_assert(kLdsBytes <= 160 * 1024, "LDS map exceeds a CU");
 
 #ifndef RM_STEP_ABL
-#define RM_STEP_ABL 0  // ablation builds (wrong results): 1 no bias / linear entry loads, 2 no d_rows stores, 4 every row = row 0
+#define RM_STEP_ABL 0  // ablation builds (wrong results): 1 no bias / linear entry loads, 2 no d_rows stores, 4 every row = row 0, 8 no DMAs, 16 no worker MFMAs
 #endif
 // diagnostic build (-DRM_STEP_STAMP, never in the product library): every wave adds up the shader-clock ticks it spends
 // in its phases; rm_debug_step_stamps reads them (tools/probe/step_stamps.py).
@@ -116,6 +121,10 @@ __device__ __forceinline__ int slot_field(int w, int j) {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma16w(float a, float b, f32x4 c) {  // the workers' (ablation: a cheap stand-in)
+  if (RM_STEP_ABL & 16) { c.x += a * b; return c; }
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
 
 // Position of 16-byte slice j of example r's 64-byte row in LDS: j ^ swz(r).  ds_read_b128 serves a wave in the lane
 // groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with lane = (example n = lane & 15, slice q = lane >> 4) a
@@ -123,28 +132,20 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // four rows that share a bank window (n mod 4 equal) four different positions in either group.
 __device__ __forceinline__ int swz(int r) { return ((r >> 3) & 1) * 3; }
 
-__device__ __forceinline__ unsigned lds_addr(const void *p) {
-  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
-}
-
-// One LDS-DMA piece: lane l's 16 bytes at src land at LDS byte lds_dst + 16 l (lds_dst wave-uniform).  Invisible to
-// hipcc's s_waitcnt bookkeeping: the waits are the hand-counted WAIT_VM below.
+// One LDS-DMA piece: lane l's 16 bytes at src land at LDS address lds_dst + 16 l (lds_dst wave-uniform).  Through the
+// builtin, so that hipcc counts it among the wave's vector-memory operations (its own s_waitcnt for the worker's
+// register loads stay exact); hipcc does NOT order LDS reads behind it - that is wait_vm's job.
 template <bool NT>
-__device__ __forceinline__ void glds16(const void *src, unsigned lds_dst) {
-  unsigned keep;
-  if (NT)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+__device__ __forceinline__ void dma16(const char *src, char *lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_dst, 16, 0, NT ? 2 : 0);
 }
 
-// waits until at most `younger` (0..16) of this wave's vector-memory operations are outstanding
+// waits until at most `younger` (0..20) of this wave's vector-memory operations are outstanding
 __device__ __forceinline__ void wait_vm(int younger) {
 #define RM_WV(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
   switch (younger) {
-    RM_WV(16) RM_WV(15) RM_WV(14) RM_WV(13) RM_WV(12) RM_WV(11) RM_WV(10) RM_WV(9) RM_WV(8) RM_WV(7) RM_WV(6)
+    RM_WV(20) RM_WV(19) RM_WV(18) RM_WV(17) RM_WV(16) RM_WV(15) RM_WV(14) RM_WV(13) RM_WV(12) RM_WV(11) RM_WV(10) RM_WV(9) RM_WV(8) RM_WV(7) RM_WV(6)
     RM_WV(5) RM_WV(4) RM_WV(3) RM_WV(2) RM_WV(1)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
@@ -177,8 +178,7 @@ __device__ __forceinline__ float sum_n(float v) {  // over the 16 lanes (0..15, 
 
 // ---------------------------------------------------------------------------------------------- worker
 template <bool NT, bool NT_OUT>
-__device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const unsigned lds0, const int w,
-                                            const int lane, const int T) {
+__device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const int w, const int lane, const int T) {
   const int n = lane & 15, q = lane >> 4;
   const int F = a.F, H0 = a.H0, K = 16 * F + a.Dn;
   int fld[kSlots];
@@ -186,13 +186,11 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
   float w0f[kSlots][2][4];      // forward A operand: W0[kb + 4 q + ks][16 uh + n]
   float w0x[kSlots][2][4];      // dX A operand:      W0[kb + n][16 uh + 4 q + i]
   f32x4 dw[kSlots][2];          // dW0[kb + 4 q + i][16 uh + n]
-  int nd = 0;                   // embedding fields of this worker = LDS-DMA instructions per tile
 #pragma unroll
   for (int j = 0; j < kSlots; ++j) {
     const int f = slot_field(w, j);
     sv[j] = f >= 0 && (f < F || (f == F && a.Dn > 0));
     sx[j] = f >= 0 && f < F;
-    nd += sx[j] ? 1 : 0;
     fld[j] = sv[j] ? f : 0;
     const int kb = 16 * fld[j];
 #pragma unroll
@@ -212,103 +210,151 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
     }
   }
   const int64_t tstride = gridDim.x;
+  // this lane's piece of a row: DMA lane (example lane >> 2, position lane & 3); the bias / linear entry it sums
+  // (floats 16 / 17 of the row: lanes with (lane & 1) == 0 take the bias entry, the others the linear weight)
+  const int piece = 16 * ((lane & 3) ^ swz(lane >> 2));
+  const int side_off = 64 + 4 * (lane & 1);
+  float sdv[kSlots];  // bias / linear entries of the tile whose rows are in flight
+#pragma unroll
+  for (int j = 0; j < kSlots; ++j) sdv[j] = 0.f;
   ST_DECL;
   ST_ADD(0);  // prologue
 
-  for (int s = -3; s <= T + 1; ++s) {
-    // ------------------------------------------------------------ backward of tile s - 2
-    if (s - 2 >= 0 && s - 2 < T) {
-      const int t = s - 2;
-      const int64_t ex0 = ((int64_t)blockIdx.x + t * tstride) * 16;
-      const char *pub = smem + oPub + (t & 1) * kPubB;
-      const char *xb = smem + oX + (t & 3) * kXBufB;
-      f32x4 dhB[2];
-      float dT[2][4];
+  for (int s = -2; s <= T + 1; ++s) {
+    const bool hasB = s - 2 >= 0 && s - 2 < T;  // backward of tile s - 2 (4 d_rows stores)
+    const bool hasD = s + 1 >= 0 && s + 1 < T;  // rows of tile s + 1 (4 DMAs + 4 entry loads)
+    // ---- the bias / linear entries of tile s (loaded a segment ago), before their registers are loaded again
+    float side_sum = 0.f;
 #pragma unroll
-      for (int uh = 0; uh < 2; ++uh) {
-        dhB[uh] = *reinterpret_cast<const f32x4 *>(pub + kPubDh + (uh * 64 + lane) * 16);
+    for (int j = 0; j < kSlots; ++j) side_sum += sx[j] ? sdv[j] : 0.f;
+    // ------------------------------------------------------------ backward of tile s - 2, rows of tile s + 1
+    // Phases WITHOUT per-slot branches (one basic block each, so that hipcc interleaves the slots' MFMA chains and
+    // keeps their LDS reads in flight together): R read everything the backward needs of the 4 slots, D issue the
+    // DMAs / entry loads of tile s + 1 into the slots just read, M 64 MFMAs, S FM term + stores.  Empty slots run on
+    // field 0's data with zero weights (their dW0 accumulators are never stored, their d_rows store is dropped).
+    {
+      const int tb = s - 2, td = s + 1;
+      const char *pub = smem + oPub + (tb & 1) * kPubB;
+      const char *xb = smem + oX + ((tb + 6) % 3) * kXBufB;
+      char *xd = smem + oX + ((td + 3) % 3) * kXBufB;  // (the same buffer: tile s + 1 replaces tile s - 2)
+      f32x4 dhB[2], gS, e4[kSlots];
+      float dT[2][4], g, col[kSlots][4];
+      if (hasB) {  // ---- R
 #pragma unroll
-        for (int es = 0; es < 4; ++es)
-          dT[uh][es] = *reinterpret_cast<const float *>(pub + kPubDT + ((4 * es + q) * kLDT + 16 * uh + n) * 4);
-      }
-      const f32x4 gS = *reinterpret_cast<const f32x4 *>(pub + kPubGS + lane * 16);
-      const float g = *reinterpret_cast<const float *>(pub + kPubG + lane * 4);
-      const int64_t left = a.B - ex0;
-      const int rows_t = left < 16 ? (int)left : 16;
-      const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.d_rows + ex0 * F * 16, 0, rows_t * F * 64, 0x00020000);
-#pragma unroll
-      for (int j = 0; j < kSlots; ++j) {
-        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-        int off = 0x7ffffff0;  // out of range: the store is dropped (every tile issues the same number of them)
-        if (sv[j]) {           // wave-uniform
-          const char *xs = xb + fld[j] * kSlotB;
-          float col[4];
+        for (int j = 0; j < kSlots; ++j) {
+          const char *xs = sx[j] || !sv[j] ? xb + fld[j] * kSlotB : smem + oDense + (tb & 3) * kSlotB;
 #pragma unroll
           for (int es = 0; es < 4; ++es)  // x[example 4 es + q][k = n]: slice n >> 2 of that row
-            col[es] = *reinterpret_cast<const float *>(xs + (4 * es + q) * 64 + 16 * ((n >> 2) ^ swz(4 * es + q)) + 4 * (n & 3));
+            col[j][es] = *reinterpret_cast<const float *>(xs + (4 * es + q) * 64 + 16 * ((n >> 2) ^ swz(4 * es + q)) + 4 * (n & 3));
+          e4[j] = *reinterpret_cast<const f32x4 *>(xs + n * 64 + 16 * (q ^ swz(n)));
+        }
+#pragma unroll
+        for (int uh = 0; uh < 2; ++uh) {
+          dhB[uh] = *reinterpret_cast<const f32x4 *>(pub + kPubDh + (uh * 64 + lane) * 16);
+#pragma unroll
+          for (int es = 0; es < 4; ++es)
+            dT[uh][es] = *reinterpret_cast<const float *>(pub + kPubDT + ((4 * es + q) * kLDT + 16 * uh + n) * 4);
+        }
+        gS = *reinterpret_cast<const f32x4 *>(pub + kPubGS + lane * 16);
+        g = *reinterpret_cast<const float *>(pub + kPubG + lane * 4);
+      }
+      ST_ADD(1);  // R
+      // ---- D, M, S interleaved: a vector-memory instruction waits for a slot of the CU's memory pipeline (the
+      // younger waves of a SIMD pair sat up to 6,000 cycles per tile in a burst of 8 of them, tools/probe/
+      // step_stamps.py) - issued one at a time between groups of 16 MFMAs, the wait runs under the matrix work
+      unsigned rid[kSlots];
+      if (hasD) {
+        const unsigned *rowid = reinterpret_cast<const unsigned *>(smem + oRow + (td & 1) * kRowB);
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) rid[j] = rowid[fld[j] * 16 + (lane >> 2)];
+      }
+      // the old rows have been READ (their values are in registers) before the new ones are requested
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int64_t ex0 = ((int64_t)blockIdx.x + tb * tstride) * 16;
+      const int64_t left = a.B - ex0;
+      const int rows_t = left < 16 ? (int)left : 16;
+      const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.d_rows + (hasB ? ex0 * F * 16 : 0), 0,
+                                                          hasB ? rows_t * F * 64 : 0, 0x00020000);
+      f32x4 acc[kSlots];
+#pragma unroll
+      for (int j = 0; j < kSlots; ++j) {
+        if (hasD) {
+          // empty slots fetch row 0 into the sink: every worker issues the same operations per tile, so the
+          // hand-counted wait of the forward holds for all of them
+          const char *row = a.table + ((RM_STEP_ABL & 4) || !sx[j] ? 0 : (int64_t)rid[j] * a.row_bytes);
+          if (!(RM_STEP_ABL & 8)) dma16<NT>(row + piece, sx[j] ? xd + fld[j] * kSlotB : smem + oJunk);
+          if (!(RM_STEP_ABL & 1)) sdv[j] = *reinterpret_cast<const float *>(row + side_off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (hasB) {
+          acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int es = 0; es < 4; ++es) {
-            dw[j][0] = mfma16(col[es], dT[0][es], dw[j][0]);
-            dw[j][1] = mfma16(col[es], dT[1][es], dw[j][1]);
-          }
-          if (sx[j]) {
-            const f32x4 e4 = *reinterpret_cast<const f32x4 *>(xs + n * 64 + 16 * (q ^ swz(n)));
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int uh = 0; uh < 2; ++uh)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc = mfma16(w0x[j][uh][i], dhB[uh][i], acc);
-            // dLoss/dE = dX + g (S - E)   (FM second order, layers.py:468-476)
-            o.x = acc.x + (gS.x - g * e4.x);
-            o.y = acc.y + (gS.y - g * e4.y);
-            o.z = acc.z + (gS.z - g * e4.z);
-            o.w = acc.w + (gS.w - g * e4.w);
-            if (!(RM_STEP_ABL & 2)) off = (n * F + fld[j]) * 64 + 16 * q;
+            dw[j][0] = mfma16w(col[j][es], dT[0][es], dw[j][0]);
+            dw[j][1] = mfma16w(col[j][es], dT[1][es], dw[j][1]);
+            acc[j] = mfma16w(w0x[j][0][es], dhB[0][es], acc[j]);
+            acc[j] = mfma16w(w0x[j][1][es], dhB[1][es], acc[j]);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (hasB && j > 0) {
+          // the PREVIOUS slot's row gradient: dLoss/dE = dX + g (S - E)   (FM second order, layers.py:468-476);
+          // slots without an embedding field: out of range, the store is dropped - every tile issues 4 of them
+          const int i = j - 1;
+          f32x4 o;
+          o.x = acc[i].x + (gS.x - g * e4[i].x);
+          o.y = acc[i].y + (gS.y - g * e4[i].y);
+          o.z = acc[i].z + (gS.z - g * e4[i].z);
+          o.w = acc[i].w + (gS.w - g * e4[i].w);
+          const int off = (sx[i] && !(RM_STEP_ABL & 2)) ? (n * F + fld[i]) * 64 + 16 * q : 0x7ffffff0;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, off, 0, NT_OUT ? 2 : 0);
+        }
+      }
+      if (hasB) {
+        const int i = kSlots - 1;
+        f32x4 o;
+        o.x = acc[i].x + (gS.x - g * e4[i].x);
+        o.y = acc[i].y + (gS.y - g * e4[i].y);
+        o.z = acc[i].z + (gS.z - g * e4[i].z);
+        o.w = acc[i].w + (gS.w - g * e4[i].w);
+        const int off = (sx[i] && !(RM_STEP_ABL & 2)) ? (n * F + fld[i]) * 64 + 16 * q : 0x7ffffff0;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, off, 0, NT_OUT ? 2 : 0);
       }
     }
-    ST_ADD(1);  // backward
-    // ------------------------------------------------------------ rows of tile s + 2 (into the buffer just freed)
-    if (s + 2 >= 0 && s + 2 < T) {
-      const int t = s + 2;
-      const unsigned *rowid = reinterpret_cast<const unsigned *>(smem + oRow + (t & 1) * kRowB);
-      const unsigned xdst = lds0 + oX + (t & 3) * kXBufB;
-      const int piece = 16 * ((lane & 3) ^ swz(lane >> 2));
-      // (all row numbers first, then the DMAs back to back: the asm statements are memory barriers for hipcc, a read
-      // placed between them waits out its LDS round trip before the next piece is issued)
-      unsigned rid[kSlots];
-#pragma unroll
-      for (int j = 0; j < kSlots; ++j) rid[j] = rowid[fld[j] * 16 + (lane >> 2)];
-#pragma unroll
-      for (int j = 0; j < kSlots; ++j)
-        if (sx[j])  // wave-uniform
-          glds16<NT>(a.table + ((RM_STEP_ABL & 4) ? 0 : (int64_t)rid[j] * a.row_bytes) + piece, xdst + fld[j] * kSlotB);
-    }
-    ST_ADD(2);  // DMA issue
+    ST_ADD(6);  // M + S
     // ------------------------------------------------------------ forward of tile s
     if (s >= 0 && s < T) {
-      // the tile's DMAs were the last vector-memory operations of segment s - 2; younger: segment s - 1's and this
-      // segment's 4 stores + nd DMAs each, where they exist
-      const int younger = 4 * ((s - 3 >= 0 ? 1 : 0) + (s - 2 >= 0 ? 1 : 0)) + nd * ((s + 1 < T ? 1 : 0) + (s + 2 < T ? 1 : 0));
+      // the tile's last DMA (slot 3, segment s - 1) is followed by that slot's entry load and the segment's last two
+      // stores (slots 2 and 3), then by this segment's operations
+      const int younger = 1 + ((s - 3 >= 0) ? 2 : 0) + 4 * (2 * (hasD ? 1 : 0) + (hasB ? 1 : 0));
       wait_vm(younger);
       ST_ADD(3);  // wait for the tile's rows
-      const char *xb = smem + oX + (s & 3) * kXBufB;
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const char *xb = smem + oX + (s % 3) * kXBufB;
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, S = acc0, Q = acc0;
+      f32x4 x4[kSlots];
 #pragma unroll
-      for (int j = 0; j < kSlots; ++j)
-        if (sv[j]) {
-          const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xb + fld[j] * kSlotB + n * 64 + 16 * (q ^ swz(n)));
+      for (int j = 0; j < kSlots; ++j) {
+        const char *xs = sx[j] || !sv[j] ? xb + fld[j] * kSlotB : smem + oDense + (s & 3) * kSlotB;
+        x4[j] = *reinterpret_cast<const f32x4 *>(xs + n * 64 + 16 * (q ^ swz(n)));
+      }
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            acc0 = mfma16(w0f[j][0][ks], x4[ks], acc0);
-            acc1 = mfma16(w0f[j][1][ks], x4[ks], acc1);
-          }
+      for (int j = 0; j < kSlots; ++j) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          acc0 = mfma16w(w0f[j][0][ks], x4[j][ks], acc0);
+          acc1 = mfma16w(w0f[j][1][ks], x4[j][ks], acc1);
         }
+        // FM sums of this worker's fields (layers.py:467-476): slice q of example n
+        const float m = sx[j] ? 1.f : 0.f;
+        S += m * x4[j];
+        Q += m * (x4[j] * x4[j]);
+      }
       char *part = smem + oPart + ((s & 1) * kWorkers + w) * kPartB;
-      *reinterpret_cast<f32x4 *>(part + lane * 16) = acc0;
-      *reinterpret_cast<f32x4 *>(part + (64 + lane) * 16) = acc1;
+      *reinterpret_cast<f32x4 *>(part + kPartH + lane * 16) = acc0;
+      *reinterpret_cast<f32x4 *>(part + kPartH + (64 + lane) * 16) = acc1;
+      *reinterpret_cast<f32x4 *>(part + kPartS + lane * 16) = S;
+      *reinterpret_cast<float *>(part + kPartQ + lane * 4) = (Q.x + Q.y) + (Q.z + Q.w);
+      *reinterpret_cast<float *>(part + kPartSd + lane * 4) = side_sum;
     }
     ST_ADD(4);  // forward
     __syncthreads();
@@ -324,7 +370,7 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
         for (int i = 0; i < 4; ++i)
           a.dW0_part[((int64_t)blockIdx.x * a.Kp + 16 * fld[j] + 4 * q + i) * 32 + 16 * uh + n] = dw[j][uh][i];
     }
-  ST_ADD(6);
+  ST_ADD(0);
   ST_FLUSH(w);
 }
 
@@ -360,9 +406,6 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
   const float *w1s = reinterpret_cast<const float *>(smem + oW1);
   const char *par = smem + oPar;
   const float w0o = a.w0_out[0], lw0 = a.lin_w0[0];
-  // this lane's fields q + 4 j (ids -> row numbers, bias / linear entries).  Everything about them is UNCONDITIONAL:
-  // fields past F read field F - 1 again and are dropped by a select where they are summed (per-lane branches around
-  // the loads made hipcc serialise them behind s_waitcnt vmcnt(0): 7 exposed HBM round trips per tile)
 
   // ---- accumulators of the small gradients
   f32x4 dW1[2][2];
@@ -381,21 +424,19 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
     const int64_t b = ((int64_t)blockIdx.x + t * tstride) * 16 + n;
     return b < B ? b : B - 1;
   };
-  // prefetch registers
-  unsigned idr[7];  // ids (low words) of tile s + 3, loaded one segment earlier
-  float2 sdr[7];    // (bias, linear) entries of tile s + 2
+  // prefetch registers.  Everything about this lane's fields q + 4 j is UNCONDITIONAL: fields past F read field
+  // F - 1 again and land in row-number slots nobody reads (per-lane branches around the loads made hipcc serialise
+  // them behind s_waitcnt vmcnt(0): 7 exposed HBM round trips per tile).  Loaded values are used RAW a segment
+  // later: a select or conversion next to a load waits for it - and for every load issued before it.
+  unsigned idr[7];  // ids (low words: row numbers < 2^32) of tile s + 2, loaded one segment earlier
   float dnr[4];     // dense columns 4 q .. 4 q + 3 of tile s + 1
-  unsigned yr = 0;  // ... and its label, RAW (low word of the int64 / the float's bits): converting it where it is
-                    // loaded put an s_waitcnt vmcnt(0) behind this segment's loads - 5,000 cycles per tile
+  unsigned yr = 0;  // ... and its label (low word of the int64 / the float's bits)
 #pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    idr[j] = 0;
-    sdr[j] = make_float2(0.f, 0.f);
-  }
+  for (int j = 0; j < 7; ++j) idr[j] = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) dnr[i] = 0.f;
   auto load_ids = [&](int t) {
-    const unsigned *p = reinterpret_cast<const unsigned *>(a.idx + ex_of(t) * F);  // low words (row numbers < 2^32)
+    const unsigned *p = reinterpret_cast<const unsigned *>(a.idx + ex_of(t) * F);
 #pragma unroll
     for (int j = 0; j < 7; ++j) idr[j] = p[2 * (q + 4 * j < F ? q + 4 * j : F - 1)];
   };
@@ -403,50 +444,38 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
   ST_DECL;
   ST_ADD(0);
 
-  for (int s = -3; s <= T + 1; ++s) {
+  for (int s = -2; s <= T + 1; ++s) {
     // ------------------------------------------------------------ epilogue of tile s - 1
     if (s - 1 >= 0 && s - 1 < T) {
       const int t = s - 1;
       const int64_t bex = ((int64_t)blockIdx.x + t * tstride) * 16 + n;
       const bool valid = bex < B;
-      const char *xb = smem + oX + (t & 3) * kXBufB;
-      // partial h0 of the 7 workers, fixed order
-      f32x4 pre[2];
-      pre[0] = pre[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // the 7 workers' partial sums, fixed order: h0 (pre-activation), FM sums, bias / linear entries
+      f32x4 pre[2], S = f32x4{0.f, 0.f, 0.f, 0.f};
+      pre[0] = pre[1] = S;
+      float ss = 0.f, y1 = 0.f, ls = 0.f;
 #pragma unroll
       for (int w = 0; w < kWorkers; ++w) {
         const char *part = smem + oPart + ((t & 1) * kWorkers + w) * kPartB;
-        pre[0] += *reinterpret_cast<const f32x4 *>(part + lane * 16);
-        pre[1] += *reinterpret_cast<const f32x4 *>(part + (64 + lane) * 16);
-        if (w == 3) __builtin_amdgcn_sched_barrier(0);  // (two batches of reads: 14 in flight cost 56 registers)
+        pre[0] += *reinterpret_cast<const f32x4 *>(part + kPartH + lane * 16);
+        pre[1] += *reinterpret_cast<const f32x4 *>(part + kPartH + (64 + lane) * 16);
+        S += *reinterpret_cast<const f32x4 *>(part + kPartS + lane * 16);
+        ss += *reinterpret_cast<const float *>(part + kPartQ + lane * 4);
+        const float2 sd = *reinterpret_cast<const float2 *>(part + kPartSd + 16 * n);  // DMA lanes 4 n, 4 n + 1
+        y1 += sd.x;
+        ls += sd.y;
+        if (w == 3) __builtin_amdgcn_sched_barrier(0);  // (two batches of reads)
       }
-      __builtin_amdgcn_sched_barrier(0);
-      // FM sums over the fields: this lane's slice q of example n
-      f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f};
-      float ss = 0.f;
-      const int xo = n * 64 + 16 * (q ^ swz(n));
-      // (groups of 4 reads in flight, then the remainder)
-      f32x4 Q = f32x4{0.f, 0.f, 0.f, 0.f};  // per-component sums of squares
-      int f0 = 0;
-      for (; f0 + 4 <= F; f0 += 4) {
-        f32x4 e[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = *reinterpret_cast<const f32x4 *>(xb + (f0 + i) * kSlotB + xo);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          S += e[i];
-          Q += e[i] * e[i];
-        }
-      }
-      for (; f0 < F; ++f0) {
-        const f32x4 e = *reinterpret_cast<const f32x4 *>(xb + f0 * kSlotB + xo);
-        S += e;
-        Q += e * e;
-      }
-      ss = (Q.x + Q.y) + (Q.z + Q.w);
-      f32x4 dn4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (Dn > 0) dn4 = *reinterpret_cast<const f32x4 *>(xb + F * kSlotB + xo);
-      ST_ADD(1);  // partial sums + FM sums
+      const f32x4 dn4 = Dn > 0 ? *reinterpret_cast<const f32x4 *>(smem + oDense + (t & 3) * kSlotB + n * 64 + 16 * (q ^ swz(n)))
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+      // FM and linear logits (their reductions ahead of the layer-1 MFMAs)
+      const f32x4 wdv = *reinterpret_cast<const f32x4 *>(par + kParWd + 16 * q);
+      const float fmq = sum_q(S.x * S.x + S.y * S.y + S.z * S.z + S.w * S.w - ss);
+      const float lind = sum_q(dn4.x * wdv.x + dn4.y * wdv.y + dn4.z * wdv.z + dn4.w * wdv.w);
+      const float fm = y1 + 0.5f * fmq;
+      const float lin = ls + lind + lw0;
+      const float ty = *reinterpret_cast<const float *>(smem + oY + ((t & 3) * 16 + n) * 4);
+      ST_ADD(1);  // partial sums
       // layer 0 activation; h0 as [example][unit] for dW1
       float h0[2][4], h1[2][4];
 #pragma unroll
@@ -483,13 +512,6 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
         }
       }
       dnn = sum_q(dnn) + w0o;
-      // FM and linear logits
-      const float fmq = sum_q(S.x * S.x + S.y * S.y + S.z * S.z + S.w * S.w - ss);
-      const float2 sd = *reinterpret_cast<const float2 *>(smem + oSide + ((t & 3) * 16 + n) * 8);
-      const float fm = sd.x + 0.5f * fmq;
-      const f32x4 wdv = *reinterpret_cast<const f32x4 *>(par + kParWd + 16 * q);
-      const float lin = sd.y + sum_q(dn4.x * wdv.x + dn4.y * wdv.y + dn4.z * wdv.z + dn4.w * wdv.w) + lw0;
-      const float ty = *reinterpret_cast<const float *>(smem + oY + ((t & 3) * 16 + n) * 4);
       // PredictionLayer + loss (rm_logit_loss's arithmetic, same order of the branch sum)
       float z = 0.f;
       z += lin;
@@ -572,38 +594,22 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
     // ------------------------------------------------------------ the prefetch chain: FIRST everything that consumes
     // registers loaded one segment ago, THEN this segment's loads (a conservative s_waitcnt vmcnt(0) in front of a
     // consumer must not find loads that have only just been issued)
-    if (s + 2 >= 0 && s + 2 < T) {  // bias / linear entries of tile s + 2 -> LDS
-      float y1 = 0.f, ls = 0.f;
-#pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        y1 += q + 4 * j < F ? sdr[j].x : 0.f;
-        ls += q + 4 * j < F ? sdr[j].y : 0.f;
-      }
-      y1 = sum_q(y1);
-      ls = sum_q(ls);
-      if (q == 0) *reinterpret_cast<float2 *>(smem + oSide + (((s + 2) & 3) * 16 + n) * 8) = make_float2(y1, ls);
-    }
-    if (s + 1 >= 0 && s + 1 < T) {  // dense inputs / label of tile s + 1 -> LDS
+    if (s + 1 >= 0 && s + 1 < T) {  // dense inputs / label of tile s + 1 -> LDS (columns past Dn masked here)
       const int t = s + 1;
-      if (Dn > 0)  // (columns past Dn are masked HERE, a segment after the load: a select next to the load waits for it)
-        *reinterpret_cast<f32x4 *>(smem + oX + (t & 3) * kXBufB + F * kSlotB + n * 64 + 16 * (q ^ swz(n))) =
+      if (Dn > 0)
+        *reinterpret_cast<f32x4 *>(smem + oDense + (t & 3) * kSlotB + n * 64 + 16 * (q ^ swz(n))) =
             f32x4{4 * q + 0 < Dn ? dnr[0] : 0.f, 4 * q + 1 < Dn ? dnr[1] : 0.f, 4 * q + 2 < Dn ? dnr[2] : 0.f,
                   4 * q + 3 < Dn ? dnr[3] : 0.f};
       if (q == 0)
         *reinterpret_cast<float *>(smem + oY + ((t & 3) * 16 + n) * 4) = a.y ? (float)(int)yr : __uint_as_float(yr);
     }
-    unsigned rid[7];
-    if (s + 3 < T) {  // row numbers of tile s + 3 -> LDS (slots >= F: never read)
-      unsigned *rowid = reinterpret_cast<unsigned *>(smem + oRow + ((s + 3) & 1) * kRowB);
+    if (s + 2 < T) {  // row numbers of tile s + 2 -> LDS (slots >= F: never read)
+      unsigned *rowid = reinterpret_cast<unsigned *>(smem + oRow + ((s + 2) & 1) * kRowB);
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        rid[j] = idr[j] + *reinterpret_cast<const unsigned *>(par + kParFo + (q + 4 * j) * 4);
-        rowid[(q + 4 * j) * 16 + n] = rid[j];
-      }
+      for (int j = 0; j < 7; ++j)
+        rowid[(q + 4 * j) * 16 + n] = idr[j] + *reinterpret_cast<const unsigned *>(par + kParFo + (q + 4 * j) * 4);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // (issue order: the registers whose last consumer sits behind another guard first - hipcc protects their re-load
-    // with a conservative s_waitcnt, which must not find this segment's other loads already in flight)
     if (s + 2 >= 0 && s + 2 < T) {
       const int64_t b = ex_of(s + 2);
       if (Dn > 0) {
@@ -614,12 +620,7 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
       const unsigned *yp = a.y ? reinterpret_cast<const unsigned *>(a.y + b) : reinterpret_cast<const unsigned *>(a.y_f + b);
       yr = *yp;
     }
-    if (s + 4 < T) load_ids(s + 4);
-    if (s + 3 < T) {  // ... and its bias / linear entries
-#pragma unroll
-      for (int j = 0; j < 7; ++j)
-        if (!(RM_STEP_ABL & 1)) sdr[j] = *reinterpret_cast<const float2 *>(a.table + (int64_t)rid[j] * a.row_bytes + 64);
-    }
+    if (s + 3 < T) load_ids(s + 3);
     ST_ADD(6);  // prefetch chain
     __syncthreads();
     ST_ADD(5);  // barrier
@@ -666,10 +667,18 @@ __global__ __launch_bounds__(512) void deepfm_step_kernel(StepArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t ntiles = (a.B + 15) / 16;
   const int T = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);  // tiles blockIdx.x + i gridDim.x
-  if (wave < kWorkers)
-    step_worker<NT, NT_OUT>(a, smem, lds_addr(smem), wave, lane, T);
-  else
+#ifndef RM_STEP_PRIO
+#define RM_STEP_PRIO 1
+#endif
+  if (wave < kWorkers) {
+    // static priority for the younger half: waves 4..6 lose every arbitration (issue ports, the vector-memory queue)
+    // against their SIMD partners 0..2 otherwise and run their phases AFTER them instead of beside them
+    if (RM_STEP_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    step_worker<NT, NT_OUT>(a, smem, wave, lane, T);
+  } else {
+    if (RM_STEP_PRIO) __builtin_amdgcn_s_setprio(2);  // the head's epilogue is one dependent chain: never make it queue
     step_head(a, smem, lane, T);
+  }
 }
 
 }  // namespace

@@ -32,7 +32,7 @@ n = 256 * 8
 buf = (ctypes.c_ulonglong * (8 * n))()
 assert lib.rm_debug_step_stamps(buf, 8 * n) == 0
 s = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8, 8).astype(np.float64)
-names_w = ["prologue", "backward", "dma issue", "row wait", "forward", "barrier", "final", "total"]
+names_w = ["pro+epilogue", "bwd reads", "dma issue", "row wait", "forward", "barrier", "bwd mfma+store", "total"]
 names_h = ["pro+epilogue", "partial+FM", "L1+loss", "chain+publish", "small grads", "barrier", "prefetch", "total"]
 print("ticks are shader-clock cycles (s_memtime); mean over the 256 blocks")
 for wv in range(8):
