@@ -247,7 +247,8 @@ int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const i
  *   dLoss/dlogit: the per-occurrence gradient of the bias-table and sparse linear entries), loss [1] (mean over B,
  *   no l2 terms), dW[l] / db[l] (db may be NULL), d_w_out [H1], d_w0_out [1], d_lin_w_dense [Dn], d_lin_w0 [1].
  * workspace: rm_deepfm_step_workspace(F, Dn) floats.  flags: bit 0 = non-temporal row loads
- *   (RM_EMBED_STREAM_ROWS), bit 1 = non-temporal d_rows stores (only when nothing re-reads them soon).
+ *   (RM_EMBED_STREAM_ROWS), bit 1 = non-temporal d_rows stores (only when nothing re-reads them soon), bit 2 = skip
+ *   the finishing launch (measurement only: the parameter gradients and the loss are then NOT written).
  * Deterministic (fixed summation orders, no float atomics). */
 int rm_deepfm_step_supported(int F, int D, int64_t table_ld, int Dn, int NL, const int *H);
 int64_t rm_deepfm_step_workspace(int F, int Dn);

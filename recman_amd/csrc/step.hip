@@ -745,6 +745,7 @@ extern "C" int rm_deepfm_step(const int64_t *idx, const float *table, int64_t ta
   else { if (nt_out) RM_STEP(false, true) else RM_STEP(false, false) }
 #undef RM_STEP
   RM_CHECK_LAUNCH("rm_deepfm_step");
+  if (flags & 4) return RM_OK;  // (measurement: the step kernel alone, the per-block partial sums stay in the workspace)
   return rm_internal_mlp_finish(a.dW0_part, nblk, K, Kp, H[0], dW[0], a.sg_part, nblk, 2, H, dW, db, d_w_out,
                                 d_w0_out, Dn > 0 ? d_lin_w_dense : nullptr, d_lin_w0, Dn, a.loss_part, nblk, B, loss,
                                 st);

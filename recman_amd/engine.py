@@ -695,23 +695,31 @@ class Engine:
                 t_now.synchronize()
                 if t_warm.elapsed_time(t_now) >= 40.0:
                     break
+            iters_p = max(iters, 50) if p["bound"] == "hbm" else iters  # (the MFMA kernels take milliseconds each)
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                  for _ in range(iters)]
+                  for _ in range(iters_p)]
             for a, b in ev:
                 a.record()
                 fn()
                 b.record()
             torch.cuda.synchronize()
-            ms = sum(a.elapsed_time(b) for a, b in ev) / iters
+            ts = sorted(a.elapsed_time(b) for a, b in ev)
+            ms = sum(ts) / len(ts)
             if p["bound"] == "hbm":
                 achieved, peak, unit = p["work"] / (ms * 1e-3) / 1e9, 8000.0, "GB/s"
             else:
                 achieved, peak, unit = p["work"] / (ms * 1e-3) / 1e12, 157.3, "TFLOP/s"
-            out.append({"kernel": p["name"], "symbol": p["symbol"], "bound": p["bound"],
-                        "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                        "frac": round(achieved / peak, 4), "traffic": None,
-                        "avg_launch_us": round(ms * 1e3, 2), "algorithmic_per_launch": p["work"],
-                        "timing": f"hipEvent pairs, {iters} launches"})
+            rec = {"kernel": p["name"], "symbol": p["symbol"], "bound": p["bound"],
+                   "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                   "frac": round(achieved / peak, 4), "traffic": None,
+                   "avg_launch_us": round(ms * 1e3, 2), "min_launch_us": round(ts[0] * 1e3, 2),
+                   "median_launch_us": round(ts[len(ts) // 2] * 1e3, 2), "algorithmic_per_launch": p["work"],
+                   "timing": f"hipEvent pairs, {iters_p} launches (mean; min and median beside it)"}
+            if "work_min" in p:
+                # the same launch priced on the bytes the fused kernel itself has to move
+                rec["algorithmic_min_per_launch"] = p["work_min"]
+                rec["frac_min"] = round(p["work_min"] / (ms * 1e-3) / 1e9 / 8000.0, 4)
+            out.append(rec)
         return out
 
     def roofline_probe(self, idx, dense, y, iters=20):
@@ -848,7 +856,7 @@ class Engine:
 
 
 # DeepFM's fwd_bwd through rm_deepfm_step (one kernel) where it applies; False = rm_embed_mlp_fwd + rm_mlp_bwd
-STEP_FUSION_DEFAULT = False
+STEP_FUSION_DEFAULT = True
 
 
 class DeepFMEngine(Engine):
@@ -928,12 +936,7 @@ class DeepFMEngine(Engine):
             self._step_ok = bool(ops.deepfm_step_supported(self.F, self.D, self.LD, self.Dn, self.mlp.hidden))
         return self._step_ok
 
-    def fwd_bwd(self, idx, dense, y, masks=None, mv=None):
-        B = idx.shape[0]
-        self._alloc(B)
-        if not self._step_fused(masks, mv):
-            return super().fwd_bwd(idx, dense, y, masks=masks, mv=mv)
-        self._mv = None
+    def _step_call(self, idx, dense, y, skip_finish=False):
         mlp, p, g = self.mlp, self.params, self.grads
         if getattr(self, "_step_ws", None) is None:
             self._step_ws = torch.zeros(ops.deepfm_step_workspace(self.F, self.Dn), dtype=F32, device=self.device)
@@ -946,19 +949,44 @@ class DeepFMEngine(Engine):
             [g[f"{pre}dnn_layer_{i}_weights"] for i in range(n)], [g[f"{pre}dnn_layer_{i}_bias"] for i in range(n)],
             g[f"{pre}dnn_w"].view(-1), g[f"{pre}dnn_w0"], g["linear_w_dense"] if self.Dn else None, g["linear_w0"],
             self._step_ws, grad_scale=getattr(self, "grad_scale", 1.0),
-            stream_rows=self.hp.get("table_row_reuse", "stream") == "stream",
-            stream_d_rows=self.hp.get("d_rows_reuse", "cache") == "stream")
+            # (plain row loads unless asked otherwise: the reason for streaming them - keeping E in the caches for the
+            # MLP kernels - is gone with E; measured 97 vs 102 us per step, uniform ids)
+            stream_rows=self.hp.get("step_row_loads", "cache") == "stream",
+            stream_d_rows=self.hp.get("d_rows_reuse", "cache") == "stream", skip_finish=skip_finish)
+
+    def fwd_bwd(self, idx, dense, y, masks=None, mv=None):
+        B = idx.shape[0]
+        self._alloc(B)
+        if not self._step_fused(masks, mv):
+            return super().fwd_bwd(idx, dense, y, masks=masks, mv=mv)
+        self._mv = None
+        self._step_call(idx, dense, y)
         self.d_bias = None
         self._head_done = self._lin_done = True
+        g = self.grads
         if self.Dn and self.lin_dense_mask is not None:
             g["linear_w_dense"].mul_(self.lin_dense_mask)  # linear_features subset
         reg = self.hp.get("deep_l2_reg", 0.0)
         if reg:
-            mlp.add_l2_grads(reg)
+            self.mlp.add_l2_grads(reg)
         return self._add_l2(self.loss)
 
     def roofline_probes(self, idx, dense, y):
         probes = super().roofline_probes(idx, dense, y)
+        self._alloc(idx.shape[0])
+        if self._step_fused(None, None):
+            # the step's dominant (only large) kernel.  Algorithmic bytes: SURVEY.md 8d's embed+FM forward AND
+            # backward figure, 8,952 B per example at F = 26, D = 16 (idx, rows, E, S, g, dE, gradient rows) - the
+            # path this kernel replaces end to end; `work_min` = what the fused kernel itself has to move (ids, 72
+            # useful bytes per looked-up row, dense inputs, labels in; row gradients, logit / pred / dlogit out)
+            B, F, D, Dn = idx.shape[0], self.F, self.D, self.Dn
+            fwd = B * F * (8 + 4 * D + 4) + B * 4 + B * F * 4 * D
+            bwd = B * F * (8 + 4 * D + 4 * D + 4 * D + 4) + B * 4
+            work_min = B * (F * (8 + 4 * D + 8) + 4 * Dn + y.element_size() + F * 4 * D + 3 * 4)
+            step = [dict(name="deepfm_step_kernel (rm_deepfm_step: gather + FM + linear + MLP + loss + every gradient)",
+                         symbol="deepfm_step_kernel", fn=lambda: self._step_call(idx, dense, y, skip_finish=True),
+                         work=fwd + bwd, work_min=work_min, bound="hbm")]
+            return step + probes
         if not self._front_fused({}, None):
             return probes
         # the step's dominant kernel is the one-kernel front; its algorithmic bytes = rm_embed_fwd's

@@ -407,8 +407,9 @@ def deepfm_step_workspace(F, Dn):
 
 def deepfm_step(idx, rows, field_off, D, table_ld, dense, y, Ws, bs, w_out, w0_out, lin_w_dense, lin_w0, act, task,
                 d_rows, logit, pred, dlogit, loss, dW, db, d_w_out, d_w0_out, d_lin_w_dense, d_lin_w0, workspace,
-                grad_scale=1.0, stream_rows=False, stream_d_rows=False):
-    """rm_deepfm_step: DeepFM's forward + every gradient in one kernel (+ the finishing reduction)."""
+                grad_scale=1.0, stream_rows=False, stream_d_rows=False, skip_finish=False):
+    """rm_deepfm_step: DeepFM's forward + every gradient in one kernel (+ the finishing reduction; skip_finish =
+    measurement only, the parameter gradients and the loss are then not written)."""
     B, F = idx.shape
     Dn = 0 if dense is None else dense.shape[1]
     H = [W.shape[1] for W in Ws]
@@ -435,7 +436,7 @@ def deepfm_step(idx, rows, field_off, D, table_ld, dense, y, Ws, bs, w_out, w0_o
               _chk(d_w_out, "d_w_out", F32, (H[-1],)), _chk(d_w0_out, "d_w0_out", F32, (1,)),
               _chk(d_lin_w_dense, "d_lin_w_dense", F32, (Dn,), allow_none=True),
               _chk(d_lin_w0, "d_lin_w0", F32, (1,)), _chk(workspace, "workspace", F32),
-              (1 if stream_rows else 0) | (2 if stream_d_rows else 0), _stream())
+              (1 if stream_rows else 0) | (2 if stream_d_rows else 0) | (4 if skip_finish else 0), _stream())
 
 
 def shard_route(idx, field_off, world, pos, send_ids, counts, workspace):
