@@ -726,12 +726,14 @@ class Engine:
         """The dominant kernel's roofline record (roofline_probe_all()[0])."""
         return self.roofline_probe_all(idx, dense, y, iters)[0]
 
-    def optimizer_probe(self, idx, iters=10):
+    def optimizer_probe(self, idx, iters=10, more_ids=()):
         """Times the separately-reported optimizer step on the gradients of the last fwd_bwd: the
         row-wise step on the touched table rows + the dense parameters in one launch; checks that two
-        identical steps from the same state give bit-identical tables."""
+        identical steps from the same state give bit-identical tables.  more_ids: further id batches -
+        the timed steps then cycle through all of them (every step touches other rows, as in fit())."""
         from .optim import FusedDenseOptimizer, SparseTableOptimizer
 
+        ids = [idx] + list(more_ids)
         sopt, dopt = SparseTableOptimizer(self, "adam", 1e-3), FusedDenseOptimizer(self, "adam", 1e-3)
         # determinism: the same step twice from the same state (rows + moments restored in between)
         rows0, mom0 = self.rows.clone(), sopt.mom.clone()
@@ -743,19 +745,20 @@ class Engine:
         sopt.step(idx)
         same = bool(torch.equal(self.rows, rows1) and torch.equal(sopt.mom, mom1))
         del rows0, mom0, rows1, mom1
-        for _ in range(3):
-            sopt.step(idx)
+        iters = max(iters, 2 * len(ids))
+        for i in range(3):
+            sopt.step(ids[i % len(ids)])
             dopt.step()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        for _ in range(iters):
-            sopt.step(idx)
+        for i in range(iters):
+            sopt.step(ids[i % len(ids)])
         ev[1].record()
         for _ in range(iters):
             dopt.step()
         ev[2].record()
-        for _ in range(iters):
-            sopt.prepare(idx)
+        for i in range(iters):
+            sopt.prepare(ids[i % len(ids)])
         ev[3].record()
         torch.cuda.synchronize()
         sopt._prepared = None
@@ -763,7 +766,7 @@ class Engine:
         ms_p = ev[2].elapsed_time(ev[3]) / iters
         return {"ms": round(ms_s + ms_d, 4), "sparse_rows_ms": round(ms_s, 4), "dense_params_ms": round(ms_d, 4),
                 "sort_ms": round(ms_p, 4), "apply_ms": round(ms_s - ms_p, 4),
-                "bit_identical_rerun": same,
+                "bit_identical_rerun": same, "id_batches_rotated": len(ids),
                 "what": "row-wise lazy Adam on the touched table rows (rm_sparse_optimizer_step: stable sort by "
                         "row, duplicates summed in occurrence order, no float atomics) + Adam on the dense "
                         "parameters in one launch (rm_dense_optimizer_step), timed back to back; sort_ms is the "
