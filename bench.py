@@ -109,6 +109,9 @@ def parse(argv=None):
                     help="do not start the rocprofv3 --pmc child passes (roofline.traffic then comes from "
                          "the committed profile, tagged traffic_live=false)")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # comma list of workloads
+    # (tests) the rank runtime alone, on CPU with gloo: every rank all_reduces in a loop; "die:R:K" makes rank R
+    # exit abruptly before iteration K, "raise:R:K" makes it raise there
+    ap.add_argument("--selftest-ranks", default="", help=argparse.SUPPRESS)
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent for indices (0 = uniform)")
     ap.add_argument("--cpu-budget", type=float, default=0.0,
                     help="seconds of CPU-baseline work per workload (default 20 for the contract line, "
@@ -585,6 +588,8 @@ def measure(a, wname, dev, rank, world, dist, rehearse, sharded, live_traffic, f
                    else "single GPU"},
         "roofline": roofs[0] if roofs else None,
     }
+    if sharded:
+        rec["exchange"] = exchange_record(engine, world, (dist.get_backend() if dist is not None else "none"), B, w)
     if len(roofs) > 1:
         rec["rooflines"] = roofs
     if w["model"] == "deepfm" and not sharded:
@@ -625,6 +630,169 @@ def measure(a, wname, dev, rank, world, dist, rehearse, sharded, live_traffic, f
     return rec
 
 
+RANK_TIMEOUT_S = float(os.environ.get("RECMAN_BENCH_TIMEOUT_S", "120"))  # collectives give up after this long
+
+
+def exchange_record(engine, world, backend, B, w):
+    """What a row-sharded step moves per GPU (recman_amd/dist.py): ids + rows out and gradient rows back through
+    all_to_all, the dense gradients through one flat all_reduce.  (W-1)/W of it crosses xGMI."""
+    n = B * w["F"]
+    fixed = engine.st.capacity_factor is not None
+    slots = world * engine.st.capacity(n) if fixed else n
+    width = (w["D"] + 4) * 4
+    a2a = slots * 8 + 2 * slots * width
+    dense = int(engine._flat_grads.numel()) * 4
+    remote = (world - 1) / world
+    return {"world_size": world, "backend": backend,
+            "layout": ("fixed-capacity buckets (equal splits, no host sync)" if fixed
+                       else "dynamic split sizes (a count all_to_all + one host sync per batch)"),
+            "micro_batches": engine.micro_batches, "occurrence_slots_per_gpu": slots,
+            "all_to_all_bytes_per_gpu_per_step": a2a, "of_which_cross_gpu": int(a2a * remote),
+            "dense_all_reduce_bytes": dense,
+            "what": "ids (8 B) + fused rows [D+4] out + gradient rows [D+4] back per occurrence slot; "
+                    "(W-1)/W of the all_to_all volume leaves the GPU"}
+
+
+def collect(a, rank, world, local, dist, rehearse, backend, live, pmc_note, fallback):
+    """Everything this rank measures -> the output record (rank 0 prints it)."""
+    dev = torch.device("cuda", local)
+    wname = a.workload or "deepfm"
+    sharded = world > 1 or a.force_sharded
+    plain = a.workload is None and not a.only and not a.batch and not a.vocab and a.zipf == 0
+    extras = plain and world == 1 and not a.force_sharded
+    bname = {"nccl": "nccl (RCCL over xGMI)", "gloo": "gloo (one-GPU rehearsal, host-staged)"}.get(
+        backend, backend) if backend else "none (single process)"
+
+    def sharded_sub(name, batch, steps, warm):
+        """One row-sharded sub-record at the current world size (per-GPU batch `batch`)."""
+        ab = argparse.Namespace(**vars(a))
+        ab.batch = batch
+        r = measure(ab, name, dev, rank, world, dist, rehearse, True, {}, {}, steps, warm, 0.0, want_cpu=False)
+        return _sub(r, steps=steps, warmup=warm)
+
+    rec = measure(a, wname, dev, rank, world, dist, rehearse, sharded, live, fallback, a.steps, a.warmup,
+                  a.cpu_budget or 20.0, zipf=a.zipf)
+    out = {
+        "metric": METRIC, "value": rec.pop("value"), "unit": rec.pop("unit"), "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": rec.pop("ms_per_step"),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "world_size": (dist.get_world_size() if dist is not None else 1), "backend": bname,
+    }
+    out.update(rec)
+    sub_steps, sub_warm = max(5, min(a.steps, 20)), max(2, min(a.warmup, 5))
+    if extras:
+        out["zipf"] = _sub(measure(a, "deepfm", dev, rank, world, dist, rehearse, False, {}, {}, a.steps,
+                                   a.warmup, 0.0, zipf=1.05, want_cpu=False, want_opt=False),
+                           note="the DeepFM workload with Zipf(1.05) ids; SURVEY.md 8d asks for both index "
+                                "distributions")
+        out["workloads"] = {}
+        for name in ("xdeepfm", "dcn"):
+            out["workloads"][name] = _sub(measure(a, name, dev, rank, world, dist, rehearse, False, live,
+                                                  fallback, sub_steps, sub_warm, a.cpu_budget or 12.0),
+                                          steps=sub_steps, warmup=sub_warm)
+    if plain and (extras or world > 1):
+        # BASELINE configs[4] - the workload the >= 6x target of north_star is about - through the row-sharded
+        # engine at THIS world size (N = 1: the first point of the scaling curve), weak scaling: the per-GPU batch
+        # is fixed.  Two per-GPU batches: 8192 (SURVEY.md 8d/8e: a global batch of 65536 over 8 GPUs) and 65536
+        # (configs[1-2]'s batch on every GPU).  For N > 1 also configs[2] (xDeepFM on the 26 M-row table).
+        wl = out.setdefault("workloads", {})
+        s5, w5 = max(3, min(sub_steps, 10)), 2
+        wl["xdeepfm_100m"] = _sub(sharded_sub("xdeepfm_100m", 8192, s5, w5),
+                                  note="per-GPU batch 8192 (weak scaling; SURVEY.md 8d/8e: global 65536 at 8 GPUs)")
+        wl["xdeepfm_100m_b65536"] = _sub(sharded_sub("xdeepfm_100m", 65536, s5, w5),
+                                         note="per-GPU batch 65536 (weak scaling)")
+        if world > 1:
+            wl["xdeepfm"] = sharded_sub("xdeepfm", 0, sub_steps, sub_warm)
+    if rank == 0 and world == 1:
+        out["pmc_passes"] = pmc_note
+    return out
+
+
+def rank_main(a, rank, world, local):
+    """One rank of the job (or the only process).  Fails FAST and LOUD: every collective gives up after
+    RANK_TIMEOUT_S, any exception ends this rank with a non-zero code, and rank 0 prints a JSON line with an
+    "error" field instead of a result - a rank that dies never leaves the others (and the driver) waiting."""
+    import datetime
+    import traceback
+
+    wname = a.workload or "deepfm"
+    sharded = world > 1 or a.force_sharded
+    extras = (a.workload is None and not a.only and world == 1 and not a.force_sharded
+              and not a.batch and not a.vocab and a.zipf == 0)
+    dist = backend = None
+    code = 0
+    try:
+        # ---- HBM traffic of the roofline kernels: rocprofv3 --pmc child passes, BEFORE any GPU call here ----
+        live, pmc_note = {}, "not requested"
+        full_size = not a.batch and not a.vocab and a.zipf == 0
+        if rank == 0 and world == 1 and not sharded and not a.no_pmc and full_size:
+            t0 = time.perf_counter()
+            live, pmc_note = pmc_passes(["deepfm", "xdeepfm", "dcn"] if extras else [wname])
+            pmc_note = pmc_note or f"ok ({time.perf_counter() - t0:.0f} s)"
+            if not live:
+                print(f"[bench] live PMC traffic unavailable: {pmc_note}", file=sys.stderr)
+        fallback = json.load(open(TRAFFIC_FALLBACK)) if os.path.exists(TRAFFIC_FALLBACK) else {}
+
+        # RECMAN_REHEARSE_ONE_GPU=1: every rank on GPU 0 with gloo (host-staged) collectives - a
+        # rehearsal of the multi-rank control flow on a one-GPU box, not a measurement
+        rehearse = os.environ.get("RECMAN_REHEARSE_ONE_GPU", "0") == "1"
+        if rehearse:
+            local = 0
+        if a.selftest_ranks:
+            import torch.distributed as dist
+
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=RANK_TIMEOUT_S))
+            kind, who, when = (a.selftest_ranks.split(":") + ["-1", "-1"])[:3]
+            t = torch.zeros(1)
+            for it in range(a.steps):
+                if rank == int(who) and it == int(when):
+                    if kind == "die":
+                        os._exit(9)
+                    raise RuntimeError("selftest: this rank fails here")
+                t += 1
+                dist.all_reduce(t)
+                time.sleep(0.05)
+            if rank == 0:
+                print(json.dumps({"metric": METRIC, "value": float(t), "n_gpus": world, "selftest": True}), flush=True)
+            dist.destroy_process_group()
+            return 0
+        torch.cuda.set_device(local)
+        if world > 1 or "RANK" in os.environ:
+            import torch.distributed as dist
+
+            to = datetime.timedelta(seconds=RANK_TIMEOUT_S)
+            if rehearse:
+                dist.init_process_group("gloo", timeout=to)
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=to)
+            backend = dist.get_backend()
+            assert dist.get_world_size() == world
+        out = collect(a, rank, world, local, dist, rehearse, backend, live, pmc_note, fallback)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+    except BaseException as e:  # noqa: BLE001 - SystemExit included: it must still become a line and a code
+        code = e.code if isinstance(e, SystemExit) and isinstance(e.code, int) and e.code else 1
+        msg = f"{type(e).__name__}: {str(e)[:400]}"
+        print(f"[bench] rank {rank} failed: {msg}", file=sys.stderr, flush=True)
+        traceback.print_exc(file=sys.stderr)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "examples/s", "n_gpus": world,
+                              "steps": a.steps, "warmup": a.warmup, "error": msg,
+                              "higher_is_better": True}), flush=True)
+        # no collective from here on: the peers may be gone.  os._exit skips the process-group destructor, which
+        # would wait for them
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(code)
+    if dist is not None:
+        import gc
+
+        gc.collect()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+    return code
+
+
 def main():
     a = parse()
     if a.pmc_child:
@@ -638,73 +806,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start one rank per GPU")
-    wname = a.workload or "deepfm"
-    sharded = world > 1 or a.force_sharded
-    extras = (a.workload is None and not a.only and world == 1 and not a.force_sharded
-              and not a.batch and not a.vocab and a.zipf == 0)
-
-    # ---- HBM traffic of the roofline kernels: rocprofv3 --pmc child passes, BEFORE any GPU call here ----
-    live, pmc_note = {}, "not requested"
-    full_size = not a.batch and not a.vocab and a.zipf == 0
-    if rank == 0 and world == 1 and not sharded and not a.no_pmc and full_size:
-        t0 = time.perf_counter()
-        live, pmc_note = pmc_passes(["deepfm", "xdeepfm", "dcn"] if extras else [wname])
-        pmc_note = pmc_note or f"ok ({time.perf_counter() - t0:.0f} s)"
-        if not live:
-            print(f"[bench] live PMC traffic unavailable: {pmc_note}", file=sys.stderr)
-    fallback = json.load(open(TRAFFIC_FALLBACK)) if os.path.exists(TRAFFIC_FALLBACK) else {}
-
-    # RECMAN_REHEARSE_ONE_GPU=1: every rank on GPU 0 with gloo (host-staged) collectives - a
-    # rehearsal of the multi-rank control flow on a one-GPU box, not a measurement
-    rehearse = os.environ.get("RECMAN_REHEARSE_ONE_GPU", "0") == "1"
-    if rehearse:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    backend = None
-    if world > 1 or "RANK" in os.environ:
-        import torch.distributed as dist
-
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-        backend = dist.get_backend()
-        assert dist.get_world_size() == world
-
-    rec = measure(a, wname, dev, rank, world, dist, rehearse, sharded, live, fallback, a.steps, a.warmup,
-                  a.cpu_budget or 20.0, zipf=a.zipf)
-    out = {
-        "metric": METRIC, "value": rec.pop("value"), "unit": rec.pop("unit"), "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": rec.pop("ms_per_step"),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "world_size": (dist.get_world_size() if dist is not None else 1),
-        "backend": ({"nccl": "nccl (RCCL over xGMI)", "gloo": "gloo (one-GPU rehearsal, host-staged)"}.get(
-            backend, backend) if backend else "none (single process)"),
-    }
-    out.update(rec)
-    if extras:
-        sub_steps, sub_warm = max(5, min(a.steps, 20)), max(2, min(a.warmup, 5))
-        out["zipf"] = _sub(measure(a, "deepfm", dev, rank, world, dist, rehearse, False, {}, {}, a.steps,
-                                   a.warmup, 0.0, zipf=1.05, want_cpu=False, want_opt=False),
-                           note="the DeepFM workload with Zipf(1.05) ids (cached row loads); SURVEY.md 8d asks "
-                                "for both index distributions")
-        out["workloads"] = {}
-        for name in ("xdeepfm", "dcn"):
-            out["workloads"][name] = _sub(measure(a, name, dev, rank, world, dist, rehearse, False, live,
-                                                  fallback, sub_steps, sub_warm, a.cpu_budget or 12.0),
-                                          steps=sub_steps, warmup=sub_warm)
-    if rank == 0 and world == 1:
-        out["pmc_passes"] = pmc_note
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        import gc
-
-        gc.collect()
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
+    sys.exit(rank_main(a, rank, world, local))
 
 
 def _sub(rec, **extra):

@@ -70,6 +70,38 @@ def test_real_torchrun_child_of_the_launcher_on_cpu(tmp_path):
     assert rec == {"metric": "x", "n_gpus": 2, "sum": 2.0}
 
 
+def _run_selftest(mode, timeout_env="20"):
+    import time
+
+    cmd = bench.launch_command(2, ["--gpus", "2", "--steps", "8", "--selftest-ranks", mode])
+    env = dict(os.environ, RECMAN_BENCH_TIMEOUT_S=timeout_env)
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, lines, time.time() - t0, r.stderr
+
+
+def test_rank_runtime_prints_one_line_when_every_rank_finishes():
+    rc, lines, _, err = _run_selftest("none")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1 and lines[0]["selftest"] is True and lines[0]["n_gpus"] == 2
+
+
+def test_a_rank_that_dies_mid_run_ends_the_job_quickly_with_a_nonzero_code():
+    """Rank 1 exits abruptly before its 4th collective: rank 0 must not sit in all_reduce for the backend's
+    default timeout (10-30 min, past the driver's limit) - the job ends non-zero well within 150 s, and if rank 0
+    got to report at all, its line carries an "error" field, never a value."""
+    rc, lines, dt, err = _run_selftest("die:1:3")
+    assert rc != 0 and dt < 150, (rc, dt, err[-2000:])
+    assert all(l.get("value") is None and "error" in l for l in lines), lines
+
+
+def test_a_rank_that_raises_mid_run_ends_the_job_with_an_error_line_or_code():
+    rc, lines, dt, err = _run_selftest("raise:0:2")
+    assert rc != 0 and dt < 150, (rc, dt, err[-2000:])
+    assert len(lines) == 1 and lines[0]["value"] is None and "selftest" in lines[0]["error"], lines
+
+
 def _row(i, name, counter, v):
     return {"Dispatch_Id": str(i), "Kernel_Name": name, "Counter_Name": counter, "Counter_Value": str(v)}
 
