@@ -246,6 +246,11 @@ int rm_mlp_bwd(const float *xe, const float *xd, int FD, int Dn, int NL, const i
  * Out: d_rows [B,F,16] = dLoss/dE (IndexedSlices form, duplicates not merged), logit / pred / dlogit [B] (dlogit =
  *   dLoss/dlogit: the per-occurrence gradient of the bias-table and sparse linear entries), loss [1] (mean over B,
  *   no l2 terms), dW[l] / db[l] (db may be NULL), d_w_out [H1], d_w0_out [1], d_lin_w_dense [Dn], d_lin_w0 [1].
+ * packed_rows > 0 (row-sharded table, recman_amd/dist.py): `table` is the buffer of RECEIVED rows [packed_rows,
+ *   20] ([16 embedding | bias | linear | 0 0], table_ld = 20), idx [B,F] = the position of every occurrence in it
+ *   (field_off zeros), and d_rows is the send buffer of the backward exchange, [packed_rows, 20]: occurrence (b, f)
+ *   writes [dE | dlogit | dlogit * lin_field_mask[f] | 0 0] to row idx[b, f] - what rm_pack_grad_rows builds from
+ *   the plain layout (lin_field_mask [F] or NULL: the linear_features subset).  packed_rows = 0: the plain layout.
  * workspace: rm_deepfm_step_workspace(F, Dn) floats.  flags: bit 0 = non-temporal row loads
  *   (RM_EMBED_STREAM_ROWS), bit 1 = non-temporal d_rows stores (only when nothing re-reads them soon), bit 2 = skip
  *   the finishing launch (measurement only: the parameter gradients and the loss are then NOT written).
@@ -258,7 +263,8 @@ int rm_deepfm_step(const int64_t *idx, const float *table, int64_t table_ld, con
                    const float *w0_out, const float *lin_w_dense, const float *lin_w0, int act, int task,
                    float grad_scale, float *d_rows, float *logit, float *pred, float *dlogit, float *loss,
                    float *const *dW, float *const *db, float *d_w_out, float *d_w0_out, float *d_lin_w_dense,
-                   float *d_lin_w0, float *workspace, int flags, rm_stream_t stream);
+                   float *d_lin_w0, float *workspace, int64_t packed_rows, const float *lin_field_mask, int flags,
+                   rm_stream_t stream);
 
 /* Epilogues of the library-GEMM DNN path (wide hidden layers, layers.py:593-601):
  * rm_bias_act: x[b,j] = act(x[b,j] + bias[j]) in place (bias may be NULL);

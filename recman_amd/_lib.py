@@ -50,7 +50,7 @@ SIGNATURES = {
                    P, P, P, P, c_int, P],
     "rm_deepfm_step_supported": [c_int, c_int, I64, c_int, c_int, P],
     "rm_deepfm_step": [P, P, I64, P, P, c_int, P, P, I64, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, c_int,
-                       c_float, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P],
+                       c_float, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, c_int, P],
     "rm_bias_act": [P, P, I64, c_int, c_int, P],
     "rm_act_bwd": [P, P, I64, c_int, c_int, P],
     "rm_outer_actgrad": [P, P, P, I64, c_int, c_int, P, P],

@@ -99,6 +99,10 @@ struct StepArgs {
   float grad_scale;
   int64_t B;
   float *d_rows, *logit, *pred, *dlogit, *dW0_part, *sg_part, *loss_part;
+  // packed output (row-sharded table): the row gradient of occurrence (b, f) goes to row idx[b, f] of d_rows - rows
+  // of out_row_bytes = (16 + 4) floats [dE | g | g * lin_mask[f] | 0 0], the send buffer of the backward exchange
+  int packed, out_row_bytes, out_rows;
+  const float *lin_mask;
 };
 
 // activation and its derivative off the post-activation value, branch-free: slope = 0 (relu), 0.2 (leaky_relu,
@@ -141,11 +145,11 @@ __device__ __forceinline__ void dma16(const char *src, char *lds_dst) {
                                    (__attribute__((address_space(3))) void *)lds_dst, 16, 0, NT ? 2 : 0);
 }
 
-// waits until at most `younger` (0..20) of this wave's vector-memory operations are outstanding
+// waits until at most `younger` (0..24) of this wave's vector-memory operations are outstanding
 __device__ __forceinline__ void wait_vm(int younger) {
 #define RM_WV(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
   switch (younger) {
-    RM_WV(20) RM_WV(19) RM_WV(18) RM_WV(17) RM_WV(16) RM_WV(15) RM_WV(14) RM_WV(13) RM_WV(12) RM_WV(11) RM_WV(10) RM_WV(9) RM_WV(8) RM_WV(7) RM_WV(6)
+    RM_WV(24) RM_WV(23) RM_WV(22) RM_WV(21) RM_WV(20) RM_WV(19) RM_WV(18) RM_WV(17) RM_WV(16) RM_WV(15) RM_WV(14) RM_WV(13) RM_WV(12) RM_WV(11) RM_WV(10) RM_WV(9) RM_WV(8) RM_WV(7) RM_WV(6)
     RM_WV(5) RM_WV(4) RM_WV(3) RM_WV(2) RM_WV(1)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
@@ -177,7 +181,7 @@ __device__ __forceinline__ float sum_n(float v) {  // over the 16 lanes (0..15, 
 }
 
 // ---------------------------------------------------------------------------------------------- worker
-template <bool NT, bool NT_OUT>
+template <bool NT, bool NT_OUT, bool PACKED>
 __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const int w, const int lane, const int T) {
   const int n = lane & 15, q = lane >> 4;
   const int F = a.F, H0 = a.H0, K = 16 * F + a.Dn;
@@ -217,6 +221,15 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
   float sdv[kSlots];  // bias / linear entries of the tile whose rows are in flight
 #pragma unroll
   for (int j = 0; j < kSlots; ++j) sdv[j] = 0.f;
+  // PACKED: the row numbers (= positions in the exchange buffers) of example n's occurrences, kept from the segment
+  // that requests a tile's rows (tile s + 1 in segment s) to the one that stores its gradients (tile s - 2)
+  unsigned rp[4][kSlots];
+  float lmask[kSlots];  // linear_features subset: the field's factor on the linear-entry gradient
+#pragma unroll
+  for (int j = 0; j < kSlots; ++j) {
+    rp[0][j] = rp[1][j] = rp[2][j] = rp[3][j] = 0;
+    lmask[j] = (PACKED && a.lin_mask != nullptr && sx[j]) ? a.lin_mask[fld[j]] : 1.f;
+  }
   ST_DECL;
   ST_ADD(0);  // prologue
 
@@ -263,18 +276,47 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
       // younger waves of a SIMD pair sat up to 6,000 cycles per tile in a burst of 8 of them, tools/probe/
       // step_stamps.py) - issued one at a time between groups of 16 MFMAs, the wait runs under the matrix work
       unsigned rid[kSlots];
+      if (PACKED) {  // after this: rp[g] = tile s + 1 - g; rp[3] = tile s - 2, whose gradients are stored below
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+          rp[3][j] = rp[2][j];
+          rp[2][j] = rp[1][j];
+          rp[1][j] = rp[0][j];
+        }
+      }
       if (hasD) {
         const unsigned *rowid = reinterpret_cast<const unsigned *>(smem + oRow + (td & 1) * kRowB);
 #pragma unroll
-        for (int j = 0; j < kSlots; ++j) rid[j] = rowid[fld[j] * 16 + (lane >> 2)];
+        for (int j = 0; j < kSlots; ++j) {
+          rid[j] = rowid[fld[j] * 16 + (lane >> 2)];
+          if (PACKED) rp[0][j] = rowid[fld[j] * 16 + n];
+        }
       }
       // the old rows have been READ (their values are in registers) before the new ones are requested
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const int64_t ex0 = ((int64_t)blockIdx.x + tb * tstride) * 16;
       const int64_t left = a.B - ex0;
       const int rows_t = left < 16 ? (int)left : 16;
-      const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.d_rows + (hasB ? ex0 * F * 16 : 0), 0,
-                                                          hasB ? rows_t * F * 64 : 0, 0x00020000);
+      const rsrc_t rd = PACKED ? __builtin_amdgcn_make_buffer_rsrc(a.d_rows, 0, hasB ? a.out_rows * a.out_row_bytes : 0, 0x00020000)
+                               : __builtin_amdgcn_make_buffer_rsrc(a.d_rows + (hasB ? ex0 * F * 16 : 0), 0,
+                                                                   hasB ? rows_t * F * 64 : 0, 0x00020000);
+      const bool ex_ok = n < rows_t;
+      // the row gradient of slot i (slots without an embedding field and examples past B: out of range, the store is
+      // dropped - every tile issues the same number of them).  PACKED: to row rp[3][i] of the exchange buffer, and
+      // the lanes of slice 0 add the row's tail [g_bias | g_lin | 0 0]
+      auto store_row = [&](int i, const f32x4 &o) {
+        const bool ok = sx[i] && !(RM_STEP_ABL & 2);
+        if (PACKED) {
+          const int base = (ok && ex_ok) ? (int)rp[3][i] * a.out_row_bytes : 0x7ffffff0 - 64;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, base + 16 * q, 0, NT_OUT ? 2 : 0);
+          const f32x4 tail = f32x4{g, g * lmask[i], 0.f, 0.f};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tail), rd, q == 0 ? base + 64 : 0x7ffffff0,
+                                                 0, NT_OUT ? 2 : 0);
+        } else {
+          const int off = ok ? (n * F + fld[i]) * 64 + 16 * q : 0x7ffffff0;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, off, 0, NT_OUT ? 2 : 0);
+        }
+      };
       f32x4 acc[kSlots];
 #pragma unroll
       for (int j = 0; j < kSlots; ++j) {
@@ -306,8 +348,7 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
           o.y = acc[i].y + (gS.y - g * e4[i].y);
           o.z = acc[i].z + (gS.z - g * e4[i].z);
           o.w = acc[i].w + (gS.w - g * e4[i].w);
-          const int off = (sx[i] && !(RM_STEP_ABL & 2)) ? (n * F + fld[i]) * 64 + 16 * q : 0x7ffffff0;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, off, 0, NT_OUT ? 2 : 0);
+          store_row(i, o);
         }
       }
       if (hasB) {
@@ -317,8 +358,7 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
         o.y = acc[i].y + (gS.y - g * e4[i].y);
         o.z = acc[i].z + (gS.z - g * e4[i].z);
         o.w = acc[i].w + (gS.w - g * e4[i].w);
-        const int off = (sx[i] && !(RM_STEP_ABL & 2)) ? (n * F + fld[i]) * 64 + 16 * q : 0x7ffffff0;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, off, 0, NT_OUT ? 2 : 0);
+        store_row(i, o);
       }
     }
     ST_ADD(6);  // M + S
@@ -326,7 +366,8 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
     if (s >= 0 && s < T) {
       // the tile's last DMA (slot 3, segment s - 1) is followed by that slot's entry load and the segment's last two
       // stores (slots 2 and 3), then by this segment's operations
-      const int younger = 1 + ((s - 3 >= 0) ? 2 : 0) + 4 * (2 * (hasD ? 1 : 0) + (hasB ? 1 : 0));
+      constexpr int SP = PACKED ? 2 : 1;  // stores per slot
+      const int younger = 1 + ((s - 3 >= 0) ? 2 * SP : 0) + 8 * (hasD ? 1 : 0) + 4 * SP * (hasB ? 1 : 0);
       wait_vm(younger);
       ST_ADD(3);  // wait for the tile's rows
       const char *xb = smem + oX + (s % 3) * kXBufB;
@@ -660,7 +701,7 @@ __device__ __forceinline__ void step_head(const StepArgs &a, char *smem, const i
   ST_FLUSH(7);
 }
 
-template <bool NT, bool NT_OUT>
+template <bool NT, bool NT_OUT, bool PACKED>
 __global__ __launch_bounds__(512) void deepfm_step_kernel(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -674,7 +715,7 @@ __global__ __launch_bounds__(512) void deepfm_step_kernel(StepArgs a) {
     // static priority for the younger half: waves 4..6 lose every arbitration (issue ports, the vector-memory queue)
     // against their SIMD partners 0..2 otherwise and run their phases AFTER them instead of beside them
     if (RM_STEP_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    step_worker<NT, NT_OUT>(a, smem, wave, lane, T);
+    step_worker<NT, NT_OUT, PACKED>(a, smem, wave, lane, T);
   } else {
     if (RM_STEP_PRIO) __builtin_amdgcn_s_setprio(2);  // the head's epilogue is one dependent chain: never make it queue
     step_head(a, smem, lane, T);
@@ -706,7 +747,8 @@ extern "C" int rm_deepfm_step(const int64_t *idx, const float *table, int64_t ta
                               const float *lin_w0, int act, int task, float grad_scale, float *d_rows,
                               float *logit, float *pred, float *dlogit, float *loss, float *const *dW,
                               float *const *db, float *d_w_out, float *d_w0_out, float *d_lin_w_dense,
-                              float *d_lin_w0, float *workspace, int flags, rm_stream_t stream) {
+                              float *d_lin_w0, float *workspace, int64_t packed_rows, const float *lin_field_mask,
+                              int flags, rm_stream_t stream) {
   RM_REQUIRE(H && rm_deepfm_step_supported(F, D, table_ld, Dn, NL, H),
              "rm_deepfm_step: needs D = 16, fused rows (table_ld >= 20, a multiple of 4), F <= 26, Dn <= 16 and two "
              "hidden layers of width <= 32");
@@ -719,6 +761,7 @@ extern "C" int rm_deepfm_step(const int64_t *idx, const float *table, int64_t ta
   RM_REQUIRE((y != nullptr) != (y_f != nullptr), "rm_deepfm_step: exactly one of y / y_f");
   RM_REQUIRE(task == 0 || task == 1, "rm_deepfm_step: task must be 0 or 1");
   RM_REQUIRE(rm_aligned16(table) && rm_aligned16(d_rows), "rm_deepfm_step: table / d_rows must be 16-byte aligned");
+  RM_REQUIRE(packed_rows >= 0 && packed_rows * 80 < (1ll << 31), "rm_deepfm_step: packed_rows out of range");
   const int K = 16 * F + Dn, Kp = ((K + 63) / 64) * 64;
   const int64_t ntiles = (B + 15) / 16;
   const int nblk = rm_grid_cap(ntiles, 256);  // one 8-wave workgroup per CU
@@ -730,19 +773,25 @@ extern "C" int rm_deepfm_step(const int64_t *idx, const float *table, int64_t ta
   a.F = F; a.Dn = Dn; a.H0 = H[0]; a.H1 = H[1]; a.act = act; a.task = task; a.Kp = Kp;
   a.grad_scale = grad_scale; a.B = B;
   a.d_rows = d_rows; a.logit = logit; a.pred = pred; a.dlogit = dlogit;
+  a.packed = packed_rows > 0; a.out_row_bytes = 80; a.out_rows = (int)packed_rows; a.lin_mask = lin_field_mask;
   a.dW0_part = workspace;
   a.sg_part = workspace + (int64_t)256 * Kp * 32;
   a.loss_part = a.sg_part + (int64_t)256 * kRmSgStride;
   hipStream_t st = (hipStream_t)stream;
   const bool nt = (flags & 1) != 0, nt_out = (flags & 2) != 0;
-#define RM_STEP(NT_, NTO_)                                                                                   \
+#define RM_STEP(NT_, NTO_, PK_)                                                                              \
   {                                                                                                          \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deepfm_step_kernel<NT_, NTO_>),                 \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deepfm_step_kernel<NT_, NTO_, PK_>),            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);                        \
-    hipLaunchKernelGGL((deepfm_step_kernel<NT_, NTO_>), dim3(nblk), dim3(512), kLdsBytes, st, a);            \
+    hipLaunchKernelGGL((deepfm_step_kernel<NT_, NTO_, PK_>), dim3(nblk), dim3(512), kLdsBytes, st, a);       \
   }
-  if (nt) { if (nt_out) RM_STEP(true, true) else RM_STEP(true, false) }
-  else { if (nt_out) RM_STEP(false, true) else RM_STEP(false, false) }
+  if (a.packed) {
+    if (nt) RM_STEP(true, false, true) else RM_STEP(false, false, true)
+  } else if (nt) {
+    if (nt_out) RM_STEP(true, true, false) else RM_STEP(true, false, false)
+  } else {
+    if (nt_out) RM_STEP(false, true, false) else RM_STEP(false, false, false)
+  }
 #undef RM_STEP
   RM_CHECK_LAUNCH("rm_deepfm_step");
   if (flags & 4) return RM_OK;  // (measurement: the step kernel alone, the per-block partial sums stay in the workspace)

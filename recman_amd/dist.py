@@ -556,19 +556,79 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                     g[:, D + 1] = self.dlogit[seg] * wl
                 grad_rows.index_copy_(0, self._mv_pos[j], g)
 
+        def _step_packed_ok(self, masks, mv):
+            """DeepFM's one-kernel step (rm_deepfm_step, packed form) covers this (micro-)batch: it gathers from the
+            RECEIVED rows and writes the gradient rows straight into the send buffer of the backward exchange -
+            the front kernel, the backward kernel and rm_pack_grad_rows in one launch."""
+            from . import ops
+
+            if self.model != "deepfm" or masks or mv is not None or self.mv_fields:
+                return False
+            if not self.hp.get("step_fusion", eng.STEP_FUSION_DEFAULT):
+                return False
+            if not (self.use_fm and self.use_deep and self.use_linear and self.use_bias_tables):
+                return False
+            if getattr(self, "_step_pk", None) is None:
+                self._step_pk = bool(self.mlp.fused_ok and ops.deepfm_step_supported(
+                    self.F, self.D, self.D + PAD, self.Dn, self.mlp.hidden))
+            return self._step_pk
+
+        def _fwd_bwd_packed(self, idx, dense, y, masks, grad_rows, mv=None, pos=None):
+            """Forward + backward of one (micro-)batch with its gradient rows [dE | g_fm | g_lin | 0 0] written in
+            bucketed order into grad_rows (the send buffer of the backward all_to_all); returns the loss."""
+            from . import ops
+
+            if self._step_packed_ok(masks, mv):
+                B = idx.shape[0]
+                self._alloc(B)
+                self._mv = None
+                pos = self._lookup(idx).view(B, self.F)  # runs / finishes the row exchange: self.rows
+                mlp, p, g = self.mlp, self.params, self.grads
+                if getattr(self, "_step_ws", None) is None:
+                    self._step_ws = torch.zeros(ops.deepfm_step_workspace(self.F, self.Dn), dtype=torch.float32,
+                                                device=self.device)
+                pre, n = mlp.prefix, len(mlp.hidden)
+                rows = self.rows
+                ops.deepfm_step(
+                    pos, rows, self._zoff, self.D, self.D + PAD, dense if self.Dn else None, y,
+                    [p[f"{pre}dnn_layer_{i}_weights"] for i in range(n)],
+                    [p[f"{pre}dnn_layer_{i}_bias"] for i in range(n)], p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"],
+                    self.linear_w_dense if self.Dn else None, p["linear_w0"], mlp.act, self.task, grad_rows,
+                    self.logit, self.pred, self.dlogit, self.loss,
+                    [g[f"{pre}dnn_layer_{i}_weights"] for i in range(n)],
+                    [g[f"{pre}dnn_layer_{i}_bias"] for i in range(n)], g[f"{pre}dnn_w"].view(-1), g[f"{pre}dnn_w0"],
+                    g["linear_w_dense"] if self.Dn else None, g["linear_w0"], self._step_ws,
+                    grad_scale=getattr(self, "grad_scale", 1.0), packed_rows=min(rows.shape[0], grad_rows.shape[0]),
+                    lin_field_mask=self.lin_field_mask)
+                self.d_bias = None
+                if self.Dn and self.lin_dense_mask is not None:
+                    g["linear_w_dense"].mul_(self.lin_dense_mask)
+                reg = self.hp.get("deep_l2_reg", 0.0)
+                if reg:
+                    mlp.add_l2_grads(reg)
+                return self._add_l2(self.loss)
+            loss = base.fwd_bwd(self, idx, dense, y, masks, mv=mv) if mv is not None else base.fwd_bwd(self, idx, dense, y, masks)
+            if self.mv_fields:
+                return loss
+            ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
+                               self.dlogit if self.use_linear else None,
+                               (self._pos if pos is None else pos).reshape(-1), grad_rows,
+                               lin_field_mask=self.lin_field_mask)
+            return loss
+
         def _one(self, idx, dense, y, masks, grad_rows, mv=None):
             """fwd+bwd of one (micro-)batch; its gradient rows are packed into grad_rows and their
             exchange is started: returns (loss, ids, rows, work)."""
             from . import ops
 
-            loss = base.fwd_bwd(self, idx, dense, y, masks, mv=mv) if mv is not None else base.fwd_bwd(self, idx, dense, y, masks)
+            loss = self._fwd_bwd_packed(idx, dense, y, masks, grad_rows, mv=mv)
             if self.mv_fields:
                 # (slots + pooled-row region; the pooled rows' own gradients land behind the slots and stay home)
                 grad_rows = torch.zeros(self.rows.shape[0], self.D + PAD, dtype=torch.float32, device=self.device)
-            # gradient rows [dE | g_fm | g_lin | 0 0], written straight in bucketed order -> owners
-            ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
-                               self.dlogit if self.use_linear else None, self._pos.reshape(-1), grad_rows,
-                               lin_field_mask=self.lin_field_mask)
+                # gradient rows [dE | g_fm | g_lin | 0 0], written straight in bucketed order -> owners
+                ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
+                                   self.dlogit if self.use_linear else None, self._pos.reshape(-1), grad_rows,
+                                   lin_field_mask=self.lin_field_mask)
             if self.mv_fields:
                 self._pack_mv(grad_rows)
                 grad_rows = grad_rows[: self.ex.slots]
@@ -707,12 +767,9 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             def compute(s, c):
                 self._slot = s
                 try:
-                    loss = base.fwd_bwd(self, s.idx, s.dense, s.y, None)
+                    loss = self._fwd_bwd_packed(s.idx, s.dense, s.y, None, s.grad_rows, pos=s.pos)
                 finally:
                     self._slot = None
-                ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
-                                   self.dlogit if self.use_linear else None, s.pos, s.grad_rows,
-                                   lin_field_mask=self.lin_field_mask)
                 if c == 0:
                     self._seg_loss.copy_(loss)
                 else:

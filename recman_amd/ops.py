@@ -407,9 +407,12 @@ def deepfm_step_workspace(F, Dn):
 
 def deepfm_step(idx, rows, field_off, D, table_ld, dense, y, Ws, bs, w_out, w0_out, lin_w_dense, lin_w0, act, task,
                 d_rows, logit, pred, dlogit, loss, dW, db, d_w_out, d_w0_out, d_lin_w_dense, d_lin_w0, workspace,
-                grad_scale=1.0, stream_rows=False, stream_d_rows=False, skip_finish=False):
+                grad_scale=1.0, stream_rows=False, stream_d_rows=False, skip_finish=False, packed_rows=0,
+                lin_field_mask=None):
     """rm_deepfm_step: DeepFM's forward + every gradient in one kernel (+ the finishing reduction; skip_finish =
-    measurement only, the parameter gradients and the loss are then not written)."""
+    measurement only, the parameter gradients and the loss are then not written).  packed_rows > 0: the row-sharded
+    form - rows = the received rows [packed_rows, D + 4], idx = positions in it, d_rows = the gradient send buffer
+    [packed_rows, D + 4] written in bucketed order (see include/recman_hip.h)."""
     B, F = idx.shape
     Dn = 0 if dense is None else dense.shape[1]
     H = [W.shape[1] for W in Ws]
@@ -420,6 +423,8 @@ def deepfm_step(idx, rows, field_off, D, table_ld, dense, y, Ws, bs, w_out, w0_o
         _chk(db[l], f"db[{l}]", F32, (H[l],))
     if rows.dim() != 2 or rows.shape[1] != table_ld or not rows.is_contiguous():
         raise ValueError("deepfm_step: rows must be the contiguous fused table [R, table_ld]")
+    if packed_rows and (d_rows.numel() < packed_rows * (D + 4) or rows.shape[0] < packed_rows or table_ld != D + 4):
+        raise ValueError("deepfm_step: packed form needs rows / d_rows of [packed_rows, D + 4]")
     if rows.shape[0] >= 1 << 32:
         raise ValueError("deepfm_step: the table has more than 2^32 rows")
     if workspace.numel() < deepfm_step_workspace(F, Dn):
@@ -435,7 +440,8 @@ def deepfm_step(idx, rows, field_off, D, table_ld, dense, y, Ws, bs, w_out, w0_o
               _chk(dlogit, "dlogit", F32, (B,)), _chk(loss, "loss", F32, (1,)), _ptr_array(dW), _ptr_array(db),
               _chk(d_w_out, "d_w_out", F32, (H[-1],)), _chk(d_w0_out, "d_w0_out", F32, (1,)),
               _chk(d_lin_w_dense, "d_lin_w_dense", F32, (Dn,), allow_none=True),
-              _chk(d_lin_w0, "d_lin_w0", F32, (1,)), _chk(workspace, "workspace", F32),
+              _chk(d_lin_w0, "d_lin_w0", F32, (1,)), _chk(workspace, "workspace", F32), int(packed_rows),
+              _chk(lin_field_mask, "lin_field_mask", F32, (F,), allow_none=True),
               (1 if stream_rows else 0) | (2 if stream_d_rows else 0) | (4 if skip_finish else 0), _stream())
 
 
