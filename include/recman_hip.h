@@ -442,6 +442,12 @@ int rm_pool_rows_bwd(const float *d_rows, int64_t dr_stride, const float *g_bias
  *                 [m[0:4] v[0:4] | m[4:8] v[4:8] | ..] (Adagrad uses the v halves; SGD: may be NULL)
  *   d_rows [B,F,D], g_bias / g_lin [B] (per-example gradient of column D / D+1, or NULL),
  *   lin_field_mask [F] or NULL (linear_features subsets)
+ *   l2_embedding / l2_linear: LAZY l2 (0 = none) - the gradient of FeatEmbedding.l2 / LinearLayer.l2
+ *                 (reg * 1/2 |.|^2, layers.py:188-193, 349-354) is added as reg * row (resp. reg * linear entry)
+ *                 for the rows this batch touches, once per distinct row and step, inside the same pass (one FMA
+ *                 per element, no extra traffic).  The reference's dense term touches EVERY row every step (the
+ *                 whole table, 1.7 - 25.6 GB at the BASELINE configs): the two coincide when every row is touched
+ *                 each step; DESIGN.md section 6.
  *   workspace: rm_sparse_optimizer_workspace(B * F) BYTES.
  * rm_sparse_optimizer_prepare: the id-only part of a step (keys + stable sort by table row) on its own,
  *   so that it can be issued before / beside the forward+backward pass; the following step call on the
@@ -457,13 +463,14 @@ int rm_sparse_optimizer_prepare(const int64_t *idx, const int64_t *field_off, co
 int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field_off, const float *d_rows,
                              const float *g_bias, const float *g_lin, int64_t B, int F, int D,
                              int64_t R, float *rows, int64_t ld, float *mom, int step, int kind,
-                             float lr, float beta1, float beta2, float eps, int reset,
-                             const float *lin_field_mask, int prepared, void *workspace, int64_t ws_bytes,
-                             rm_stream_t stream);
+                             float lr, float beta1, float beta2, float eps, int reset, float l2_embedding,
+                             float l2_linear, const float *lin_field_mask, int prepared, void *workspace,
+                             int64_t ws_bytes, rm_stream_t stream);
 int rm_sparse_optimizer_step_rows(const int64_t *row_ids, const float *grad_rows, int64_t gw, int64_t n,
                                   int D, int64_t R, float *rows, int64_t ld, float *mom, int step, int kind,
-                                  float lr, float beta1, float beta2, float eps, int reset, int prepared,
-                                  void *workspace, int64_t ws_bytes, rm_stream_t stream);
+                                  float lr, float beta1, float beta2, float eps, int reset, float l2_embedding,
+                                  float l2_linear, int prepared, void *workspace, int64_t ws_bytes,
+                                  rm_stream_t stream);
 int rm_dense_optimizer_step(float *p, const float *g, float *m, float *v, int64_t n, int step, int kind,
                             float lr, float beta1, float beta2, float eps, int reset, rm_stream_t stream);
 

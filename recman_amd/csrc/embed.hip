@@ -360,16 +360,32 @@ __global__ void colsum_w_stage2(const float *__restrict__ partial, int nblk, int
   }
 }
 
+// (U independent (row id -> row piece) chains per thread and iteration: with one, the kernel was a dependent pair of
+// loads per 16 bytes - 90 us for the 1.7 M rows of a DeepFM batch, profiles/r03_sharded_step.md)
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(
     const float4 *__restrict__ table, int64_t ld4, const int64_t *__restrict__ rows, int64_t n, int G,
     float4 *__restrict__ out) {
+  constexpr int U = 8;
   const int64_t total = n * G;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t i = t / G;
-    const int sub = (int)(t - i * G);
-    const int64_t r = rows[i];  // r < 0: an empty slot of the fixed-capacity exchange -> zero row
-    out[t] = r >= 0 ? table[r * ld4 + sub] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += U * stride) {
+    int64_t r[U];
+    int sub[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = t0 + u * stride;
+      const int64_t i = (t < total ? t : total - 1) / G;
+      sub[u] = (int)((t < total ? t : total - 1) - i * G);
+      r[u] = rows[i];  // r < 0: an empty slot of the fixed-capacity exchange -> zero row
+    }
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = table[(r[u] >= 0 ? r[u] : 0) * ld4 + sub[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = t0 + u * stride;
+      if (t < total) out[t] = r[u] >= 0 ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 

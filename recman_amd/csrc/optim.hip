@@ -51,6 +51,10 @@ struct OptArgs {
   int kind;  // 0 Adam, 1 Adagrad, 2 SGD
   float lr_t, lr, beta1, beta2, eps;
   int reset;
+  // lazy l2: the gradient of embedding_l2_reg * 1/2 |row|^2 (resp. linear_l2_reg on the linear entry) is added
+  // for the rows a batch touches, ONCE per distinct row and step (the reference's dense term, layers.py:188-193,
+  // 349-354, makes every row's gradient non-zero: the whole table per step).  The FM bias entry has no l2.
+  float l2_emb, l2_lin;
 };
 
 // key of occurrence o: its global table row, or R for a skipped one (sorts behind every row).
@@ -149,6 +153,11 @@ __device__ __forceinline__ void apply_row(float *__restrict__ rows, int64_t ld, 
   // lane GE needs (v_b, v_l) of lane GE + 1, and hands the updated pair back
   const float vb_in = __shfl_down(s.p.x, 1, G), vl_in = __shfl_down(s.p.y, 1, G);
   float vb = vb_in, vl = vl_in;
+  if (sub < GE) {
+    g.x += a.l2_emb * s.p.x; g.y += a.l2_emb * s.p.y; g.z += a.l2_emb * s.p.z; g.w += a.l2_emb * s.p.w;
+  } else if (sub == GE) {
+    g.y += a.l2_lin * s.p.y;
+  }
   if (sub < GE) {
     opt_update(s.p.x, s.m.x, s.v.x, g.x, a);
     opt_update(s.p.y, s.m.y, s.v.y, g.y, a);
@@ -340,9 +349,11 @@ int ws_layout(int64_t n, WsLayout *w) {
   return RM_OK;
 }
 
-OptArgs opt_args(int step, int kind, float lr, float beta1, float beta2, float eps, int reset) {
+OptArgs opt_args(int step, int kind, float lr, float beta1, float beta2, float eps, int reset, float l2_emb = 0.f,
+                 float l2_lin = 0.f) {
   OptArgs a;
   a.kind = kind; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.reset = reset;
+  a.l2_emb = l2_emb; a.l2_lin = l2_lin;
   a.lr_t = lr;
   if (kind == 0) {
     const double t = reset ? 1.0 : (double)step;
@@ -447,6 +458,7 @@ extern "C" int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field
                                         const float *g_bias, const float *g_lin, int64_t B, int F, int D,
                                         int64_t R, float *rows, int64_t ld, float *mom, int step, int kind,
                                         float lr, float beta1, float beta2, float eps, int reset,
+                                        float l2_embedding, float l2_linear,
                                         const float *lin_field_mask, int prepared, void *workspace,
                                         int64_t ws_bytes, rm_stream_t stream) {
   RM_REQUIRE(B >= 0 && F > 0, "rm_sparse_optimizer_step: bad sizes");
@@ -455,23 +467,23 @@ extern "C" int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field
   RM_REQUIRE(prepared || (idx && field_off), "rm_sparse_optimizer_step: NULL argument");
   GradSrc src = {0, d_rows, D, g_bias, g_lin, lin_field_mask, F};
   return sparse_step(idx, field_off, F, nullptr, B * F, src, D, R, rows, ld, mom,
-                     opt_args(step, kind, lr, beta1, beta2, eps, reset), prepared, workspace, ws_bytes,
-                     (hipStream_t)stream, "rm_sparse_optimizer_step");
+                     opt_args(step, kind, lr, beta1, beta2, eps, reset, l2_embedding, l2_linear), prepared,
+                     workspace, ws_bytes, (hipStream_t)stream, "rm_sparse_optimizer_step");
 }
 
 extern "C" int rm_sparse_optimizer_step_rows(const int64_t *row_ids, const float *grad_rows, int64_t gw,
                                              int64_t n, int D, int64_t R, float *rows, int64_t ld, float *mom,
                                              int step, int kind, float lr, float beta1, float beta2, float eps,
-                                             int reset, int prepared, void *workspace, int64_t ws_bytes,
-                                             rm_stream_t stream) {
+                                             int reset, float l2_embedding, float l2_linear, int prepared,
+                                             void *workspace, int64_t ws_bytes, rm_stream_t stream) {
   RM_REQUIRE(n >= 0 && gw >= D + 2, "rm_sparse_optimizer_step_rows: gradient rows need D + 2 columns");
   RM_REQUIRE(kind >= 0 && kind <= 2 && step >= 1, "rm_sparse_optimizer_step_rows: bad kind / step");
   if (n == 0) return RM_OK;
   RM_REQUIRE(prepared || row_ids, "rm_sparse_optimizer_step_rows: NULL argument");
   GradSrc src = {1, grad_rows, gw, nullptr, nullptr, nullptr, 1};
   return sparse_step(nullptr, nullptr, 1, row_ids, n, src, D, R, rows, ld, mom,
-                     opt_args(step, kind, lr, beta1, beta2, eps, reset), prepared, workspace, ws_bytes,
-                     (hipStream_t)stream, "rm_sparse_optimizer_step_rows");
+                     opt_args(step, kind, lr, beta1, beta2, eps, reset, l2_embedding, l2_linear), prepared,
+                     workspace, ws_bytes, (hipStream_t)stream, "rm_sparse_optimizer_step_rows");
 }
 
 extern "C" int rm_dense_optimizer_step(float *p, const float *g, float *m, float *v, int64_t n, int step,

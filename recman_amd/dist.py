@@ -278,6 +278,7 @@ class ShardedTable:
         plus 6 sigma of the binomial spread, rounded up to 64."""
         if not self.capacity_factor:
             return 0
+        n = getattr(self, "cap_occurrences", None) or n  # (fit(): the largest part over the ranks - rank-uniform)
         mean = n / self.world
         cap = self.capacity_factor * mean + 6.0 * (mean * (1 - 1 / self.world)) ** 0.5 + 1
         return int(-(-cap // 64) * 64)
@@ -399,10 +400,12 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                     f"row-sharded table: multi-valued / value features {sorted(spec.scratch_names)} need the "
                     "dynamic exchange layout (capacity_factor=None) and micro_batches=1")
             for k in ("embedding_l2_reg", "linear_l2_reg"):
-                if hp.get(k, 0.0):
-                    # a dense l2 term on the table makes EVERY row's gradient non-zero (layers.py:188-193):
-                    # 25.6 GB per step at BASELINE configs[4] - the row-wise owner-side step cannot honour it
-                    raise NotImplementedError(f"row-sharded table: {k} must be 0 (a dense table gradient)")
+                if hp.get(k, 0.0) and not hp.get("lazy_l2", True):
+                    # the reference's DENSE l2 term on the table makes EVERY row's gradient non-zero
+                    # (layers.py:188-193): 25.6 GB per step at BASELINE configs[4] - the row-wise owner-side step
+                    # cannot honour it; the lazy form (reg * row for the rows a step touches, applied by
+                    # ShardedOptimizer) is what this engine offers
+                    raise NotImplementedError(f"row-sharded table: {k} needs lazy_l2 (a dense table gradient otherwise)")
             self._shard_args = (rank, world, group)
             self._pending = None
             self._slot = None
@@ -959,10 +962,17 @@ class ShardedOptimizer:
         self.dense = FusedDenseOptimizer(engine, name, lr)
         self._ws = None
         self.t = 0
+        # embedding_l2_reg / linear_l2_reg, lazily: reg * row for the rows this step touches (once per row: the owner
+        # adds it after summing every rank's gradient rows); the linear term's dense weights exactly
+        hpf = getattr(engine, "_hp_full", engine.hp)
+        self.l2_embedding = float(hpf.get("embedding_l2_reg", 0.0))
+        self.l2_linear = float(hpf.get("linear_l2_reg", 0.0)) if engine.use_linear else 0.0
 
     def step(self, reset=False):
         e = self.e
         self.t += 1
+        if self.l2_linear and e.Dn:
+            e.grads["linear_w_dense"].add_(e.params["linear_w_dense"], alpha=self.l2_linear)
         ids, rows = e.shard_grad_ids, e.shard_grad_rows
         if isinstance(ids, list):  # micro-batches: ONE update per row from all their pieces together
             ids, rows = (ids[0], rows[0]) if len(ids) == 1 else (torch.cat(ids), torch.cat(rows))
@@ -972,5 +982,6 @@ class ShardedOptimizer:
             self._ws = torch.zeros(need, dtype=torch.uint8, device=e.device)
         if n:
             self.ops.sparse_optimizer_step_rows(ids.contiguous(), rows.contiguous(), e.D, e.st.shard, self.mom,
-                                                self._ws, self.t, self.name, self.lr, reset=reset)
+                                                self._ws, self.t, self.name, self.lr, reset=reset,
+                                                l2_embedding=self.l2_embedding, l2_linear=self.l2_linear)
         self.dense.step(reset=reset)

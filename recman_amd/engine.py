@@ -649,6 +649,15 @@ class Engine:
     def _add_l2(self, loss):
         hp = self.hp
         total = loss
+        if hp.get("lazy_l2", False):
+            # LAZY l2 (the row-wise optimizer adds reg * row for the rows a batch touches): the
+            # table's l2 terms are neither summed into the loss (a pass over the whole table per step) nor turned
+            # into a dense gradient; the linear term's DENSE weights keep their exact l2 gradient
+            reg = hp.get("linear_l2_reg", 0.0)
+            if reg and self.use_linear and self.Dn:
+                self.grads["linear_w_dense"].add_(self.linear_w_dense, alpha=reg)
+                total = total + reg * 0.5 * self.linear_w_dense.square().sum()
+            return self._add_l2_model(total)
         reg = hp.get("embedding_l2_reg", 0.0)
         if reg:
             total = total + reg * 0.5 * self.rows[:, : self.D].square().sum()

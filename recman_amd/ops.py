@@ -514,7 +514,7 @@ def sparse_optimizer_prepare(workspace, R, idx=None, field_off=None, row_ids=Non
 
 def sparse_optimizer_step(idx, field_off, d_rows, rows, mom, workspace, step, kind, lr, D=None,
                           g_bias=None, g_lin=None, reset=False, beta1=0.9, beta2=0.999, eps=1e-7,
-                          lin_field_mask=None, prepared=False):
+                          lin_field_mask=None, prepared=False, l2_embedding=0.0, l2_linear=0.0):
     """Lazy row-wise optimizer step on table rows [R, ld] (see rm_sparse_optimizer_step): rows =
     [D emb | bias | lin | m_b | m_l | v_b | v_l | pad], mom [R, 2D] = [m | v] of the embedding."""
     B, F, Dg = d_rows.shape
@@ -528,13 +528,13 @@ def sparse_optimizer_step(idx, field_off, d_rows, rows, mom, workspace, step, ki
               _chk(g_bias, "g_bias", F32, (B,), allow_none=True),
               _chk(g_lin, "g_lin", F32, (B,), allow_none=True), B, F, D, R, _chk(rows, "rows", F32), ld,
               None if mom is None else mom.data_ptr(), int(step), OPT_KINDS[kind], float(lr), float(beta1),
-              float(beta2), float(eps), 1 if reset else 0,
+              float(beta2), float(eps), 1 if reset else 0, float(l2_embedding), float(l2_linear),
               _chk(lin_field_mask, "lin_field_mask", F32, (F,), allow_none=True), 1 if prepared else 0,
               wp, wn, _stream())
 
 
 def sparse_optimizer_step_rows(row_ids, grad_rows, D, rows, mom, workspace, step, kind, lr, reset=False,
-                               beta1=0.9, beta2=0.999, eps=1e-7, prepared=False):
+                               beta1=0.9, beta2=0.999, eps=1e-7, prepared=False, l2_embedding=0.0, l2_linear=0.0):
     """The same step from gradient rows that carry their (local) table row: row_ids [n] (< 0: skip),
     grad_rows [n, gw] = [dE | g_bias | g_lin | ...] (rm_sparse_optimizer_step_rows)."""
     n, gw = grad_rows.shape
@@ -545,7 +545,8 @@ def sparse_optimizer_step_rows(row_ids, grad_rows, D, rows, mom, workspace, step
     _lib.call("rm_sparse_optimizer_step_rows", _chk(row_ids, "row_ids", I64, (n,)),
               _chk(grad_rows, "grad_rows", F32), gw, n, D, R, _chk(rows, "rows", F32), ld,
               None if mom is None else mom.data_ptr(), int(step), OPT_KINDS[kind], float(lr), float(beta1),
-              float(beta2), float(eps), 1 if reset else 0, 1 if prepared else 0, wp, wn, _stream())
+              float(beta2), float(eps), 1 if reset else 0, float(l2_embedding), float(l2_linear),
+              1 if prepared else 0, wp, wn, _stream())
 
 
 def dense_optimizer_step(p, g, m, v, step, kind, lr, reset=False, beta1=0.9, beta2=0.999, eps=1e-7):

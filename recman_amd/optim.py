@@ -121,9 +121,11 @@ class FusedDenseOptimizer:
 class SparseTableOptimizer:
     """Lazy row-wise update of the fused table rows straight from the IndexedSlices the
     backward produces (rm_sparse_optimizer_step): only rows occurring in the batch are
-    touched, no dense gradient is ever formed, results are bit-reproducible.  Needs
-    embedding_l2_reg == linear_l2_reg == 0 (a dense l2 term touches every row, layers.py:188-193) -
-    DeepModel falls back to the dense path otherwise - and a fused row with room for the four moment
+    touched, no dense gradient is ever formed, results are bit-reproducible.  embedding_l2_reg /
+    linear_l2_reg are applied LAZILY (l2_embedding / l2_linear: reg * row added to the gradient of the rows a
+    batch touches, once per distinct row and step; the reference's dense term touches every row every step,
+    layers.py:188-193 - the two coincide when every row is touched each step).  Needs a
+    fused row with room for the four moment
     entries of its bias / linear columns (LD >= D + 8: D >= 8 with the engines' LD = 2 D rows).
     State: those four entries in the row itself + one [R, 2 D] array of the embedding entries' moments,
     interleaved [m4 v4] per float4 slice (moments(): the plain [R, D] views).
@@ -132,12 +134,13 @@ class SparseTableOptimizer:
     expanded one-field occurrence list - one occurrence per tag, its row gradient scaled by the
     pooling / value factor (rm_pool_rows_bwd's factors)."""
 
-    def __init__(self, engine, name="adam", lr=1e-3):
+    def __init__(self, engine, name="adam", lr=1e-3, l2_embedding=0.0, l2_linear=0.0):
         from . import ops
 
         if name not in ("adam", "adagrad", "gd", "sgd"):
             raise ValueError(f"SparseTableOptimizer: {name!r} unsupported (adam, adagrad, sgd)")
         self.ops, self.e, self.name, self.lr = ops, engine, name, float(lr)
+        self.l2_embedding, self.l2_linear = float(l2_embedding), float(l2_linear)
         R, LD = engine.rows.shape
         D = engine.D
         if LD < D + 8 or not 8 <= D <= 64:
@@ -202,7 +205,8 @@ class SparseTableOptimizer:
         self.ops.sparse_optimizer_step(
             idx, e.field_off, e.d_rows, e.rows, self.mom, self._workspace(B * F), self.t,
             self.name, self.lr, g_bias=g_bias, g_lin=g_lin, reset=reset,
-            lin_field_mask=getattr(e, "lin_field_mask", None), prepared=prepared)
+            lin_field_mask=getattr(e, "lin_field_mask", None), prepared=prepared,
+            l2_embedding=self.l2_embedding, l2_linear=self.l2_linear if e.use_linear else 0.0)
         for f in e.mv_fields:
             offsets, ids, vals = e._mv_entry(f)
             n = offsets[1:] - offsets[:-1]
@@ -219,7 +223,8 @@ class SparseTableOptimizer:
                 self.t, self.name, self.lr,
                 g_bias=(g_bias[seg] * wb).contiguous() if g_bias is not None else None,
                 g_lin=(g_lin[seg] * wl).contiguous() if (g_lin is not None and self._lin_on(f)) else None,
-                reset=reset)
+                reset=reset, l2_embedding=self.l2_embedding,
+                l2_linear=self.l2_linear if (e.use_linear and self._lin_on(f)) else 0.0)
 
     def roofline(self, idx, ms):
         """The step against the HBM roofline: bytes a step HAS to move with this layout - per occurrence

@@ -77,16 +77,22 @@ class DeepModel(BaseEstimator, TransformerMixin):
         eng.init_reference(e, self.random_seed)
         self._engine = e
         self._opt = Optimizer(hp.get("optimizer", "adam"), hp.get("learning_rate", 1e-3))
-        # row-wise sparse step for the table when nothing forces a dense gradient
-        no_l2 = not hp.get("embedding_l2_reg", 0.0) and not hp.get("linear_l2_reg", 0.0)
+        # row-wise sparse step for the table.  embedding_l2_reg / linear_l2_reg (1e-5 in the reference's default
+        # hyper-parameters, hparams/xDeepFM.py:22-23) would force a DENSE table gradient (layers.py:188-193): with
+        # the row-wise step they are applied lazily - reg * row for the rows a batch touches (hparams["lazy_l2"],
+        # default on whenever the row-wise optimizer is in use; strict_reference keeps the reference's dense term)
+        has_l2 = bool(hp.get("embedding_l2_reg", 0.0) or hp.get("linear_l2_reg", 0.0))
         want = hp.get("sparse_optimizer", e.rows.numel() > (1 << 24))
+        lazy = bool(hp.get("lazy_l2", not self.strict_reference))
         self._sparse_opt = None
         fits = e.rows.shape[1] >= e.D + 8 and 8 <= e.D <= 64  # room for the bias / linear moments in the row
-        if want and no_l2 and fits and hp.get("optimizer", "adam") in ("adam", "adagrad", "gd", "sgd"):
-            self._sparse_opt = SparseTableOptimizer(e, hp.get("optimizer", "adam"),
-                                                    hp.get("learning_rate", 1e-3))
+        if want and (lazy or not has_l2) and fits and hp.get("optimizer", "adam") in ("adam", "adagrad", "gd", "sgd"):
+            e.hp["lazy_l2"] = has_l2
+            self._sparse_opt = SparseTableOptimizer(e, hp.get("optimizer", "adam"), hp.get("learning_rate", 1e-3),
+                                                    l2_embedding=hp.get("embedding_l2_reg", 0.0),
+                                                    l2_linear=hp.get("linear_l2_reg", 0.0))
             # ... and the dense parameters in one launch (the dict-walking Optimizer stays the path
-            # for densified table gradients: small tables, l2 terms, FM bias dropout)
+            # for densified table gradients: small tables, strict l2 terms, FM bias dropout)
             self._dense_fused = FusedDenseOptimizer(e, hp.get("optimizer", "adam"), hp.get("learning_rate", 1e-3))
         return e
 
@@ -136,15 +142,62 @@ class DeepModel(BaseEstimator, TransformerMixin):
         b = a + base + (1 if rank < rem else 0)
         return a, b, (b - a) / n
 
-    def _fit_sharded_batch(self, idx, dense, yt, mv=None):
+    def _any_rank(self, flag):
+        """True on every rank when `flag` is true on ANY rank (one tiny all_reduce through the host)."""
+        if self._shard is None or self._shard[1] == 1:
+            return bool(flag)
+        import torch.distributed as dist
+
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            t = t.to(self._engine.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
+    def _fit_sharded_batch(self, idx, dense, yt, mv=None, masks=None, parts=None):
+        """One training step of the row-sharded engine on this rank's part of the global batch.  Every choice
+        that changes the NUMBER or the SIZES of the collectives is made rank-uniformly: `parts` = (smallest,
+        largest) part of the global batch over the ranks (fit() knows the split; fit_on_batch agrees on it with
+        one all_reduce) decides whether the micro-batch pipeline runs (every part divisible by M) and sizes the
+        fixed-capacity buckets (the largest part); a fixed-capacity batch that overflowed on ANY rank is redone
+        with exact split sizes before the optimizer step."""
         e = self._engine
         M = e.micro_batches
-        if idx.shape[0] % M:           # a ragged part: this step without the micro-batch pipeline
-            e.micro_batches = 1
+        B = idx.shape[0]
+        if parts is None:  # fit_on_batch: agree on the part sizes
+            parts = (B, B)
+            if self._shard[1] > 1:
+                import torch.distributed as dist
+
+                t = torch.tensor([-B, B], dtype=torch.int64)
+                if dist.get_backend() == "nccl":
+                    t = t.to(e.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                parts = (-int(t[0]), int(t[1]))
+        lo, hi = parts
+        ragged = lo != hi or lo % M != 0
+        st = e.st
+        fixed = st.capacity_factor
+        redone = False
         try:
-            loss = e.fwd_bwd(idx, dense, yt, weight=self._w, mv=mv)
+            if ragged or masks is not None:  # (dropout masks: no micro-batch pipeline, dist.py)
+                e.micro_batches = 1
+            if fixed:
+                st.cap_occurrences = hi * e.F  # the same bucket size on every rank
+            loss = e.fwd_bwd(idx, dense, yt, masks=masks, weight=self._w, mv=mv)
+            if fixed and self._any_rank(e.overflowed()):
+                # skewed ids: occurrences were clamped onto the last slot of a bucket - this step's rows and
+                # gradients are wrong on some rank; redo it with exact split sizes (every rank, same decision)
+                st.capacity_factor = None
+                e._B = None
+                redone = True
+                loss = e.fwd_bwd(idx, dense, yt, masks=masks, weight=self._w, mv=mv)
         finally:
             e.micro_batches = M
+            if fixed:
+                st.capacity_factor, st.cap_occurrences = fixed, None
+                if redone:
+                    e._B = None  # (the buffers are sized for the layout: re-made for the next fixed-capacity batch)
         self._shard_opt.step(reset=self.strict_reference)
         return loss
 
@@ -273,10 +326,9 @@ class DeepModel(BaseEstimator, TransformerMixin):
         if idx.shape[0] == 0:
             return None
         if self._shard is not None:
-            if self._dropout_masks(1) is not None:
-                raise NotImplementedError("row-sharded fit(): dropout is not wired through the exchange yet")
             self._w = getattr(self, "_w", None)
-            return self._fit_sharded_batch(idx, dense, yt, mv)
+            parts, self._parts = getattr(self, "_parts", None), None
+            return self._fit_sharded_batch(idx, dense, yt, mv, masks=self._dropout_masks(idx.shape[0]), parts=parts)
         side = None
         if self._sparse_opt is not None and not e.spec.scratch_names:
             # the id-only third of the row-wise step (keys + sort by row) runs on a side stream beside the
@@ -351,6 +403,8 @@ class DeepModel(BaseEstimator, TransformerMixin):
                     part = self._local_part(s, t)
                     if part is None:
                         continue
+                    base, rem = divmod(t - s, self._shard[1])
+                    self._parts = (base, base + (1 if rem else 0))  # smallest / largest part over the ranks
                     s, t, self._w = part
                 self._fit_encoded(idx[s:t].contiguous(), dense[s:t].contiguous(), yt[s:t].contiguous(),
                                   self._mv_batch(mv_host, s, t))

@@ -411,7 +411,18 @@ def _fit_worker(rank, world, port, model, out_path):
         hp = {"embedding_size": 16, "deep_dropout": (1, 1, 1), "cin_cross_layer_units": [16, 16],
               "cin_dropout": [1, 1, 1], "learning_rate": 0.01, "embedding_l2_reg": 0.0, "linear_l2_reg": 0.0,
               "deep_l2_reg": 1e-4, "micro_batches": 2}
-        if model == "xdeepfm":
+        if model == "xdeepfm_ragged_fixed":
+            # 1001 rows, batch 96: the last batch has 41 rows -> parts of 21 and 20 (one odd, one even: the
+            # micro-batch choice and the bucket capacity must be the SAME on both ranks), fixed-capacity exchange
+            df = ml_frame().iloc[:1001].copy()
+            fd = ml_features(df)
+            hp = dict(hp, exchange_capacity_factor=1.5)
+        if model == "xdeepfm_defaults":
+            # the reference's DEFAULT hyper-parameters (hparams/xDeepFM.py:19-34: embedding_l2_reg = linear_l2_reg =
+            # 1e-5, dropout, D = 8) - the l2 terms on the table are applied lazily by the owner-side step
+            hp = dict(th.hparams.xDeepFM().defaults(), learning_rate=0.01)
+            assert hp["embedding_l2_reg"] == 1e-5 and hp["linear_l2_reg"] == 1e-5
+        if model in ("xdeepfm", "xdeepfm_defaults", "xdeepfm_ragged_fixed"):
             m = th.xDeepFM(fd, hp, epoch=2, batch_size=96)
         elif model == "deepfm_genres":
             m = th.DeepFM(fd, embedding_size=16, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_dropout=(1, 1, 1),
@@ -429,7 +440,7 @@ def _fit_worker(rank, world, port, model, out_path):
         path = f"{out_path}.ckpt"
         m.save(path)
         dist.barrier()
-        m2 = (th.xDeepFM(fd, hp, epoch=1, batch_size=96) if model == "xdeepfm" else
+        m2 = (th.xDeepFM(fd, hp, epoch=1, batch_size=96) if model.startswith("xdeepfm") else
               th.DeepFM(fd, embedding_size=16, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_dropout=(1, 1, 1),
                         epoch=1, batch_size=96))
         m2.restore(path)
@@ -442,7 +453,7 @@ def _fit_worker(rank, world, port, model, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model", ["deepfm", "xdeepfm", "deepfm_genres"])
+@pytest.mark.parametrize("model", ["deepfm", "xdeepfm", "deepfm_genres", "xdeepfm_defaults", "xdeepfm_ragged_fixed"])
 def test_model_fit_predict_save_restore_with_a_row_sharded_table_on_two_ranks(hip_lib, tmp_path, model):
     """The model classes under a two-rank torch.distributed job: the table row-sharded, fit() data parallel
     (ragged last batch, micro-batches, dense l2; "deepfm_genres": with ml-100k's multi-valued `genres`, whose tags
@@ -450,7 +461,7 @@ def test_model_fit_predict_save_restore_with_a_row_sharded_table_on_two_ranks(hi
     went down, a restored model predicts the same."""
     world = 2
     out = str(tmp_path / "f")
-    port = 29990 + ["deepfm", "xdeepfm", "deepfm_genres"].index(model)
+    port = 29990 + ["deepfm", "xdeepfm", "deepfm_genres", "xdeepfm_defaults", "xdeepfm_ragged_fixed"].index(model)
     mp.spawn(_fit_worker, args=(world, port, model, out), nprocs=world, join=True)
     res = [torch.load(f"{out}.{r}", weights_only=True) for r in range(world)]
     assert res[0]["after"] < res[0]["before"] - 0.01

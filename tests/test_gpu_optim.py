@@ -194,6 +194,52 @@ def test_lazy_equals_keras_dense_when_every_row_is_touched_and_diverges_otherwis
     assert float((e1.params[k][1:] - e2.params[k][1:]).abs().max()) <= 5e-6  # touched rows still agree
 
 
+@pytest.mark.parametrize("name", ["adam", "gd"])
+def test_lazy_l2_equals_the_dense_l2_term_when_every_row_is_touched_and_diverges_otherwise(hip_lib, name):
+    """embedding_l2_reg / linear_l2_reg (FeatEmbedding.l2 / LinearLayer.l2, layers.py:188-193, 349-354) applied
+    LAZILY by the row-wise step - reg * row for the rows a batch touches - against the reference's dense term
+    (the densified gradient + reg * table, through Optimizer): identical while every row occurs in every batch,
+    and a row a batch leaves out keeps its value where the dense term would shrink it."""
+    from recman_amd.optim import Optimizer, SparseTableOptimizer
+
+    sizes = [3, 4, 2]
+    spec, p, idx, dense, y, hp = make_case("deepfm", B=200, F=3, D=8, sizes=sizes)
+    reg_e, reg_l = 3e-2, 2e-2
+    hp = dict(hp, embedding_l2_reg=reg_e, linear_l2_reg=reg_l, deep_l2_reg=0.0)
+    g = torch.Generator().manual_seed(7)
+    full = []
+    for _ in range(3):
+        ib = torch.stack([torch.randint(0, v, (200,), generator=g) for v in sizes], 1)
+        for f, v in enumerate(sizes):
+            ib[:v, f] = torch.arange(v)
+        full.append((ib.cuda(), dense.cuda(), y.cuda()))
+    e1 = _engine("deepfm", spec, 8, hp, p)                        # dense l2 (the reference's term)
+    e2 = _engine("deepfm", spec, 8, dict(hp, lazy_l2=True), p)    # lazy
+    dopt, sdense = Optimizer(name, 0.01), Optimizer(name, 0.01)
+    sopt = SparseTableOptimizer(e2, name, 0.01, l2_embedding=reg_e, l2_linear=reg_l)
+    for ib, db, yb in full:
+        e1.fwd_bwd(ib, db, yb)
+        dopt.step(e1.params, e1.dense_grads(ib))
+    _run_steps(e2, sopt, sdense, full)
+    for k in e1.params:
+        a, b = e1.params[k], e2.params[k]
+        assert float((a - b).abs().max()) <= 5e-6 * max(1.0, float(a.abs().max())), k
+    # a step without row 0 of field 0: the dense term still shrinks it, the lazy one leaves it alone
+    ib = full[0][0].clone()
+    ib[:, 0] = ib[:, 0].clamp(min=1)
+    k = f"{spec.sparse_names[0]}_feat_embed"
+    row0 = e2.params[k][0].clone()
+    e1.fwd_bwd(ib, full[0][1], full[0][2])
+    dopt.step(e1.params, e1.dense_grads(ib))
+    _run_steps(e2, sopt, sdense, [(ib, full[0][1], full[0][2])])
+    assert torch.equal(e2.params[k][0], row0)
+    assert float((e1.params[k][0] - row0).abs().max()) > 1e-6
+    assert float((e1.params[k][1:] - e2.params[k][1:]).abs().max()) <= 5e-6
+    # the FM bias entries carry no l2 in either form (layers.py:188-193 sums the embedding tables only)
+    kb = f"{spec.sparse_names[1]}_feat_bias"
+    assert float((e1.params[kb] - e2.params[kb]).abs().max()) <= 5e-6
+
+
 def test_sparse_step_is_bit_reproducible_with_heavy_duplicates(hip_lib):
     """Runs of equal rows far beyond the short-run kernel's cap (a 3-row field over 4,000 examples): the
     one-wave-per-run kernel sums in a fixed order; two runs from the same state are bit-identical and
