@@ -530,6 +530,78 @@ def time_steps(a, engine, idx, dense, y, sharded, world, dist, rehearse, dev, st
     return ms, enq_ms, kind, fixed, rotation
 
 
+def train_step_record(a, w, engine, dev, B, V, steps=60):
+    """What fit() achieves (recman/tf/core/DeepModel.py:180-202, xDeepFM.py:116-126): the loop
+    DeepModel._fit_encoded runs - a NEW batch every step -> forward+backward -> row-wise optimizer step on the
+    touched table rows (its id-only sort issued on a side stream beside fwd+bwd) -> dense parameters - over
+    `steps` steps, with the encoded dataset (a) resident in HBM and (b) in pinned host memory behind
+    th/feeder.py's double-buffered H2D copies.  Reported, NOT part of `value`."""
+    from recman_amd.optim import FusedDenseOptimizer, SparseTableOptimizer
+    from recman_amd.th.feeder import BatchFeeder
+
+    nb = 16  # distinct batches of the synthetic dataset
+    g = torch.Generator().manual_seed(4242)
+    idx_h = torch.randint(0, V, (nb * B, w["F"]), generator=g, dtype=torch.int64)
+    dense_h = torch.randn(nb * B, w["Dn"], generator=g)
+    y_h = (torch.rand(nb * B, generator=g) < 0.25).long()
+    sopt, dopt = SparseTableOptimizer(engine, "adam", 1e-3), FusedDenseOptimizer(engine, "adam", 1e-3)
+    side = torch.cuda.Stream(device=dev)
+    sopt._workspace(B * w["F"])
+
+    def one(ib, db, yb):
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            sopt.prepare(ib)
+        engine.fwd_bwd(ib, db, yb)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        sopt.step(ib)
+        dopt.step()
+
+    def timed(batches, n):
+        it = iter(batches())
+        for _ in range(4):
+            one(*next(it))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done = 0
+        for ib, db, yb in it:
+            one(ib, db, yb)
+            done += 1
+            if done == n:
+                break
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / max(done, 1) * 1e3, done
+
+    # (a) the dataset resident in HBM
+    dev_b = [(idx_h[k * B:(k + 1) * B].to(dev), dense_h[k * B:(k + 1) * B].to(dev), y_h[k * B:(k + 1) * B].to(dev))
+             for k in range(nb)]
+
+    def resident():
+        while True:
+            yield from dev_b
+
+    ms_res, n_res = timed(resident, steps)
+    del dev_b
+    # (b) pinned host memory -> H2D on a copy stream, one batch ahead
+    feeder = BatchFeeder(idx_h, dense_h, y_h, B, dev)
+
+    def pinned():  # (a shuffled epoch, as fit() runs it: the rows of a batch are gathered on the host)
+        while True:
+            for _, _, ib, db, yb in feeder.batches(perm=torch.randperm(nb * B, generator=g)):
+                yield ib, db, yb
+
+    ms_pin, n_pin = timed(pinned, steps)
+    per_batch = B * (w["F"] * 8 + w["Dn"] * 4 + 8)
+    return {"ms_per_step_dataset_in_hbm": round(ms_res, 4), "examples_per_s_dataset_in_hbm": round(B / ms_res * 1e3, 1),
+            "ms_per_step_pinned_feeder": round(ms_pin, 4), "examples_per_s_pinned_feeder": round(B / ms_pin * 1e3, 1),
+            "steps": n_res, "distinct_batches": nb, "host_to_device_bytes_per_step": per_batch,
+            "pcie_floor_ms_at_63GBs": round(per_batch / 63e9 * 1e3, 4),
+            "what": "fit()'s loop at this workload: new batch -> fwd+bwd -> row-wise lazy Adam on the touched rows "
+                    "(sort on a side stream beside fwd+bwd) -> dense Adam; eager launches, every step on other "
+                    "ids.  With the dataset in pinned host memory the step is bound by the H2D copy of the ids "
+                    "(int64, the reference's dtype), not by the GPU: compare pcie_floor_ms.  NOT part of value"}
+
+
 def step_hbm(w, B, ms):
     """algorithmic bytes of the embedding+FM forward AND backward per batch
     (idx, rows, E, S, g, dE, gradient rows) over the whole step time."""
@@ -602,6 +674,12 @@ def measure(a, wname, dev, rank, world, dist, rehearse, sharded, live_traffic, f
                                      if not sharded else None)
         except Exception as e:  # never let the extra break the contract line
             rec["optimizer_step"] = {"ms": None, "error": f"{type(e).__name__}: {str(e)[:200]}"}
+    if (rank == 0 and not sharded and want_opt and not a.no_optimizer and wname == "deepfm" and zipf == 0
+            and B == w["B"] and V == w["V"]):
+        try:
+            rec["train_step"] = train_step_record(a, w, engine, dev, B, V)
+        except Exception as e:  # never let the extra break the contract line
+            rec["train_step"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     if sharded and want_opt and not a.no_optimizer and hasattr(engine, "optimizer_probe_sharded"):
         # every rank takes part (the dense all_reduce precedes the dense step); rank 0 reports
         try:

@@ -193,10 +193,10 @@ def cross_param_grads(P, colsum, w, b, w_out, d_w, d_b, d_w_out):
 
 def gather_rows(table, rows, out):
     """out[i, :] = table[rows[i], :width] with width = out.shape[1] <= table.shape[1] (the shard keeps
-    optimizer state behind the exchanged columns)."""
+    optimizer state behind the exchanged columns).  `table` may live in PINNED host memory (th/feeder.py)."""
     n = rows.shape[0]
     width = out.shape[1]
-    tp, ld, cols = _rows2d(table, "table")  # (a [:, :width] view of a wider shard is fine)
+    tp, ld, cols = _rows2d(table, "table", allow_pinned=True)  # (a [:, :width] view of a wider shard is fine)
     if cols < width:
         raise ValueError(f"gather_rows: table has {cols} columns, out needs {width}")
     _lib.call("rm_gather_rows", tp, ld, _chk(rows, "rows", I64, (n,)), n, width,
@@ -628,13 +628,16 @@ def act_bwd_(da, a, act):
 DENSE_BIAS_ACT, DENSE_MUL_ACTGRAD, DENSE_ADD, DENSE_CROSS = 0, 1, 2, 3
 
 
-def _rows2d(t, name, allow_none=False):
-    """A 2-D f32 tensor with unit column stride -> (pointer, leading dimension, columns)."""
+def _rows2d(t, name, allow_none=False, allow_pinned=False):
+    """A 2-D f32 tensor with unit column stride -> (pointer, leading dimension, columns).  allow_pinned: a
+    PINNED host tensor is accepted too (hipHostMalloc'ed memory is mapped into the GPU's address space: a kernel
+    reads it over PCIe - the batch feeder's zero-copy gather)."""
     if t is None:
         if allow_none:
             return None, 0, 0
         raise ValueError(f"{name} is required")
-    if t.dtype != F32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or not t.is_cuda:
+    on_dev = t.is_cuda or (allow_pinned and t.is_pinned())
+    if t.dtype != F32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or not on_dev:
         raise ValueError(f"{name}: expected a 2-D float32 device tensor with unit column stride, got "
                          f"{t.dtype} {tuple(t.shape)} strides {t.stride()}")
     return t.data_ptr(), t.stride(0), t.shape[1]
