@@ -289,8 +289,10 @@ def pmc_passes(workloads, timeout_s=240):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             plan = os.path.join(tmp, f"plan_{counter}.json")
+            # the program after `--` is THIS interpreter's real binary: a python3 found on PATH may be a wrapper
+            # script (an exec behind the profiler's preloaded library) or another torch build
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                   shutil.which("python3") or sys.executable, os.path.abspath(__file__),
+                   os.path.realpath(sys.executable), os.path.abspath(__file__),
                    "--pmc-child", ",".join(workloads), "--no-pmc"]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(env, RECMAN_PMC_PLAN=plan), timeout=timeout_s,
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

@@ -387,6 +387,8 @@ int sparse_prepare(const int64_t *idx, const int64_t *field_off, int F, const in
   return RM_OK;
 }
 
+__global__ void opt_clear_word_kernel(uint32_t *w) { *w = 0; }
+
 int sparse_step(const int64_t *idx, const int64_t *field_off, int F, const int64_t *row_ids, int64_t n,
                 GradSrc src, int D, int64_t R, float *rows, int64_t ld, float *mom, OptArgs a, int prepared,
                 void *workspace, int64_t ws_bytes, hipStream_t st, const char *fn) {
@@ -399,6 +401,10 @@ int sparse_step(const int64_t *idx, const int64_t *field_off, int F, const int64
   if (!prepared) {
     int rc = sparse_prepare(idx, field_off, F, row_ids, n, R, workspace, ws_bytes, st, fn);
     if (rc != RM_OK) return rc;
+  } else if (workspace) {
+    // a prepared sort may be consumed more than once (the same ids stepped twice): the long-run ticket counter
+    // at the head of the workspace is this step's alone (the keys kernel of an unprepared step clears it)
+    hipLaunchKernelGGL(opt_clear_word_kernel, dim3(1), dim3(1), 0, st, (uint32_t *)workspace);
   }
   WsLayout w;
   if (ws_layout(n, &w) != RM_OK) { rm_set_error("%s: rocprim size query failed", fn); return RM_ELAUNCH; }

@@ -225,29 +225,45 @@ class ShardedTable:
         return f"{path}.shard{rank}of{world}.pt"
 
     def save(self, path):
-        """Writes this rank's shard to `<path>.shard<rank>of<world>.pt` (every rank calls it)."""
-        torch.save({"R": self.R, "D": self.D, "rank": self.rank, "world": self.world,
-                    "rows": self.shard.cpu()}, self.shard_path(path, self.rank, self.world))
+        """Writes this rank's shard to `<path>.shard<rank>of<world>.pt` (every rank calls it): the PARAMETER
+        columns [D embedding | bias | linear] only - the row padding and the optimizer-state columns behind them
+        are layout details of this build (their width changed between rounds) and optimizer state is not part of
+        a model checkpoint (the embedding moments live in another array anyway)."""
+        torch.save({"R": self.R, "D": self.D, "rank": self.rank, "world": self.world, "width": self.D + 2,
+                    "rows": self.shard[:, : self.D + 2].cpu().contiguous()},
+                   self.shard_path(path, self.rank, self.world))
+
+    def _check(self, ck):
+        if (ck["R"], ck["D"]) != (self.R, self.D):
+            raise ValueError(f"checkpoint table is {ck['R']}x{ck['D']}, this one {self.R}x{self.D}")
+        w = ck["rows"].shape[1]
+        if w < self.D + 2:
+            raise ValueError(f"checkpoint rows have {w} columns, expected at least D + 2 = {self.D + 2}")
+        return ck["rows"][:, : self.D + 2]  # (older files carry padding / state columns behind the parameters)
 
     def load(self, path, saved_world=None):
-        """Restores the shard.  Same world size: reads this rank's own file.  Different world
-        size (re-sharding): streams the saved shards one at a time and keeps the rows that now
-        belong here (global row r = local * saved_world + saved_rank; it lives here when
+        """Restores the shard's parameters; every optimizer-state column of the rows is reset to zero (a restored
+        model starts its optimizer afresh: the dense moments and the step count do too).  Same world size: reads
+        this rank's own file.  Different world size (re-sharding): streams the saved shards one at a time and
+        keeps the rows that now belong here (global row r = local * saved_world + saved_rank; it lives here when
         r % world == rank)."""
         w0 = saved_world or self.world
+        P = self.D + 2
+        self.shard[:, P:].zero_()
         if w0 == self.world:
             ck = torch.load(self.shard_path(path, self.rank, self.world), weights_only=True)
-            if (ck["R"], ck["D"]) != (self.R, self.D):
-                raise ValueError(f"checkpoint table is {ck['R']}x{ck['D']}, this one {self.R}x{self.D}")
-            self.shard.copy_(ck["rows"])
+            self.shard[:, :P].copy_(self._check(ck))
+            if getattr(self, "on_load", None) is not None:
+                self.on_load()
             return
         for r0 in range(w0):
             ck = torch.load(self.shard_path(path, r0, w0), weights_only=True)
-            if (ck["R"], ck["D"]) != (self.R, self.D):
-                raise ValueError(f"checkpoint table is {ck['R']}x{ck['D']}, this one {self.R}x{self.D}")
-            g = torch.arange(ck["rows"].shape[0], dtype=torch.int64) * w0 + r0  # global row ids
+            rows = self._check(ck)
+            g = torch.arange(rows.shape[0], dtype=torch.int64) * w0 + r0  # global row ids
             mine = (g % self.world) == self.rank
-            self.shard[(g[mine] // self.world).to(self.shard.device)] = ck["rows"][mine].to(self.shard.device)
+            self.shard[(g[mine] // self.world).to(self.shard.device), :P] = rows[mine].to(self.shard.device)
+        if getattr(self, "on_load", None) is not None:
+            self.on_load()  # (the optimizer re-initialises the state columns it keeps in the rows)
 
     def lookup(self, idx, field_off, extra_rows=0):
         """idx [B,F] -> (rows [n, D+4] in BUCKETED order, the RowExchange): the row of
@@ -956,9 +972,21 @@ class ShardedOptimizer:
             self.mom = torch.zeros(n, 2 * D, device=st.shard.device)
             if name == "adagrad":
                 self.mom.view(n, D // 4, 2, 4)[:, :, 1, :] = 0.1
-        st.shard[:, D + 2: D + 6] = 0.0
-        if name == "adagrad":
-            st.shard[:, D + 4: D + 6] = 0.1
+        def init_state_columns():
+            st.shard[:, D + 2: D + 6] = 0.0
+            if name == "adagrad":
+                st.shard[:, D + 4: D + 6] = 0.1
+            if self.mom is not None:
+                self.mom.zero_()
+                if name == "adagrad":
+                    self.mom.view(n, D // 4, 2, 4)[:, :, 1, :] = 0.1
+            self.t = 0
+            if getattr(self, "dense", None) is not None:
+                self.dense.reset()
+
+        self.t = 0
+        init_state_columns()
+        st.on_load = init_state_columns  # a restored shard starts the optimizer afresh (ShardedTable.load)
         self.dense = FusedDenseOptimizer(engine, name, lr)
         self._ws = None
         self.t = 0

@@ -187,14 +187,17 @@ class SparseTableOptimizer:
             return  # (the expanded occurrence lists of multi-valued features are built in step())
         self.ops.sparse_optimizer_prepare(self._workspace(idx.numel()), e.rows.shape[0], idx=idx,
                                           field_off=e.field_off)
-        self._prepared = (idx.data_ptr(), tuple(idx.shape))
+        # (the sort is tied to the tensor's CONTENT: data pointer, shape and torch's version counter, which every
+        # in-place write - a feeder refilling a static input buffer - advances)
+        self._prepared = (idx.data_ptr(), tuple(idx.shape), idx._version)
 
     def step(self, idx, reset=False):
         import torch as _t
 
         e = self.e
         self.t += 1
-        prepared = getattr(self, "_prepared", None) == (idx.data_ptr(), tuple(idx.shape)) and not e.mv_fields
+        prepared = (getattr(self, "_prepared", None) == (idx.data_ptr(), tuple(idx.shape), idx._version)
+                    and not e.mv_fields)
         self._prepared = None
         g_bias = e.dlogit if (e.use_bias_tables and e._has_fm()) else None
         g_lin = e.dlogit if e.use_linear else None
