@@ -108,6 +108,19 @@ def test_full_size_properties(hip_lib, model):
     p64 = {k: v.double() for k, v in p.items()}
     loss_o, _, _, grads_o = T.fwd_bwd(model, p64, small, idx_small, dense[sl].cpu().double(), y[sl].cpu(), hp)
     assert abs(float(e.loss) - float(loss_o)) < 1e-5
+    # (example, unit) pairs of the DNN whose float64 pre-activation is within 1e-6 of 0: the only places where the
+    # GPU's fp32 rounding may legitimately take the other branch of relu / leaky_relu
+    n_flips = 0
+    if model in ("deepfm", "xdeepfm"):
+        E64, _ = T.feat_embedding_layer(p64, small, idx_small, use_bias=(model == "deepfm"))
+        a = T.dnn_input(E64, dense[sl].cpu().double())
+        act = T.act_fn(hp.get("deep_activation", "relu"))
+        for i in range(len(hp["deep_hidden_units"])):
+            z = a @ p64[f"dnn_layer_{i}_weights"] + p64[f"dnn_layer_{i}_bias"]
+            n_flips += int((z.abs() < 1e-6).sum())
+            a = act(z)
+    else:
+        n_flips = 2  # (DCN's wide layers: thousands of units per example - the old allowance of two entries)
     n_checked = 0
     for k, g in e.grads.items():
         if k == "linear_w_dense":
@@ -120,14 +133,19 @@ def test_full_size_properties(hip_lib, model):
         have = g.detach().cpu().double().reshape(-1)
         scale = float(want.abs().max())
         tol = 2e-5 * torch.clamp(want.abs(), min=0.1 * scale) if scale > 0 else torch.zeros_like(want)
-        # an activation whose pre-activation rounds to the other side of 0 on the GPU flips relu' for ONE
-        # (example, unit) and moves that unit's column by one summand: allow a handful of entries beyond
-        # the strict per-element bound, none beyond 1e-3 of the tensor's largest entry
+        # Strict per element - EXCEPT where the oracle itself says a relu' may have flipped: an activation whose
+        # float64 pre-activation lies within 1e-6 of 0 can round to the other side on the GPU, which moves that
+        # unit's column by one summand.  Entries beyond the bound are accepted only when such (example, unit)
+        # pairs exist in the slice, at most a column's worth per pair, and never beyond 1e-3 of the tensor's
+        # largest entry.  (Until round 3 up to 1 % of a tensor's entries were allowed off unconditionally - what a
+        # small indexing bug in a ragged tile would also look like.)
         err = (have - want).abs()
         off = int((err > tol).sum())
-        assert off <= max(2, want.numel() // 100), (f"dense grad {k}: {off} of {want.numel()} entries beyond the "
-                                                    f"per-element tolerance (max err {float(err.max()):.3e}, "
-                                                    f"tensor max {scale:.3e})")
+        # (a flip moves its unit's column of that layer's dW and, through dh, one example's share of the layers below)
+        allowed = n_flips * 4 * (int(g.shape[0]) if g.dim() == 2 else 1)
+        assert off <= allowed, (f"dense grad {k}: {off} of {want.numel()} entries beyond the per-element "
+                                f"tolerance with {n_flips} near-zero pre-activations in the slice "
+                                f"(max err {float(err.max()):.3e}, tensor max {scale:.3e})")
         assert float(err.max()) <= 1e-3 * scale, f"dense grad {k}: max err {float(err.max()):.3e} (tensor max {scale:.3e})"
         n_checked += 1
     assert n_checked >= 4, n_checked
