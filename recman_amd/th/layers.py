@@ -33,7 +33,7 @@ import torch
 
 from .. import engine as eng
 from .. import ops
-from .inputs import DenseFeat, SparseFeat
+from .inputs import DenseFeat, MultiValCsvFeat, SparseFeat, SparseValueFeat
 
 F32, I64 = torch.float32, torch.int64
 KERAS_EPS = 1e-7
@@ -109,16 +109,59 @@ class _GatherFn(torch.autograd.Function):
         return d_table, None, None
 
 
+def _csr_dev(inputs, name):
+    """(offsets, ids, vals or None) of a multi-valued / value feature on the GPU (DataInputs.mv holds the CSR)."""
+    cache = inputs.__dict__.setdefault("_mv_dev_cache", {})
+    if name not in cache:
+        c = inputs.mv[name]
+        dev = _device()
+        cache[name] = (torch.from_numpy(np.ascontiguousarray(c.offsets)).to(dev),
+                       torch.from_numpy(np.ascontiguousarray(c.ids)).to(dev),
+                       None if c.vals is None else torch.from_numpy(np.ascontiguousarray(c.vals)).to(dev, F32))
+    return cache[name]
+
+
+class _PoolFn(torch.autograd.Function):
+    """One multi-valued (MultiValCsvFeat: sqrtn combiner, layers.py:144-169) or value (SparseValueFeat: value *
+    row, bias unscaled, layers.py:129-142) feature: (E_f [B,D], bias_f [B]) through rm_pool_rows over a temporary
+    fused copy [V, D + 4] of the feature's table and bias table; backward rm_pool_rows_bwd."""
+
+    @staticmethod
+    def forward(ctx, table, bias, offsets, ids, vals):
+        V, D = table.shape
+        B = offsets.shape[0] - 1
+        fused = torch.zeros(V, D + 4, device=table.device, dtype=F32)
+        fused[:, :D] = table.detach()
+        if bias is not None:
+            fused[:, D] = bias.detach().reshape(-1)
+        out = torch.empty(B, D + 4, device=table.device, dtype=F32)
+        ops.pool_rows(fused, 0, D, offsets, ids, out, vals=vals)
+        ctx.save_for_backward(offsets, ids, vals)
+        ctx.shape, ctx.has_bias = (V, D), bias is not None
+        return out[:, :D].contiguous(), out[:, D].contiguous()
+
+    @staticmethod
+    def backward(ctx, dE, dbias):
+        offsets, ids, vals = ctx.saved_tensors
+        V, D = ctx.shape
+        d_table = torch.zeros(V, D, device=dE.device, dtype=F32)
+        d_bias = torch.zeros(V, device=dE.device, dtype=F32) if ctx.has_bias else None
+        ops.pool_rows_bwd(dE.contiguous(), dbias.contiguous() if ctx.has_bias else None, None, D, offsets, ids, 0,
+                          d_table, d_bias, None, vals=vals)
+        return d_table, (d_bias.view(V, 1) if ctx.has_bias else None), None, None, None
+
+
 class FeatEmbedding:
-    """layers.py:68-193, SparseFeat branch: one feature's table (+ bias table)."""
+    """layers.py:68-193: one feature's table (+ bias table).  SparseFeat (:117-128) features are gathered
+    together by FeatEmbeddingLayer; MultiValCsvFeat (:144-169) and SparseValueFeat (:129-142) through _PoolFn."""
 
     display_name = "FeatEmbedding"
 
     def __init__(self, variables, feat, embedding_size, l2_reg=0.00001, use_bias=True, prefix="", seed=2019):
         assert not isinstance(feat, DenseFeat)  # layers.py:85
-        if not isinstance(feat, SparseFeat):
-            raise NotImplementedError(f"feature {feat.name}: th.layers embeds SparseFeat only (the model "
-                                      "classes handle multi-valued / value features)")
+        if not isinstance(feat, (SparseFeat, MultiValCsvFeat, SparseValueFeat)):
+            raise NotImplementedError(f"feature {feat.name}: th.layers embeds SparseFeat, MultiValCsvFeat and "
+                                      "SparseValueFeat (the reference raises for the others too)")
         self.variables, self.feat, self.embedding_size = variables, feat, int(embedding_size)
         self.l2_reg, self.use_bias, self.prefix, self.seed = l2_reg, use_bias, prefix, seed
 
@@ -157,14 +200,33 @@ class FeatEmbeddingLayer:
         idx, _ = _dev_inputs(inputs)
         if idx.shape[1] != len(feats):
             raise ValueError("inputs were not loaded with this feature dictionary")
-        sizes = [f.feat_size for f in feats]
-        offs = torch.tensor(np.concatenate(([0], np.cumsum(sizes)[:-1])), dtype=I64, device=idx.device)
-        table = torch.cat([self.variables[f"{self.prefix}{f.name}_feat_embed"] for f in feats], 0)
-        E = _GatherFn.apply(table, idx, offs)
-        bias = None
-        if self.use_bias:
-            btab = torch.cat([self.variables[f"{self.prefix}{f.name}_feat_bias"] for f in feats], 0)
-            bias = btab[(idx + offs)]  # [B,F,1] (a torch lookup: B*F scalars)
+        mv = getattr(inputs, "mv", None) or {}
+        plain = [j for j, f in enumerate(feats) if f.name not in mv]
+        cols_e, cols_b = [None] * len(feats), [None] * len(feats)
+        if plain:  # the id features: ONE gather launch over their concatenated tables
+            pf = [feats[j] for j in plain]
+            sizes = [f.feat_size for f in pf]
+            offs = torch.tensor(np.concatenate(([0], np.cumsum(sizes)[:-1])), dtype=I64, device=idx.device)
+            table = torch.cat([self.variables[f"{self.prefix}{f.name}_feat_embed"] for f in pf], 0)
+            pidx = idx if len(plain) == len(feats) else idx[:, plain].contiguous()
+            Ep = _GatherFn.apply(table, pidx, offs)
+            bp = None
+            if self.use_bias:
+                btab = torch.cat([self.variables[f"{self.prefix}{f.name}_feat_bias"] for f in pf], 0)
+                bp = btab[(pidx + offs)]  # [B,Fp,1] (a torch lookup: B*Fp scalars)
+            if len(plain) == len(feats):
+                return Ep, bp
+            for k, j in enumerate(plain):
+                cols_e[j] = Ep[:, k]
+                cols_b[j] = bp[:, k] if bp is not None else None
+        for j, f in enumerate(feats):  # multi-valued / value features: pooled rows, one launch each
+            if f.name in mv:
+                offsets, ids, vals = _csr_dev(inputs, f.name)
+                bt = self.variables[f"{self.prefix}{f.name}_feat_bias"] if self.use_bias else None
+                e, b = _PoolFn.apply(self.variables[f"{self.prefix}{f.name}_feat_embed"], bt, offsets, ids, vals)
+                cols_e[j], cols_b[j] = e, b.view(-1, 1)
+        E = torch.stack(cols_e, 1)
+        bias = torch.stack(cols_b, 1) if self.use_bias else None
         return E, bias
 
     def l2(self):
@@ -194,22 +256,30 @@ class LinearCombiner:
 
     def __call__(self, inputs):
         dev = _device()
-        cols, offs, dcols, dpos = [], [], [], []
+        cols, offs, dcols, dpos, mvs = [], [], [], [], []
         at = 0
         for feat in self.linear_feats:
             if isinstance(feat, DenseFeat):
                 dcols.append(np.asarray(inputs[feat.name], dtype=np.float32).reshape(-1, 1))
                 dpos.append(at)
+            elif isinstance(feat, (MultiValCsvFeat, SparseValueFeat)):
+                # multi-hot count without slot 0 (utils.py:86-108) / value * one-hot (utils.py:70-71): weighted ids
+                offsets, ids, vals = _csr_dev(inputs, feat.name)
+                wts = vals if vals is not None else (ids >= 1).to(F32)
+                seg = torch.repeat_interleave(torch.arange(offsets.shape[0] - 1, device=dev), offsets[1:] - offsets[:-1])
+                mvs.append((at, ids, wts, seg))
             elif isinstance(feat, SparseFeat):
                 cols.append(np.asarray(inputs[feat.name], dtype=np.int64).reshape(-1, 1))
                 offs.append(at)
             else:
-                raise NotImplementedError(f"feature {feat.name}: th.layers handles SparseFeat / DenseFeat")
+                raise NotImplementedError(f"feature {feat.name}: th.layers handles SparseFeat / SparseValueFeat / "
+                                          "MultiValCsvFeat / DenseFeat")
             at += feat.feat_size
         idx = torch.from_numpy(np.concatenate(cols, 1)).to(dev) if cols else None
         dense = torch.from_numpy(np.concatenate(dcols, 1)).to(dev) if dcols else None
         self.output = _LinearInput(idx, torch.tensor(offs, dtype=I64, device=dev) if cols else None, dense,
                                    torch.tensor(dpos, dtype=I64, device=dev) if dcols else None, at)
+        self.output.mvs = mvs
         return self.output
 
 
@@ -273,8 +343,12 @@ class LinearLayer:
             if any(getattr(f, "_weights", None) for f in self.linear_feats):
                 mw = np.concatenate([np.asarray(f.weights, dtype=np.float64).reshape(-1) for f in self.linear_feats])
                 W = W + torch.from_numpy(mw.astype(np.float32)).to(W.device).view(-1, 1)
-        return _LinearFn.apply(W, self.variables[f"{self.prefix}linear_w0"], inputs.idx, inputs.lin_off,
-                               inputs.dense, inputs.dense_pos)
+        out = _LinearFn.apply(W, self.variables[f"{self.prefix}linear_w0"], inputs.idx, inputs.lin_off,
+                              inputs.dense, inputs.dense_pos)
+        for at, ids, wts, seg in getattr(inputs, "mvs", ()):  # multi-valued / value features: weighted ids
+            part = torch.zeros(out.shape[0], device=out.device, dtype=F32)
+            out = out + part.index_add(0, seg, W.view(-1)[at + ids] * wts).view(-1, 1)
+        return out
 
     def l2(self):
         return self.l2_reg * 0.5 * self.variables[f"{self.prefix}linear_w"].square().sum()
@@ -440,28 +514,42 @@ class DNN:
 # CIN
 # ------------------------------------------------------------------------------------------------
 class _CINFn(torch.autograd.Function):
-    """rm_cin_layer_fwd per layer + rm_rowdot; backward rm_cin_layer_bwd per layer (csrc/cin.hip, f32 MFMA)."""
+    """rm_cin_layer_fwd per layer + rm_rowdot; backward rm_cin_layer_bwd per layer (csrc/cin.hip, f32 MFMA).
+    masks: None, or the L + 1 keep masks of cin_dropout (the input E, layers.py:707-708, then every layer's maps
+    behind the activation, :740): a dropped layer's maps are scaled in place after its kernel and its pooled
+    columns re-summed; in the backward its upstream gradient ([next layer's dXk | g x cin_w]) is built explicitly
+    and scaled by mask / keep - as the xDeepFM engine does (engine.XDeepFMEngine._cin_fwd / _branches_bwd)."""
 
     @staticmethod
-    def forward(ctx, core, E, *params):
+    def forward(ctx, core, masks, E, *params):
         c = core
         B, m, D = E.shape
         c._alloc(B, m, D)
+        L = len(c.units)
+        keep = c.dropout
+        on = [bool(masks is not None and masks[i] is not None and keep[i] < 1) for i in range(L + 1)]
         X0 = E.detach().contiguous()
+        if on[0]:
+            X0 = X0 * (masks[0] / keep[0])
         xk = X0
         for i, n in enumerate(c.units):
             ops.cin_layer_fwd(X0, xk, c.Hs[i], c.variables[c.fname(i)].detach()[0], c.variables[c.bname(i)].detach(),
-                              c.act, c.maps[i], c.fws, pooled=c.pooled, pool_col0=c.pool_col0[i],
-                              pool_from=c.pool_from[i])
+                              c.act, c.maps[i], c.fws, pooled=None if on[i + 1] else c.pooled,
+                              pool_col0=c.pool_col0[i], pool_from=c.pool_from[i])
+            if on[i + 1]:
+                pf, c0 = c.pool_from[i], c.pool_col0[i]
+                c.maps[i].mul_(masks[i + 1] / keep[i + 1])
+                torch.sum(c.maps[i][:, pf:, :], dim=2, out=c.pooled[:, c0: c0 + n - pf])
             xk = c.maps[i]
         out = torch.empty(B, device=E.device, dtype=F32)
         ops.rowdot(c.pooled, c.variables[c.prefix + "cin_w"].detach().view(-1), c.variables[c.prefix + "cin_w0"].detach(), out)
-        ctx.core, ctx.X0 = core, X0
+        ctx.core, ctx.X0, ctx.masks, ctx.on = core, X0, masks, on
         return out.view(B, 1)
 
     @staticmethod
     def backward(ctx, g):
-        c, X0 = ctx.core, ctx.X0
+        c, X0, masks, on = ctx.core, ctx.X0, ctx.masks, ctx.on
+        keep = c.dropout
         B, m, D = X0.shape
         g = g.reshape(-1).contiguous()
         L = len(c.units)
@@ -474,13 +562,24 @@ class _CINFn(torch.autograd.Function):
             n, pf, c0 = c.units[i], c.pool_from[i], c.pool_col0[i]
             dW = torch.empty(m * c.Hs[i], n, device=g.device, dtype=F32)
             db = torch.empty(n, device=g.device, dtype=F32)
+            d_hidden = c.dxk[i + 1] if i + 1 < L else None
+            cwd, pfa = cw[c0: c0 + n - pf], pf
+            if on[i + 1]:
+                up = torch.empty_like(c.maps[i])
+                if pf:
+                    up[:, :pf] = d_hidden
+                up[:, pf:] = g.view(-1, 1, 1) * cw[c0: c0 + n - pf].view(1, -1, 1)
+                up.mul_(masks[i + 1] / keep[i + 1])
+                d_hidden, cwd, pfa = up, None, n
             ops.cin_layer_bwd(X0, X0 if i == 0 else c.maps[i - 1], c.Hs[i], c.variables[c.fname(i)].detach()[0], c.act,
                               c.maps[i], g, dX0, dW, db, c.bws, xk_is_x0=(i == 0),
-                              d_hidden=c.dxk[i + 1] if i + 1 < L else None, cin_w_direct=cw[c0: c0 + n - pf],
-                              pool_from=pf, accumulate_dx0=True, dXk=c.dxk[i] if i > 0 else None)
+                              d_hidden=d_hidden, cin_w_direct=cwd,
+                              pool_from=pfa, accumulate_dx0=True, dXk=c.dxk[i] if i > 0 else None)
             grads[c.fname(i)], grads[c.bname(i)] = dW.view(1, m * c.Hs[i], n), db
+        if on[0]:
+            dX0 = dX0 * (masks[0] / keep[0])
         grads[c.prefix + "cin_w"], grads[c.prefix + "cin_w0"] = d_cw.view(-1, 1), d_cw0
-        return (None, dX0) + tuple(grads[n] for n in c.names)
+        return (None, None, dX0) + tuple(grads[n] for n in c.names)
 
 
 class CIN:
@@ -496,9 +595,6 @@ class CIN:
         self.activation, self.dropout, self.l2_reg, self.prefix, self.seed = activation, list(dropout), l2_reg, prefix, seed
         assert len(self.cross_layer_units) > 0  # layers.py:656
         assert len(self.cross_layer_units) + 1 == len(self.dropout)  # :657
-        if any(k < 1 for k in self.dropout):
-            raise NotImplementedError("th.layers.CIN: dropout keep-probabilities must be 1 (the xDeepFM model class "
-                                      "implements cin_dropout)")
         self.units, self.act = self.cross_layer_units, eng.act_name(activation)
         self._shape = None
 
@@ -550,7 +646,12 @@ class CIN:
     def __call__(self, inputs):
         assert inputs.dim() == 3  # layers.py:698
         self._upsert_variables(inputs.shape[1])
-        return _CINFn.apply(self, inputs, *[self.variables[n] for n in self.names])
+        masks = None
+        if any(k < 1 for k in self.dropout):  # tf.nn.dropout on the input (:707-708) and on every layer's maps (:740)
+            B, _, D = inputs.shape
+            shapes = [tuple(inputs.shape)] + [(B, n, D) for n in self.units]
+            masks = [_keep_mask(sh, k) if k < 1 else None for sh, k in zip(shapes, self.dropout)]
+        return _CINFn.apply(self, masks, inputs, *[self.variables[n] for n in self.names])
 
     def l2(self):
         ws = [self.variables[self.fname(i)] for i in range(len(self.units))] + [self.variables[self.prefix + "cin_w"]]

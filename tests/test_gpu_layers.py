@@ -189,18 +189,93 @@ def test_dcn_graph_composed_from_layers_with_crossnet(hip_lib):
 
 
 def test_layers_reject_what_they_do_not_cover(hip_lib):
-    from recman_amd.th import FeatureDictionary, MultiValCsvFeat, SparseFeat
+    from recman_amd.th import FeatureDictionary, SparseFeat
     from recman_amd.th import layers as L
 
+    with pytest.raises(AssertionError):
+        L.CIN({}, [8, 8], "relu", [1, 0.9])           # one keep-probability per layer + the input (layers.py:657)
+
+    class SequenceFeat:                                # (raises in the reference too, inputs.py:443)
+        name, feat_size = "q", 4
+
     with pytest.raises(NotImplementedError):
-        L.CIN({}, [8, 8], "relu", [1, 0.9, 1])
-    fd = FeatureDictionary()
-    fd["g"] = MultiValCsvFeat("g", tags=("a", "b"))
-    with pytest.raises(NotImplementedError):
-        L.FeatEmbeddingLayer({}, fd, 8)
+        L.FeatEmbedding({}, SequenceFeat(), 8)
     fd2 = FeatureDictionary()
     fd2["s"] = SparseFeat("s", 3)
     with pytest.raises(ValueError):
         L.FeatEmbeddingLayer({}, fd2, 6)
     with pytest.raises(ValueError):
         L.create_loss(np.zeros(3), torch.zeros(3), task="ranking")
+
+
+def test_xdeepfm_from_layers_with_cin_dropout_and_a_multi_valued_feature(hip_lib, monkeypatch):
+    """th.layers.CIN with dropout (layers.py:707-708, 740) and FeatEmbeddingLayer / SparseLinearCombiner with a
+    MultiValCsvFeat (sqrtn-pooled lookup layers.py:144-169, multi-hot linear input utils.py:86-108) - composed as
+    xDeepFM._out composes them, against the oracle run with the SAME dropout masks."""
+    from recman_amd.th import MultiValCsvFeat
+    from recman_amd.th.inputs import CSR
+    from recman_amd.th import layers as L
+
+    spec, p, idx, dense, y, hp, fd, inp = _setup("xdeepfm", B=45, D=8, cin_units=(16, 8), scale=0.2)
+    mname = spec.sparse_names[2]
+    V = spec.feat_sizes[2]
+    ospec = T.Spec(spec.sparse_names, spec.feat_sizes, spec.dense_names, multi_names=[mname])
+    g = torch.Generator().manual_seed(3)
+    n = torch.randint(0, 4, (45,), generator=g)
+    n[1] = 0
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), n.cumsum(0)])
+    ids = torch.randint(0, V, (int(n.sum()),), generator=g)
+    mv = {mname: (offsets, ids)}
+    # the feature dictionary with the multi-valued feature in the same position
+    fd2 = type(fd)()
+    for k, f in fd.items():
+        fd2[k] = MultiValCsvFeat(name=mname, tags=tuple(f"t{i}" for i in range(V - 1))) if k == mname else f
+    assert fd2[mname].feat_size == V
+    inp.mv = {mname: CSR(offsets.numpy(), ids.numpy())}
+    inp.idx = inp.idx.copy()
+    inp.idx[:, 2] = 0
+    # deterministic dropout masks, shared with the oracle: input E, layer 0 maps, layer 1 maps
+    keep = [0.8, 0.7, 1.0]
+    shapes = [(45, 5, 8), (45, 16, 8), (45, 8, 8)]
+    gm = torch.Generator().manual_seed(4)
+    masks = [(torch.rand(*sh, generator=gm) < k).float() if k < 1 else None for sh, k in zip(shapes, keep)]
+    drawn = iter([m for m in masks if m is not None])
+    monkeypatch.setattr(L, "_keep_mask", lambda shape, k: next(drawn).cuda())
+    variables = {}
+
+    def out():
+        emb = L.FeatEmbeddingLayer(variables, fd2, 8, hp["embedding_l2_reg"], use_bias=False, seed=2019)
+        feat_embeds, _ = emb(inp)
+        linear_feats = fd2.linear_feats
+        linear = L.SparseLinearLayer(variables, linear_feats, hp["linear_l2_reg"])
+        linear_logit = linear(L.SparseLinearCombiner(linear_feats)(inp))
+        cin = L.CIN(variables, hp["cin_cross_layer_units"], hp["cin_activation"], keep, hp["cin_l2_reg"])
+        cin_logit = cin(feat_embeds)
+        dnn = L.DNN(variables, hp["deep_hidden_units"], [1, 1, 1], hp["deep_activation"], hp["deep_l2_reg"])
+        dnn_logit = dnn(L.DNNCombiner()([feat_embeds] + inp.dense_inputs(fd2)))
+        final_logit = linear_logit + cin_logit + dnn_logit
+        return L.PredictionLayer(variables, "classification")(final_logit), final_logit, [emb, linear, dnn, cin]
+
+    monkeypatch.setattr(L, "_keep_mask", lambda shape, k: torch.ones(*shape, device="cuda"))
+    out()  # creates the variables
+    # the oracle's parameters; linear_w random in the layers' own order (the reference's: sparse, value,
+    # multi-valued, dense features, utils.py:31-36 - the oracle spec stacks it the same way and reads it back
+    # from the variables below)
+    with torch.no_grad():
+        for k, v in variables.items():
+            if k == "linear_w":
+                v.copy_(0.2 * torch.randn(v.shape, generator=torch.Generator().manual_seed(8)).cuda())
+            else:
+                v.copy_(p[k].reshape(v.shape).cuda())
+    drawn = iter([m for m in masks if m is not None])
+    monkeypatch.setattr(L, "_keep_mask", lambda shape, k: next(drawn).cuda())
+    pred, logit, layers = out()
+    loss = L.create_loss(inp.y, pred) + sum(layer.l2() for layer in layers)
+    loss.backward()
+    hp_o = dict(hp, cin_dropout=keep)
+    p_o = {k: v.detach().cpu() for k, v in variables.items()}
+    loss_o, logit_o, pred_o, grads_o = T.fwd_bwd("xdeepfm", p_o, ospec, idx, dense, y, hp_o,
+                                                 masks={"cin": masks}, mv=mv)
+    assert float((logit.detach().cpu().reshape(-1) - logit_o).abs().max()) < 1e-5
+    assert abs(float(loss) - float(loss_o)) < 1e-5
+    _check_grads(variables, grads_o)
