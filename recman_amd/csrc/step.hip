@@ -214,6 +214,18 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
     }
   }
   const int64_t tstride = gridDim.x;
+  // per-lane offsets inside a slot's 1 KiB image, computed once: slice q of example n; element n of examples
+  // 4 es + q.  A slot's base is wave-uniform (field, ring buffer): base + lane offset is ONE add per access (a
+  // `slot is a field ? ring : dense ring` select on the per-lane pointer was two v_cndmask per access)
+  const int lo_slice = n * 64 + 16 * (q ^ swz(n));
+  int lo_col[4];
+#pragma unroll
+  for (int es = 0; es < 4; ++es) lo_col[es] = (4 * es + q) * 64 + 16 * ((n >> 2) ^ swz(4 * es + q)) + 4 * (n & 3);
+  const int lo_row = n * F * 64 + 16 * q;  // d_rows: example n, slice q (the field adds 64 f)
+  auto slot_base = [&](int j, int tile) {  // LDS byte offset of slot j's image of `tile` (wave-uniform)
+    const int ring = oX + ((tile + 6) % 3) * kXBufB + fld[j] * kSlotB, dn = oDense + (tile & 3) * kSlotB;
+    return __builtin_amdgcn_readfirstlane((sx[j] || !sv[j]) ? ring : dn);
+  };
   // this lane's piece of a row: DMA lane (example lane >> 2, position lane & 3); the bias / linear entry it sums
   // (floats 16 / 17 of the row: lanes with (lane & 1) == 0 take the bias entry, the others the linear weight)
   const int piece = 16 * ((lane & 3) ^ swz(lane >> 2));
@@ -248,18 +260,17 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
     {
       const int tb = s - 2, td = s + 1;
       const char *pub = smem + oPub + (tb & 1) * kPubB;
-      const char *xb = smem + oX + ((tb + 6) % 3) * kXBufB;
       char *xd = smem + oX + ((td + 3) % 3) * kXBufB;  // (the same buffer: tile s + 1 replaces tile s - 2)
       f32x4 dhB[2], gS, e4[kSlots];
       float dT[2][4], g, col[kSlots][4];
       if (hasB) {  // ---- R
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
-          const char *xs = sx[j] || !sv[j] ? xb + fld[j] * kSlotB : smem + oDense + (tb & 3) * kSlotB;
+          const char *xs = smem + slot_base(j, tb);
 #pragma unroll
           for (int es = 0; es < 4; ++es)  // x[example 4 es + q][k = n]: slice n >> 2 of that row
-            col[j][es] = *reinterpret_cast<const float *>(xs + (4 * es + q) * 64 + 16 * ((n >> 2) ^ swz(4 * es + q)) + 4 * (n & 3));
-          e4[j] = *reinterpret_cast<const f32x4 *>(xs + n * 64 + 16 * (q ^ swz(n)));
+            col[j][es] = *reinterpret_cast<const float *>(xs + lo_col[es]);
+          e4[j] = *reinterpret_cast<const f32x4 *>(xs + lo_slice);
         }
 #pragma unroll
         for (int uh = 0; uh < 2; ++uh) {
@@ -313,7 +324,7 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tail), rd, q == 0 ? base + 64 : 0x7ffffff0,
                                                  0, NT_OUT ? 2 : 0);
         } else {
-          const int off = ok ? (n * F + fld[i]) * 64 + 16 * q : 0x7ffffff0;
+          const int off = lo_row + __builtin_amdgcn_readfirstlane(ok ? fld[i] * 64 : 0x70000000);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, off, 0, NT_OUT ? 2 : 0);
         }
       };
@@ -370,13 +381,11 @@ __device__ __forceinline__ void step_worker(const StepArgs &a, char *smem, const
       const int younger = 1 + ((s - 3 >= 0) ? 2 * SP : 0) + 8 * (hasD ? 1 : 0) + 4 * SP * (hasB ? 1 : 0);
       wait_vm(younger);
       ST_ADD(3);  // wait for the tile's rows
-      const char *xb = smem + oX + (s % 3) * kXBufB;
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, S = acc0, Q = acc0;
       f32x4 x4[kSlots];
 #pragma unroll
       for (int j = 0; j < kSlots; ++j) {
-        const char *xs = sx[j] || !sv[j] ? xb + fld[j] * kSlotB : smem + oDense + (s & 3) * kSlotB;
-        x4[j] = *reinterpret_cast<const f32x4 *>(xs + n * 64 + 16 * (q ^ swz(n)));
+        x4[j] = *reinterpret_cast<const f32x4 *>(smem + slot_base(j, s) + lo_slice);
       }
 #pragma unroll
       for (int j = 0; j < kSlots; ++j) {
@@ -714,7 +723,7 @@ __global__ __launch_bounds__(512) void deepfm_step_kernel(StepArgs a) {
   if (wave < kWorkers) {
     // static priority for the younger half: waves 4..6 lose every arbitration (issue ports, the vector-memory queue)
     // against their SIMD partners 0..2 otherwise and run their phases AFTER them instead of beside them
-    if (RM_STEP_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (RM_STEP_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     step_worker<NT, NT_OUT, PACKED>(a, smem, wave, lane, T);
   } else {
     if (RM_STEP_PRIO) __builtin_amdgcn_s_setprio(2);  // the head's epilogue is one dependent chain: never make it queue
