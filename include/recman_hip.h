@@ -449,6 +449,12 @@ int rm_pool_rows_bwd(const float *d_rows, int64_t dr_stride, const float *g_bias
  *                 whole table, 1.7 - 25.6 GB at the BASELINE configs): the two coincide when every row is touched
  *                 each step; DESIGN.md section 6.
  *   workspace: rm_sparse_optimizer_workspace(B * F) BYTES.
+ *   max_field_rows: 0, or a promise that lets the sort work per field: field f owns the rows
+ *                 [field_off[f], field_off[f+1]) (the last one up to R), ascending and disjoint, none with more
+ *                 than max_field_rows rows, F <= 64.  The ids are then sorted as F independent lists of B keys of
+ *                 log2(max_field_rows) bits (csrc/optim.hip, "field-segmented sort": 2 passes for < 2^20 rows per
+ *                 field instead of 4 over log2(R) bits); an id beyond its own field's rows is skipped like a
+ *                 negative one.  0: one sort of all B * F (row, occurrence) pairs, any field_off.
  * rm_sparse_optimizer_prepare: the id-only part of a step (keys + stable sort by table row) on its own,
  *   so that it can be issued before / beside the forward+backward pass; the following step call on the
  *   same ids passes prepared = 1 and the same workspace (ids: idx [n/F, F] + field_off, or row_ids [n]).
@@ -458,14 +464,14 @@ int rm_pool_rows_bwd(const float *d_rows, int64_t dr_stride, const float *g_bias
  * rm_dense_optimizer_step: the same update rule on a flat parameter buffer (dense parameters). */
 int64_t rm_sparse_optimizer_workspace(int64_t n);
 int rm_sparse_optimizer_prepare(const int64_t *idx, const int64_t *field_off, const int64_t *row_ids,
-                                int64_t n, int F, int64_t R, void *workspace, int64_t ws_bytes,
-                                rm_stream_t stream);
+                                int64_t n, int F, int64_t R, int64_t max_field_rows, void *workspace,
+                                int64_t ws_bytes, rm_stream_t stream);
 int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field_off, const float *d_rows,
                              const float *g_bias, const float *g_lin, int64_t B, int F, int D,
                              int64_t R, float *rows, int64_t ld, float *mom, int step, int kind,
                              float lr, float beta1, float beta2, float eps, int reset, float l2_embedding,
-                             float l2_linear, const float *lin_field_mask, int prepared, void *workspace,
-                             int64_t ws_bytes, rm_stream_t stream);
+                             float l2_linear, const float *lin_field_mask, int64_t max_field_rows, int prepared,
+                             void *workspace, int64_t ws_bytes, rm_stream_t stream);
 int rm_sparse_optimizer_step_rows(const int64_t *row_ids, const float *grad_rows, int64_t gw, int64_t n,
                                   int D, int64_t R, float *rows, int64_t ld, float *mom, int step, int kind,
                                   float lr, float beta1, float beta2, float eps, int reset, float l2_embedding,

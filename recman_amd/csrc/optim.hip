@@ -12,8 +12,10 @@
 // Store-then-sum instead of float atomics (MI355X_MICROARCH.md, Global float atomics: scattered 72-byte
 // segments are the slow shape, and the sum order would depend on arrival):
 //   1. keys     key[o] = global row of occurrence o (or R = "skip"), val[o] = o: iterators, never stored
-//   2. sort     stable LSD radix sort of (key, val) on the bits of R (rocPRIM device radix sort - a plain
-//               library primitive, like a library GEMM; the hot kernels around it are hand-written)
+//   2. sort     stable LSD radix sort of (key, val): per FIELD on the field's own bits with hand-written
+//               passes ("field-segmented sort" below) when the caller vouches for disjoint per-field row ranges
+//               (max_field_rows > 0: the [B, F] id batches of the engines); otherwise - row_ids lists, the
+//               sharded table's owner side - rocPRIM's device radix sort on the bits of R
 //   3. apply    one lane group per DISTINCT row (the first position of each run of equal keys): sums
 //               the run's gradient rows in occurrence order - fixed order, bit-reproducible - and
 //               updates parameter row and moments in ONE pass; nothing else is written.
@@ -67,7 +69,10 @@ __global__ __launch_bounds__(kBlock) void sparse_keys_kernel(const int64_t *__re
                                                             uint32_t *__restrict__ vals,
                                                             uint32_t *__restrict__ long_count) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *long_count = 0;  // this step's long-run ticket counter
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    long_count[0] = 0;  // this step's long-run ticket counter
+    long_count[1] = 0;  // the sorted list: two arrays
+  }
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += stride) {
     int64_t r;
     if (row_ids != nullptr) {
@@ -180,6 +185,16 @@ __device__ __forceinline__ void apply_row(float *__restrict__ rows, int64_t ld, 
   }
 }
 
+// The sorted (row, occurrence) list as the apply kernels read it: two arrays (the sort over all pairs), or ONE
+// array of 8-byte pairs starting at `keys` (the field-segmented sort: its last pass then scatters one store per
+// element instead of two).  Word 1 of the workspace header says which (written by the keys kernel of the sort).
+struct Sorted {
+  const uint32_t *keys, *vals;
+  bool pairs;
+  __device__ __forceinline__ uint32_t key(int64_t i) const { return pairs ? keys[2 * i] : keys[i]; }
+  __device__ __forceinline__ uint32_t val(int64_t i) const { return pairs ? keys[2 * i + 1] : vals[i]; }
+};
+
 // G lanes per sorted position (power of two >= GE + 2); a lane group takes kPos ADJACENT positions and
 // issues each level of their loads together.  The chain keys -> {occurrence, row, moments, gradient row}
 // -> update is dependent memory round trips (a wave lived 6.3 us with one position per group, 75 % of it
@@ -198,15 +213,16 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_kernel(
   const int sub = threadIdx.x % G;
   const int64_t base = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G) * kPos;
   if (base >= n) return;
+  const Sorted sd = {keys, vals, long_count[1] != 0};
   // keys base-1 .. base+kPos and the occurrence ids in one batch of loads (clamped at the ends)
   uint32_t k[kPos + 2], o[kPos];
 #pragma unroll
   for (int u = 0; u < kPos + 2; ++u) {
     const int64_t i = base - 1 + u;
-    k[u] = keys[i < 0 ? 0 : (i < n ? i : n - 1)];
+    k[u] = sd.key(i < 0 ? 0 : (i < n ? i : n - 1));
   }
 #pragma unroll
-  for (int u = 0; u < kPos; ++u) o[u] = vals[base + u < n ? base + u : n - 1];
+  for (int u = 0; u < kPos; ++u) o[u] = sd.val(base + u < n ? base + u : n - 1);
   bool head[kPos], more[kPos];
 #pragma unroll
   for (int u = 0; u < kPos; ++u) {
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_kernel(
     const int64_t i = base + u;
     const uint32_t kk = k[u + 1];
     int len = 2;
-    while (len <= kLong && i + len < n && keys[i + len] == kk) ++len;
+    while (len <= kLong && i + len < n && sd.key(i + len) == kk) ++len;
     if (len > kLong) {
       if (sub == 0) {
         const uint32_t slot = atomicAdd(long_count, 1u);  // (an integer ticket: order does not matter)
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_kernel(
       continue;
     }
     for (int j = 1; j < len; ++j) {
-      const float4 t = grad_slice<GE>(src, vals[i + j], sub, D);
+      const float4 t = grad_slice<GE>(src, sd.val(i + j), sub, D);
       g[u].x += t.x; g[u].y += t.y; g[u].z += t.z; g[u].w += t.w;
     }
   }
@@ -262,9 +278,10 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_long_kernel(
   __shared__ float4 part[kBlock];
   const int sub = threadIdx.x % G, grp = threadIdx.x / G;
   const uint32_t count = *long_count;
+  const Sorted sd = {keys, vals, long_count[1] != 0};
   for (uint32_t s = blockIdx.x; s < count; s += gridDim.x) {
     const int64_t i0 = long_list[s];
-    const uint32_t k = keys[i0];
+    const uint32_t k = sd.key(i0);
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     int64_t i = i0 + grp;
     while (true) {
@@ -274,8 +291,8 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_long_kernel(
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int64_t iu = i + (int64_t)u * NG;
-        ok[u] = iu < n && keys[iu < n ? iu : n - 1] == k;
-        o[u] = vals[iu < n ? iu : n - 1];
+        ok[u] = iu < n && sd.key(iu < n ? iu : n - 1) == k;
+        o[u] = sd.val(iu < n ? iu : n - 1);
       }
       float4 t[4];
 #pragma unroll
@@ -316,6 +333,194 @@ __global__ __launch_bounds__(kBlock) void dense_opt_kernel(float *__restrict__ p
   }
 }
 
+// ---- field-segmented sort ---------------------------------------------------------------------------------
+// The ids of a [B, F] batch whose fields own disjoint, ascending row ranges (field_off) are F independent
+// sorting problems of B keys of log2(rows per field) bits, and the occurrence number b * F + f need not be
+// carried: only b.  rocPRIM's radix_sort_pairs sorts all n = B * F (key, occurrence) pairs over log2(R) bits in
+// 4 passes of 7 bits (138 us for 1.7 M pairs, R = 26 M); here: keys field-major [F][Bp], then per field an LSD
+// radix sort of ceil(bits / 10)-bit digits - two passes for up to 2^20 - 1 rows per field.  A pass is three
+// launches: per-(field, 1024-element sub-block) digit counts, their prefix over the sub-blocks, the stable
+// scatter.  One WAVE owns a sub-block: its 16 rounds of 64 elements rank themselves with one ballot per digit
+// bit (lanes holding the same digit), no barrier anywhere.  The last pass writes the arrays the apply kernels
+// read: global row (R for a skipped id) and occurrence number, field f at [f * B, (f + 1) * B).
+constexpr int kFsSub = 1024;                 // elements per sub-block (one wave: 16 rounds of 64)
+constexpr int kFsRounds = kFsSub / 64;
+constexpr int kFsMaxFields = 64;
+constexpr int kFsMaxDigitBits = 10;
+constexpr uint32_t kFsSkip = 0xFFFFFFFFu;    // every digit of it is the largest: sorts behind the field's rows
+
+struct FsPlan {
+  int npass, dbits;
+  int64_t Bp, nsb;  // examples padded to whole sub-blocks, sub-blocks per field
+};
+
+// transposes a tile of 64 examples x F fields through LDS: coalesced 8-byte reads, 256-byte runs per field out
+__global__ __launch_bounds__(kBlock) void fs_keys_kernel(const int64_t *__restrict__ idx,
+                                                        const int64_t *__restrict__ field_off, int F, int64_t B,
+                                                        int64_t Bp, int64_t R, uint32_t max_rows,
+                                                        uint32_t *__restrict__ kf,
+                                                        uint32_t *__restrict__ long_count) {
+  __shared__ uint32_t tile[64 * kFsMaxFields];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    long_count[0] = 0;  // this step's long-run ticket counter
+    long_count[1] = 1;  // the sorted list: (row, occurrence) pairs
+  }
+  const int64_t b0 = (int64_t)blockIdx.x * 64;
+  const int cnt = 64 * F;
+  for (int e = threadIdx.x; e < cnt; e += kBlock) {
+    const int64_t o = b0 * F + e;
+    const int f = e % F;
+    uint32_t k = kFsSkip;
+    if (o < B * F) {
+      const int64_t id = idx[o];
+      const int64_t lo = field_off[f], hi = f + 1 < F ? field_off[f + 1] : R;
+      int64_t rows = (hi < R ? hi : R) - lo;
+      if (rows > (int64_t)max_rows) rows = max_rows;
+      if (id >= 0 && id < rows) k = (uint32_t)id;
+    }
+    tile[e] = k;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < cnt; e += kBlock) {
+    const int f = e >> 6, j = e & 63;
+    kf[(int64_t)f * Bp + b0 + j] = tile[j * F + f];
+  }
+}
+
+// Block -> (field, group of 4 sub-blocks), XCD-aware: consecutive workgroups go round-robin to the 8 XCDs, each
+// with its own L2.  All blocks of a field run on ONE XCD (field f on XCD f % 8), so the 4-byte scattered writes
+// of its 64 sub-blocks into the same lines of the field's segment merge in that L2 before they reach HBM
+// (spread over the XCDs every L2 wrote its own partial lines: 39 us per scatter instead of 25).
+__device__ __forceinline__ bool fs_where(int F, int64_t nsb, int w, int64_t *f, int64_t *sb) {
+  const int64_t nbf = (nsb + kBlock / 64 - 1) / (kBlock / 64);  // blocks per field
+  const int64_t x = blockIdx.x % 8, q = blockIdx.x / 8;
+  *f = (q / nbf) * 8 + x;
+  *sb = (q % nbf) * (kBlock / 64) + w;
+  return *f < F && *sb < nsb;
+}
+
+// lanes of the wave holding the same digit as this lane (dbits ballots)
+__device__ __forceinline__ uint64_t fs_match(uint32_t d, int dbits) {
+  uint64_t m = ~0ull;
+  for (int b = 0; b < dbits; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const uint64_t bm = __ballot(bit);
+    m &= bit ? bm : ~bm;
+  }
+  return m;
+}
+
+// digit counts of every sub-block: cnt[f][sb][d]
+// (ks: 1 = plain keys, 2 = the (key, example) pairs an earlier pass wrote)
+__global__ __launch_bounds__(kBlock) void fs_count_kernel(const uint32_t *__restrict__ kin, int ks, int F,
+                                                         int64_t Bp, int64_t nsb, int shift, int dbits,
+                                                         uint32_t *__restrict__ cnt) {
+  extern __shared__ uint32_t fs_lds[];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int64_t f, sb;
+  if (!fs_where(F, nsb, w, &f, &sb)) return;  // (wave-uniform; the kernel has no barrier)
+  const int64_t gw = f * nsb + sb;
+  const int nd = 1 << dbits;
+  uint32_t *run = fs_lds + w * nd;
+  for (int d = lane; d < nd; d += 64) run[d] = 0;
+  const uint32_t *kp = kin + (f * Bp + sb * kFsSub) * ks;
+  uint32_t key[kFsRounds];
+#pragma unroll
+  for (int r = 0; r < kFsRounds; ++r) key[r] = kp[(r * 64 + lane) * ks];
+#pragma unroll
+  for (int r = 0; r < kFsRounds; ++r) atomicAdd(&run[(key[r] >> shift) & (nd - 1)], 1u);  // (integer: order-free)
+  uint32_t *c = cnt + gw * nd;
+  for (int d = lane; d < nd; d += 64) c[d] = run[d];
+}
+
+// per field and digit: exclusive prefix of the counts over the sub-blocks (in place) and the digit's total
+__global__ __launch_bounds__(64) void fs_scan_kernel(uint32_t *__restrict__ cnt, int64_t nsb, int dbits,
+                                                    uint32_t *__restrict__ tot) {
+  const int nd = 1 << dbits;
+  const int per = nd / 64;                       // blocks per field
+  const int64_t f = blockIdx.x / per;
+  const int d = (blockIdx.x % per) * 64 + threadIdx.x;
+  uint32_t *c = cnt + f * nsb * nd + d;
+  uint32_t run = 0;
+  int64_t sb = 0;
+  for (; sb + 16 <= nsb; sb += 16) {
+    uint32_t v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = c[(sb + u) * nd];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { c[(sb + u) * nd] = run; run += v[u]; }
+  }
+  for (; sb < nsb; ++sb) { const uint32_t v = c[sb * nd]; c[sb * nd] = run; run += v; }
+  tot[f * nd + d] = run;
+}
+
+// the stable scatter of one pass.  Between passes an element travels as ONE 8-byte (key, example) pair (one
+// scattered store instead of two); FINAL: writes the (row, occurrence) arrays of the apply kernels
+template <bool FINAL>
+__global__ __launch_bounds__(kBlock) void fs_scatter_kernel(
+    const uint32_t *__restrict__ kin, const uint2 *__restrict__ pin, uint2 *__restrict__ pout,
+    const uint32_t *__restrict__ cnt,
+    const uint32_t *__restrict__ tot, int F, int64_t B, int64_t Bp, int64_t nsb, int shift, int dbits,
+    const int64_t *__restrict__ field_off, uint32_t R) {
+  extern __shared__ uint32_t fs_lds[];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int64_t f, sb;
+  if (!fs_where(F, nsb, w, &f, &sb)) return;
+  const int64_t gw = f * nsb + sb;
+  const int nd = 1 << dbits, per = nd / 64;
+  uint32_t *run = fs_lds + w * nd;
+  const int64_t e0 = f * Bp + sb * kFsSub;
+  uint32_t key[kFsRounds], val[kFsRounds];
+  if (pin) {
+#pragma unroll
+    for (int r = 0; r < kFsRounds; ++r) {
+      const uint2 t = pin[e0 + r * 64 + lane];
+      key[r] = t.x;
+      val[r] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < kFsRounds; ++r) {
+      key[r] = kin[e0 + r * 64 + lane];
+      val[r] = (uint32_t)(sb * kFsSub + r * 64 + lane);
+    }
+  }
+  {
+    // run[d] = (elements of smaller digits in the field) + (elements of digit d in earlier sub-blocks)
+    const uint32_t *t = tot + f * nd + lane * per;
+    const uint32_t *c = cnt + gw * nd + lane * per;
+    uint32_t sum = 0;
+    for (int j = 0; j < per; ++j) sum += t[j];
+    uint32_t inc = sum;  // inclusive scan of the lanes' sums
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const uint32_t up = __shfl_up(inc, s);
+      if (lane >= s) inc += up;
+    }
+    uint32_t at = inc - sum;
+    for (int j = 0; j < per; ++j) { run[lane * per + j] = at + c[j]; at += t[j]; }
+  }
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t off = FINAL ? (uint32_t)field_off[f] : 0u;
+#pragma unroll
+  for (int r = 0; r < kFsRounds; ++r) {
+    const uint32_t d = (key[r] >> shift) & (nd - 1);
+    const uint64_t m = fs_match(d, dbits);
+    const uint32_t rank = __popcll(m & lt);
+    const uint32_t base = run[d];
+    if (rank == 0) run[d] = base + (uint32_t)__popcll(m);  // (a wave's LDS operations complete in order)
+    const int64_t pos = base + rank;
+    if (FINAL) {
+      if (pos < B) {  // the padding and the skipped ids sort last; positions >= B are padding only
+        const uint32_t row = key[r] == kFsSkip ? R : off + key[r];
+        pout[f * B + pos] = make_uint2(row < R ? row : R, val[r] * (uint32_t)F + (uint32_t)f);
+      }
+    } else {
+      pout[f * Bp + pos] = make_uint2(key[r], val[r]);
+    }
+  }
+}
+
 int bits_for(uint32_t R) {  // bits needed to represent the value R itself (the "skip" key)
   int b = 1;
   while (b < 32 && (R >> b) != 0) ++b;
@@ -325,9 +530,10 @@ int bits_for(uint32_t R) {  // bits needed to represent the value R itself (the 
 struct WsLayout {
   size_t keys_in, vals_in, keys_out, vals_out, long_list, sort_temp, total;
   size_t sort_bytes;
+  size_t fs_k, fs_p[2], fs_cnt, fs_tot;  // the field-segmented sort's buffers
 };
 // the first 256 bytes of the workspace: word 0 = the long-run ticket counter (cleared by the keys kernel
-// of every step)
+// of every step), word 1 = the form of the sorted list (struct Sorted)
 constexpr size_t kWsHeader = 256;
 
 
@@ -345,6 +551,13 @@ int ws_layout(int64_t n, WsLayout *w) {
   w->long_list = at; at += up(((size_t)n / kLong + 2) * 4);
   w->sort_temp = at; at += up(sort_bytes);
   w->sort_bytes = sort_bytes;
+  // field-major keys, padded per field to whole sub-blocks (<= kFsMaxFields fields); (key, example) pairs,
+  // twice; one count per (sub-block, digit); one total per (field, digit)
+  const size_t np = (size_t)n + (size_t)kFsMaxFields * kFsSub;
+  w->fs_k = at; at += up(np * 4);
+  for (int i = 0; i < 2; ++i) { w->fs_p[i] = at; at += up(np * 8); }
+  w->fs_cnt = at; at += up((np / kFsSub + 1) * ((size_t)4 << kFsMaxDigitBits));
+  w->fs_tot = at; at += up((size_t)kFsMaxFields * ((size_t)4 << kFsMaxDigitBits));
   w->total = at;
   return RM_OK;
 }
@@ -362,10 +575,25 @@ OptArgs opt_args(int step, int kind, float lr, float beta1, float beta2, float e
   return a;
 }
 
+// plan of the field-segmented sort, or npass = 0 when it does not apply (then: rocPRIM over all n pairs)
+FsPlan fs_plan(int F, int64_t B, int64_t max_field_rows, const int64_t *row_ids) {
+  FsPlan p = {0, 0, 0, 0};
+  if (row_ids || max_field_rows <= 0 || max_field_rows >= ((int64_t)1 << 30) || F > kFsMaxFields) return p;
+  int bits = 1;
+  while (((int64_t)1 << bits) < max_field_rows + 1) ++bits;  // 2^bits - 1 ("skip") above every id
+  p.npass = (bits + kFsMaxDigitBits - 1) / kFsMaxDigitBits;
+  p.dbits = (bits + p.npass - 1) / p.npass;
+  if (p.dbits < 6) p.dbits = 6;  // (64 digits: one per lane in the scatter's prefix)
+  p.nsb = (B + kFsSub - 1) / kFsSub;
+  p.Bp = p.nsb * kFsSub;
+  return p;
+}
+
 // keys + stable sort of the occurrences by table row: depends on the ids only, so a caller may issue it
 // (rm_sparse_optimizer_prepare) before / beside the forward+backward pass that produces the gradients
 int sparse_prepare(const int64_t *idx, const int64_t *field_off, int F, const int64_t *row_ids, int64_t n,
-                   int64_t R, void *workspace, int64_t ws_bytes, hipStream_t st, const char *fn) {
+                   int64_t R, int64_t max_field_rows, void *workspace, int64_t ws_bytes, hipStream_t st,
+                   const char *fn) {
   RM_REQUIRE(n > 0 && n < (int64_t)1 << 31 && R > 0 && R < ((int64_t)1 << 32) - 1, "%s: n / R out of range", fn);
   RM_REQUIRE(row_ids || (idx && field_off && F > 0), "%s: NULL ids", fn);
   WsLayout w;
@@ -375,6 +603,36 @@ int sparse_prepare(const int64_t *idx, const int64_t *field_off, int F, const in
   char *base = (char *)workspace;
   uint32_t *keys_in = (uint32_t *)(base + w.keys_in), *vals_in = (uint32_t *)(base + w.vals_in);
   uint32_t *keys = (uint32_t *)(base + w.keys_out), *vals = (uint32_t *)(base + w.vals_out);
+  const FsPlan p = fs_plan(F, row_ids ? 0 : n / F, max_field_rows, row_ids);
+  if (p.npass > 0) {
+    const int64_t B = n / F;
+    uint32_t *k0 = (uint32_t *)(base + w.fs_k);
+    uint2 *pr[2] = {(uint2 *)(base + w.fs_p[0]), (uint2 *)(base + w.fs_p[1])};
+    uint32_t *cnt = (uint32_t *)(base + w.fs_cnt), *tot = (uint32_t *)(base + w.fs_tot);
+    hipLaunchKernelGGL(fs_keys_kernel, dim3((unsigned)(p.Bp / 64)), dim3(kBlock), 0, st, idx, field_off, F, B,
+                       p.Bp, R, (uint32_t)max_field_rows, k0, (uint32_t *)base);
+    const int nd = 1 << p.dbits;
+    const int64_t nbf = (p.nsb + kBlock / 64 - 1) / (kBlock / 64);
+    const dim3 wgrid((unsigned)(((F + 7) / 8) * 8 * nbf));  // fs_where: field f on XCD f % 8
+    const size_t lds = (size_t)(kBlock / 64) * nd * 4;
+    for (int pass = 0; pass < p.npass; ++pass) {
+      const int shift = pass * p.dbits;
+      const uint2 *pin = pass == 0 ? nullptr : pr[(pass - 1) & 1];
+      hipLaunchKernelGGL(fs_count_kernel, wgrid, dim3(kBlock), lds, st, pin ? (const uint32_t *)pin : k0,
+                         pin ? 2 : 1, F, p.Bp, p.nsb, shift, p.dbits, cnt);
+      hipLaunchKernelGGL(fs_scan_kernel, dim3((unsigned)(F * (nd / 64))), dim3(64), 0, st, cnt, p.nsb, p.dbits,
+                         tot);
+      if (pass + 1 == p.npass)
+        // (the pairs take the place of BOTH output arrays: vals_out follows keys_out)
+        hipLaunchKernelGGL((fs_scatter_kernel<true>), wgrid, dim3(kBlock), lds, st, k0, pin, (uint2 *)keys, cnt,
+                           tot, F, B, p.Bp, p.nsb, shift, p.dbits, field_off, (uint32_t)R);
+      else
+        hipLaunchKernelGGL((fs_scatter_kernel<false>), wgrid, dim3(kBlock), lds, st, k0, pin, pr[pass & 1], cnt,
+                           tot, F, B, p.Bp, p.nsb, shift, p.dbits, field_off, (uint32_t)R);
+    }
+    RM_CHECK_LAUNCH(fn);
+    return RM_OK;
+  }
   hipLaunchKernelGGL(sparse_keys_kernel, dim3(rm_grid_cap((n + kBlock - 1) / kBlock, 256 * 8)), dim3(kBlock), 0,
                      st, idx, field_off, F, row_ids, n, (uint32_t)R, keys_in, vals_in, (uint32_t *)base);
   size_t sort_bytes = w.sort_bytes;
@@ -390,8 +648,8 @@ int sparse_prepare(const int64_t *idx, const int64_t *field_off, int F, const in
 __global__ void opt_clear_word_kernel(uint32_t *w) { *w = 0; }
 
 int sparse_step(const int64_t *idx, const int64_t *field_off, int F, const int64_t *row_ids, int64_t n,
-                GradSrc src, int D, int64_t R, float *rows, int64_t ld, float *mom, OptArgs a, int prepared,
-                void *workspace, int64_t ws_bytes, hipStream_t st, const char *fn) {
+                GradSrc src, int D, int64_t R, int64_t max_field_rows, float *rows, int64_t ld, float *mom,
+                OptArgs a, int prepared, void *workspace, int64_t ws_bytes, hipStream_t st, const char *fn) {
   RM_REQUIRE(n < (int64_t)1 << 31 && R > 0 && R < ((int64_t)1 << 32) - 1, "%s: n / R out of range", fn);
   RM_REQUIRE(D % 4 == 0 && D >= 8 && D <= 64 && ld % 4 == 0 && ld >= D + 8,
              "%s: need D %% 4 == 0, 8 <= D <= 64 and a row stride ld >= D + 8 floats, ld %% 4 == 0 (D=%d ld=%lld)",
@@ -399,7 +657,7 @@ int sparse_step(const int64_t *idx, const int64_t *field_off, int F, const int64
   RM_REQUIRE(rows && rm_aligned16(rows) && (a.kind == 2 || (mom && rm_aligned16(mom))), "%s: rows / mom NULL or unaligned", fn);
   RM_REQUIRE(src.rows && rm_aligned16(src.rows) && src.ld % 4 == 0, "%s: gradient rows NULL / unaligned", fn);
   if (!prepared) {
-    int rc = sparse_prepare(idx, field_off, F, row_ids, n, R, workspace, ws_bytes, st, fn);
+    int rc = sparse_prepare(idx, field_off, F, row_ids, n, R, max_field_rows, workspace, ws_bytes, st, fn);
     if (rc != RM_OK) return rc;
   } else if (workspace) {
     // a prepared sort may be consumed more than once (the same ids stepped twice): the long-run ticket counter
@@ -453,10 +711,11 @@ extern "C" int64_t rm_sparse_optimizer_workspace(int64_t n) {
 }
 
 extern "C" int rm_sparse_optimizer_prepare(const int64_t *idx, const int64_t *field_off, const int64_t *row_ids,
-                                           int64_t n, int F, int64_t R, void *workspace, int64_t ws_bytes,
-                                           rm_stream_t stream) {
+                                           int64_t n, int F, int64_t R, int64_t max_field_rows,
+                                           void *workspace, int64_t ws_bytes, rm_stream_t stream) {
   if (n == 0) return RM_OK;
-  return sparse_prepare(idx, field_off, F, row_ids, n, R, workspace, ws_bytes, (hipStream_t)stream,
+  RM_REQUIRE(row_ids || (F > 0 && n % F == 0), "rm_sparse_optimizer_prepare: n is not a multiple of F");
+  return sparse_prepare(idx, field_off, F, row_ids, n, R, max_field_rows, workspace, ws_bytes, (hipStream_t)stream,
                         "rm_sparse_optimizer_prepare");
 }
 
@@ -465,14 +724,15 @@ extern "C" int rm_sparse_optimizer_step(const int64_t *idx, const int64_t *field
                                         int64_t R, float *rows, int64_t ld, float *mom, int step, int kind,
                                         float lr, float beta1, float beta2, float eps, int reset,
                                         float l2_embedding, float l2_linear,
-                                        const float *lin_field_mask, int prepared, void *workspace,
+                                        const float *lin_field_mask, int64_t max_field_rows, int prepared,
+                                        void *workspace,
                                         int64_t ws_bytes, rm_stream_t stream) {
   RM_REQUIRE(B >= 0 && F > 0, "rm_sparse_optimizer_step: bad sizes");
   RM_REQUIRE(kind >= 0 && kind <= 2 && step >= 1, "rm_sparse_optimizer_step: bad kind / step");
   if (B == 0) return RM_OK;
   RM_REQUIRE(prepared || (idx && field_off), "rm_sparse_optimizer_step: NULL argument");
   GradSrc src = {0, d_rows, D, g_bias, g_lin, lin_field_mask, F};
-  return sparse_step(idx, field_off, F, nullptr, B * F, src, D, R, rows, ld, mom,
+  return sparse_step(idx, field_off, F, nullptr, B * F, src, D, R, max_field_rows, rows, ld, mom,
                      opt_args(step, kind, lr, beta1, beta2, eps, reset, l2_embedding, l2_linear), prepared,
                      workspace, ws_bytes, (hipStream_t)stream, "rm_sparse_optimizer_step");
 }
@@ -487,7 +747,7 @@ extern "C" int rm_sparse_optimizer_step_rows(const int64_t *row_ids, const float
   if (n == 0) return RM_OK;
   RM_REQUIRE(prepared || row_ids, "rm_sparse_optimizer_step_rows: NULL argument");
   GradSrc src = {1, grad_rows, gw, nullptr, nullptr, nullptr, 1};
-  return sparse_step(nullptr, nullptr, 1, row_ids, n, src, D, R, rows, ld, mom,
+  return sparse_step(nullptr, nullptr, 1, row_ids, n, src, D, R, 0, rows, ld, mom,
                      opt_args(step, kind, lr, beta1, beta2, eps, reset, l2_embedding, l2_linear), prepared,
                      workspace, ws_bytes, (hipStream_t)stream, "rm_sparse_optimizer_step_rows");
 }

@@ -499,9 +499,11 @@ def _opt_ws(workspace, n):
     return workspace.data_ptr(), workspace.numel()
 
 
-def sparse_optimizer_prepare(workspace, R, idx=None, field_off=None, row_ids=None):
+def sparse_optimizer_prepare(workspace, R, idx=None, field_off=None, row_ids=None, max_field_rows=0):
     """The id-only part of a row-wise step (keys + stable sort) on the current stream
-    (rm_sparse_optimizer_prepare); follow it with sparse_optimizer_step(..., prepared=True)."""
+    (rm_sparse_optimizer_prepare); follow it with sparse_optimizer_step(..., prepared=True).
+    max_field_rows > 0: the fields own disjoint ascending row ranges of at most that many rows (the sort then runs
+    per field on the local ids)."""
     if row_ids is not None:
         n, F = row_ids.numel(), 1
     else:
@@ -509,12 +511,12 @@ def sparse_optimizer_prepare(workspace, R, idx=None, field_off=None, row_ids=Non
     wp, wn = _opt_ws(workspace, n)
     _lib.call("rm_sparse_optimizer_prepare", _chk(idx, "idx", I64, allow_none=True),
               _chk(field_off, "field_off", I64, allow_none=True), _chk(row_ids, "row_ids", I64, allow_none=True),
-              n, F, int(R), wp, wn, _stream())
+              n, F, int(R), int(max_field_rows), wp, wn, _stream())
 
 
 def sparse_optimizer_step(idx, field_off, d_rows, rows, mom, workspace, step, kind, lr, D=None,
                           g_bias=None, g_lin=None, reset=False, beta1=0.9, beta2=0.999, eps=1e-7,
-                          lin_field_mask=None, prepared=False, l2_embedding=0.0, l2_linear=0.0):
+                          lin_field_mask=None, prepared=False, l2_embedding=0.0, l2_linear=0.0, max_field_rows=0):
     """Lazy row-wise optimizer step on table rows [R, ld] (see rm_sparse_optimizer_step): rows =
     [D emb | bias | lin | m_b | m_l | v_b | v_l | pad], mom [R, 2D] = [m | v] of the embedding."""
     B, F, Dg = d_rows.shape
@@ -529,8 +531,8 @@ def sparse_optimizer_step(idx, field_off, d_rows, rows, mom, workspace, step, ki
               _chk(g_lin, "g_lin", F32, (B,), allow_none=True), B, F, D, R, _chk(rows, "rows", F32), ld,
               None if mom is None else mom.data_ptr(), int(step), OPT_KINDS[kind], float(lr), float(beta1),
               float(beta2), float(eps), 1 if reset else 0, float(l2_embedding), float(l2_linear),
-              _chk(lin_field_mask, "lin_field_mask", F32, (F,), allow_none=True), 1 if prepared else 0,
-              wp, wn, _stream())
+              _chk(lin_field_mask, "lin_field_mask", F32, (F,), allow_none=True), int(max_field_rows),
+              1 if prepared else 0, wp, wn, _stream())
 
 
 def sparse_optimizer_step_rows(row_ids, grad_rows, D, rows, mom, workspace, step, kind, lr, reset=False,

@@ -178,6 +178,14 @@ class SparseTableOptimizer:
         names = self.e.spec.linear_names
         return names is None or self.e.spec.sparse_names[f] in names
 
+    def _max_field_rows(self):
+        """The engine's fields own consecutive row ranges of feat_sizes[f] rows (engine.py, field_off = their running
+        sum): the step may sort the ids per field (rm_sparse_optimizer_step, max_field_rows).  Hyper-parameter
+        optimizer_sort = "rows" keeps the one sort over all (row, occurrence) pairs."""
+        if self.e.hp.get("optimizer_sort", "fields") != "fields" or len(self.e.spec.feat_sizes) > 64:
+            return 0
+        return int(max(self.e.spec.feat_sizes))
+
     def prepare(self, idx):
         """The id-only part of the next step (keys + stable sort by row) on the CURRENT stream: a third
         of a step's time that needs no gradient - fit() issues it on a side stream beside the
@@ -186,7 +194,7 @@ class SparseTableOptimizer:
         if e.spec.scratch_names:
             return  # (the expanded occurrence lists of multi-valued features are built in step())
         self.ops.sparse_optimizer_prepare(self._workspace(idx.numel()), e.rows.shape[0], idx=idx,
-                                          field_off=e.field_off)
+                                          field_off=e.field_off, max_field_rows=self._max_field_rows())
         # (the sort is tied to the tensor's CONTENT: data pointer, shape and torch's version counter, which every
         # in-place write - a feeder refilling a static input buffer - advances)
         self._prepared = (idx.data_ptr(), tuple(idx.shape), idx._version)
@@ -209,7 +217,8 @@ class SparseTableOptimizer:
             idx, e.field_off, e.d_rows, e.rows, self.mom, self._workspace(B * F), self.t,
             self.name, self.lr, g_bias=g_bias, g_lin=g_lin, reset=reset,
             lin_field_mask=getattr(e, "lin_field_mask", None), prepared=prepared,
-            l2_embedding=self.l2_embedding, l2_linear=self.l2_linear if e.use_linear else 0.0)
+            l2_embedding=self.l2_embedding, l2_linear=self.l2_linear if e.use_linear else 0.0,
+            max_field_rows=self._max_field_rows())
         for f in e.mv_fields:
             offsets, ids, vals = e._mv_entry(f)
             n = offsets[1:] - offsets[:-1]
@@ -240,7 +249,7 @@ class SparseTableOptimizer:
         per_row = 2 * ld_bytes + (2 * 2 * D * 4 if self.mom is not None else 0)
         work = n * (8 + 4 * D + 8) + distinct * per_row
         gbs = work / (ms * 1e-3) / 1e9
-        return {"kernel": "rm_sparse_optimizer_step (keys + radix sort + sparse_apply_kernel)", "bound": "hbm",
+        return {"kernel": "rm_sparse_optimizer_step (keys + field-segmented radix sort + sparse_apply_kernel)", "bound": "hbm",
                 "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
                 "algorithmic_per_step": work, "occurrences": n, "distinct_rows": distinct,
                 "bytes": "per occurrence idx 8 + gradient row 4D + sorted pair 8; per distinct row "

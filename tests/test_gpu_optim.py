@@ -366,3 +366,74 @@ def test_prepared_step_equals_the_one_call_step(hip_lib):
         assert torch.equal(e1.rows, e2.rows) and torch.equal(s1.mom, s2.mom)
     m, v = s1.moments()
     assert m.shape == (e1.rows.shape[0], 16) and float(v.min()) >= 0 and float(m.abs().max()) > 0
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=4000, sizes=[3, 50, 100000]),                        # long runs, two passes, ragged last sub-block
+    dict(B=1024, sizes=[1]),                                    # one row: everything is one run
+    dict(B=2500, sizes=[(1 << 20) - 1, 17, 1 << 20, 5]),        # 2^20 rows: the 21st bit -> three passes
+    dict(B=1, sizes=[9, 9]),
+    dict(B=70000, sizes=[1000001] * 5 + [40]),                  # the Criteo field size, > 64 sub-blocks per field
+    dict(B=300, sizes=[2] * 64),                                # the field limit
+], ids=lambda c: f"B{c['B']}F{len(c['sizes'])}")
+def test_field_segmented_sort_equals_the_sort_over_all_pairs(hip_lib, case):
+    """max_field_rows > 0 (ids sorted per field on their local bits, csrc/optim.hip) leaves the SAME table and
+    moments, bit for bit, as the one stable sort over all (row, occurrence) pairs: the runs of equal rows hold
+    the same occurrences in the same order.  Negative ids are skipped by both."""
+    from recman_amd import ops
+
+    B, sizes, D = case["B"], case["sizes"], 16
+    F = len(sizes)
+    g = torch.Generator().manual_seed(5)
+    cols = []
+    for v in sizes:
+        c = torch.randint(0, v, (B,), generator=g)
+        if v > 1000:  # heavy duplicates inside a large field as well
+            c[: B // 3] = c[: B // 3] % 7
+        cols.append(c)
+    idx = torch.stack(cols, 1)
+    idx[::11, 0] = -1
+    if F > 1:
+        idx[5::13, F - 1] = -1
+    idx = idx.cuda()
+    foff = torch.tensor([0] + list(np.cumsum(sizes)[:-1]), dtype=torch.int64).cuda()
+    R, LD = int(sum(sizes)), 2 * D
+    d_rows = torch.randn(B, F, D, generator=g).cuda()
+    gb, gl = torch.randn(B, generator=g).cuda(), torch.randn(B, generator=g).cuda()
+    rows0 = torch.randn(R, LD, generator=g).cuda()
+    rows0[:, D + 2: D + 6] = 0
+    ws = torch.zeros(ops.sparse_optimizer_workspace(B * F), dtype=torch.uint8, device="cuda")
+    outs = []
+    for mfr in (0, max(sizes)):
+        rows, mom = rows0.clone(), torch.zeros(R, 2 * D, device="cuda")
+        for t in (1, 2):
+            ops.sparse_optimizer_step(idx, foff, d_rows, rows, mom, ws, t, "adam", 0.01, g_bias=gb, g_lin=gl,
+                                      max_field_rows=mfr, l2_embedding=1e-3)
+        # the prepared form
+        ops.sparse_optimizer_prepare(ws, R, idx=idx, field_off=foff, max_field_rows=mfr)
+        ops.sparse_optimizer_step(idx, foff, d_rows, rows, mom, ws, 3, "adam", 0.01, g_bias=gb, g_lin=gl,
+                                  max_field_rows=mfr, prepared=True)
+        torch.cuda.synchronize()
+        outs.append((rows, mom))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not torch.equal(outs[0][0], rows0)
+
+
+def test_field_segmented_sort_skips_ids_beyond_their_field(hip_lib):
+    from recman_amd import ops
+
+    D, sizes, B = 8, [5, 7], 64
+    idx = torch.stack([torch.arange(B) % 9, torch.arange(B) % 7], 1).cuda()   # field 0: ids 5..8 are not its rows
+    foff = torch.tensor([0, 5]).cuda()
+    rows0 = torch.randn(12, 16).cuda()
+    rows0[:, D + 2: D + 6] = 0
+    d_rows = torch.randn(B, 2, D).cuda()
+    ws = torch.zeros(ops.sparse_optimizer_workspace(B * 2), dtype=torch.uint8, device="cuda")
+    ok = idx.clone()
+    ok[:, 0] = torch.where(ok[:, 0] < 5, ok[:, 0], torch.full_like(ok[:, 0], -1))
+    outs = []
+    for ids, mfr in ((idx, 7), (ok, 7), (ok, 0)):
+        rows = rows0.clone()
+        ops.sparse_optimizer_step(ids, foff, d_rows, rows, None, ws, 1, "sgd", 0.1, max_field_rows=mfr)
+        outs.append(rows)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
