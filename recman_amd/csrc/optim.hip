@@ -37,7 +37,23 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kLong = 32;  // runs longer than this many positions go to the one-wave-per-run kernel
+// Runs of up to kLong positions are summed by their lane group in sparse_apply_kernel, one member per round trip
+// (occurrence -> gradient row); longer ones go to the long-run kernels in segments of kSeg positions, one WAVE
+// each with kLongFlight members in flight per lane group.  Zipf(1.05) ids at configs[1] (rows with up to 6,100
+// occurrences, ~15 k runs longer than 8), sparse step in us by kLong: 2: 719, 4: 500, 8: 355, 16: 336, 32: 372,
+// 64: 389 (handing a run over costs a gallop for its end and a ticket from one counter); round 2 had one BLOCK
+// per run and kLong = 32: 660.
+#ifndef RM_OPT_LONG
+#define RM_OPT_LONG 16
+#endif
+constexpr int kLong = RM_OPT_LONG;
+constexpr int kSeg = 128;
+constexpr int kLongFlight = 8;  // members in flight per lane group of the long-run kernel
+// workspace header words (cleared by the keys kernel of every step)
+constexpr int kHdrSegs = 0;   // segments of long runs listed so far (a ticket counter)
+constexpr int kHdrPairs = 1;  // form of the sorted list (struct Sorted)
+constexpr int kHdrMulti = 2;  // runs of more than one segment listed so far
+constexpr int kHdrParts = 3;  // segment sums handed out
 
 struct GradSrc {
   // mode 0: d_rows [n, D] + per-example g_bias / g_lin [n / F] (+ per-field linear mask)
@@ -67,11 +83,11 @@ __global__ __launch_bounds__(kBlock) void sparse_keys_kernel(const int64_t *__re
                                                             const int64_t *__restrict__ row_ids, int64_t n,
                                                             uint32_t R, uint32_t *__restrict__ keys,
                                                             uint32_t *__restrict__ vals,
-                                                            uint32_t *__restrict__ long_count) {
+                                                            uint32_t *__restrict__ hdr) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    long_count[0] = 0;  // this step's long-run ticket counter
-    long_count[1] = 0;  // the sorted list: two arrays
+    hdr[kHdrSegs] = hdr[kHdrMulti] = hdr[kHdrParts] = 0;  // this step's ticket counters
+    hdr[kHdrPairs] = 0;  // the sorted list: two arrays
   }
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += stride) {
     int64_t r;
@@ -209,11 +225,11 @@ template <int G, int GE>
 __global__ __launch_bounds__(kBlock) void sparse_apply_kernel(
     const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t n, uint32_t R,
     GradSrc src, int D, float *__restrict__ rows, int64_t ld, float *__restrict__ mom, OptArgs a,
-    uint32_t *__restrict__ long_list, uint32_t *__restrict__ long_count) {
+    uint4 *__restrict__ seg_list, uint4 *__restrict__ multi_list, uint32_t *__restrict__ hdr) {
   const int sub = threadIdx.x % G;
   const int64_t base = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G) * kPos;
   if (base >= n) return;
-  const Sorted sd = {keys, vals, long_count[1] != 0};
+  const Sorted sd = {keys, vals, hdr[kHdrPairs] != 0};
   // keys base-1 .. base+kPos and the occurrence ids in one batch of loads (clamped at the ends)
   uint32_t k[kPos + 2], o[kPos];
 #pragma unroll
@@ -243,15 +259,39 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_kernel(
 #pragma unroll
   for (int u = 0; u < kPos; ++u) {
     if (!more[u]) continue;
-    // run length, capped: longer runs are handed to the one-block-per-run kernel
+    // run length, capped: longer runs are handed to the long-run kernels, in segments of kSeg positions
     const int64_t i = base + u;
     const uint32_t kk = k[u + 1];
     int len = 2;
     while (len <= kLong && i + len < n && sd.key(i + len) == kk) ++len;
     if (len > kLong) {
+      // the run's end: gallop, then bisect (a run is contiguous: "key == kk" is true up to its end, then false)
+      int64_t lo = i + kLong, hi, step = kLong;
+      while (true) {
+        const int64_t t = lo + step;
+        if (t >= n) { hi = n; break; }
+        if (sd.key(t) == kk) { lo = t; step <<= 1; } else { hi = t; break; }
+      }
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sd.key(mid) == kk) lo = mid; else hi = mid;
+      }
       if (sub == 0) {
-        const uint32_t slot = atomicAdd(long_count, 1u);  // (an integer ticket: order does not matter)
-        long_list[slot] = (uint32_t)i;
+        // (integer tickets: the ORDER of the lists does not matter - every segment's members, every run's segment
+        // order and so every sum are fixed)
+        const int64_t L = hi - i;
+        const uint32_t nseg = (uint32_t)((L + kSeg - 1) / kSeg);
+        const uint32_t at = atomicAdd(&hdr[kHdrSegs], nseg);
+        uint32_t part = 0xFFFFFFFFu;
+        if (nseg > 1) {
+          part = atomicAdd(&hdr[kHdrParts], nseg);
+          multi_list[atomicAdd(&hdr[kHdrMulti], 1u)] = make_uint4(kk, part, nseg, 0u);
+        }
+        for (uint32_t q = 0; q < nseg; ++q) {
+          const int64_t s0 = i + (int64_t)q * kSeg;
+          seg_list[at + q] = make_uint4((uint32_t)s0, (uint32_t)(hi - s0 < kSeg ? hi - s0 : kSeg), kk,
+                                        nseg > 1 ? part + q : 0xFFFFFFFFu);
+        }
       }
       head[u] = false;
       continue;
@@ -266,55 +306,88 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_kernel(
     if (head[u]) apply_row<G, GE>(rows, ld, mom, D, k[u + 1], sub, g[u], st[u], a);
 }
 
-// one BLOCK per long run: its 256 / G lane groups take the members round-robin (each in ascending
-// order, four independent gradient rows in flight per group), the group sums are then added in group
-// order through LDS - a fixed order, bit-reproducible
+// one WAVE per SEGMENT (<= kSeg positions) of a long run: its 64 / G lane groups take the members round-robin
+// (each in ascending order, kLongFlight independent gradient rows in flight per group), the group sums are then added
+// in group order through LDS - a fixed order, bit-reproducible.  A run of one segment is applied here; the
+// segments of a longer run (a hot row of a Zipf batch: thousands of occurrences - one block per RUN walked them
+// in 48 dependent rounds) leave their sums in `partials`, combined in segment order by sparse_apply_combine_kernel.
 template <int G, int GE>
 __global__ __launch_bounds__(kBlock) void sparse_apply_long_kernel(
-    const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t n, GradSrc src, int D,
+    const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, GradSrc src, int D,
     float *__restrict__ rows, int64_t ld, float *__restrict__ mom, OptArgs a,
-    const uint32_t *__restrict__ long_list, const uint32_t *__restrict__ long_count) {
-  constexpr int NG = kBlock / G;
+    const uint4 *__restrict__ seg_list, float4 *__restrict__ partials, const uint32_t *__restrict__ hdr) {
+  constexpr int NG = 64 / G;
   __shared__ float4 part[kBlock];
-  const int sub = threadIdx.x % G, grp = threadIdx.x / G;
-  const uint32_t count = *long_count;
-  const Sorted sd = {keys, vals, long_count[1] != 0};
-  for (uint32_t s = blockIdx.x; s < count; s += gridDim.x) {
-    const int64_t i0 = long_list[s];
-    const uint32_t k = sd.key(i0);
+  const int lane = threadIdx.x & 63, sub = lane % G, grp = lane / G;
+  float4 *wpart = part + (threadIdx.x - lane);  // this wave's 64 slots: no barrier anywhere
+  const uint32_t count = hdr[kHdrSegs];
+  const uint32_t nwaves = gridDim.x * (kBlock / 64);
+  const Sorted sd = {keys, vals, hdr[kHdrPairs] != 0};
+  for (uint32_t s = (blockIdx.x * kBlock + threadIdx.x) >> 6; s < count; s += nwaves) {
+    const uint4 e = seg_list[s];
+    const int64_t end = (int64_t)e.x + e.y;
+    RowState st;
+    if (grp == 0 && e.w == 0xFFFFFFFFu) st = load_row<GE>(rows, ld, mom, D, e.z, sub, a);  // in flight beside the members
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    int64_t i = i0 + grp;
-    while (true) {
-      // up to four members of this group per round, their loads issued together
-      bool ok[4];
-      uint32_t o[4];
+    for (int64_t i = (int64_t)e.x + grp; i < end; i += kLongFlight * NG) {
+      // up to kLongFlight members of this group per round, their loads issued together
+      uint32_t o[kLongFlight];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kLongFlight; ++u) {
         const int64_t iu = i + (int64_t)u * NG;
-        ok[u] = iu < n && sd.key(iu < n ? iu : n - 1) == k;
-        o[u] = sd.val(iu < n ? iu : n - 1);
+        o[u] = sd.val(iu < end ? iu : end - 1);
       }
-      float4 t[4];
+      float4 t[kLongFlight];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = grad_slice<GE>(src, o[u], sub, D);
+      for (int u = 0; u < kLongFlight; ++u) t[u] = grad_slice<GE>(src, o[u], sub, D);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ok[u]) { g.x += t[u].x; g.y += t[u].y; g.z += t[u].z; g.w += t[u].w; }
-      if (!ok[3]) break;
-      i += 4 * NG;
+      for (int u = 0; u < kLongFlight; ++u)
+        if (i + (int64_t)u * NG < end) { g.x += t[u].x; g.y += t[u].y; g.z += t[u].z; g.w += t[u].w; }
     }
-    part[threadIdx.x] = g;
-    __syncthreads();
+    wpart[lane] = g;
+    __builtin_amdgcn_wave_barrier();  // (a wave's LDS operations complete in order; this pins the program order)
     if (grp == 0) {
-      float4 tot = part[sub];
+      float4 tot = wpart[sub];
       for (int q = 1; q < NG; ++q) {
-        const float4 t = part[q * G + sub];
+        const float4 t = wpart[q * G + sub];
         tot.x += t.x; tot.y += t.y; tot.z += t.z; tot.w += t.w;
       }
-      const RowState st = load_row<GE>(rows, ld, mom, D, k, sub, a);
-      apply_row<G, GE>(rows, ld, mom, D, k, sub, tot, st, a);
+      if (e.w == 0xFFFFFFFFu) {
+        apply_row<G, GE>(rows, ld, mom, D, e.z, sub, tot, st, a);
+      } else {
+        partials[(int64_t)e.w * G + sub] = tot;
+      }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// one lane group per run of several segments: the segment sums in segment order, then the update
+template <int G, int GE>
+__global__ __launch_bounds__(kBlock) void sparse_apply_combine_kernel(
+    int D, float *__restrict__ rows, int64_t ld, float *__restrict__ mom, OptArgs a,
+    const uint4 *__restrict__ multi_list, const float4 *__restrict__ partials, const uint32_t *__restrict__ hdr) {
+  const int sub = threadIdx.x % G;
+  const uint32_t count = hdr[kHdrMulti];
+  const uint32_t groups = gridDim.x * (kBlock / G);
+  for (uint32_t m = (blockIdx.x * kBlock + threadIdx.x) / G; m < count; m += groups) {
+    const uint4 e = multi_list[m];
+    const RowState st = load_row<GE>(rows, ld, mom, D, e.x, sub, a);
+    const float4 *p = partials + (int64_t)e.y * G + sub;
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t q = 0;
+    for (; q + 4 <= e.z; q += 4) {
+      float4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = p[(int64_t)(q + u) * G];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { tot.x += t[u].x; tot.y += t[u].y; tot.z += t[u].z; tot.w += t[u].w; }
+    }
+    for (; q < e.z; ++q) {
+      const float4 t = p[(int64_t)q * G];
+      tot.x += t.x; tot.y += t.y; tot.z += t.z; tot.w += t.w;
+    }
+    apply_row<G, GE>(rows, ld, mom, D, e.x, sub, tot, st, a);
   }
 }
 
@@ -359,11 +432,11 @@ __global__ __launch_bounds__(kBlock) void fs_keys_kernel(const int64_t *__restri
                                                         const int64_t *__restrict__ field_off, int F, int64_t B,
                                                         int64_t Bp, int64_t R, uint32_t max_rows,
                                                         uint32_t *__restrict__ kf,
-                                                        uint32_t *__restrict__ long_count) {
+                                                        uint32_t *__restrict__ hdr) {
   __shared__ uint32_t tile[64 * kFsMaxFields];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    long_count[0] = 0;  // this step's long-run ticket counter
-    long_count[1] = 1;  // the sorted list: (row, occurrence) pairs
+    hdr[kHdrSegs] = hdr[kHdrMulti] = hdr[kHdrParts] = 0;  // this step's ticket counters
+    hdr[kHdrPairs] = 1;  // the sorted list: (row, occurrence) pairs
   }
   const int64_t b0 = (int64_t)blockIdx.x * 64;
   const int cnt = 64 * F;
@@ -528,12 +601,12 @@ int bits_for(uint32_t R) {  // bits needed to represent the value R itself (the 
 }
 
 struct WsLayout {
-  size_t keys_in, vals_in, keys_out, vals_out, long_list, sort_temp, total;
+  size_t keys_in, vals_in, keys_out, vals_out, seg_list, multi_list, partials, sort_temp, total;
   size_t sort_bytes;
   size_t fs_k, fs_p[2], fs_cnt, fs_tot;  // the field-segmented sort's buffers
 };
-// the first 256 bytes of the workspace: word 0 = the long-run ticket counter (cleared by the keys kernel
-// of every step), word 1 = the form of the sorted list (struct Sorted)
+// the first 256 bytes of the workspace: the header words kHdr* (ticket counters, cleared by the keys kernel of
+// every step; the form of the sorted list)
 constexpr size_t kWsHeader = 256;
 
 
@@ -548,7 +621,11 @@ int ws_layout(int64_t n, WsLayout *w) {
   w->vals_in = at; at += up((size_t)n * 4);
   w->keys_out = at; at += up((size_t)n * 4);
   w->vals_out = at; at += up((size_t)n * 4);
-  w->long_list = at; at += up(((size_t)n / kLong + 2) * 4);
+  // long runs: a run has > kLong positions, a run of several segments > kSeg: <= n / kLong + n / kSeg segments,
+  // <= n / kSeg such runs with <= 2 n / kSeg segment sums of (at most) 64 lanes x 16 bytes between them
+  w->seg_list = at; at += up(((size_t)n / kLong + (size_t)n / kSeg + 2) * 16);
+  w->multi_list = at; at += up(((size_t)n / kSeg + 2) * 16);
+  w->partials = at; at += up((2 * (size_t)n / kSeg + 2) * 1024);
   w->sort_temp = at; at += up(sort_bytes);
   w->sort_bytes = sort_bytes;
   // field-major keys, padded per field to whole sub-blocks (<= kFsMaxFields fields); (key, example) pairs,
@@ -645,7 +722,7 @@ int sparse_prepare(const int64_t *idx, const int64_t *field_off, int F, const in
   return RM_OK;
 }
 
-__global__ void opt_clear_word_kernel(uint32_t *w) { *w = 0; }
+__global__ void opt_clear_word_kernel(uint32_t *w) { w[kHdrSegs] = w[kHdrMulti] = w[kHdrParts] = 0; }
 
 int sparse_step(const int64_t *idx, const int64_t *field_off, int F, const int64_t *row_ids, int64_t n,
                 GradSrc src, int D, int64_t R, int64_t max_field_rows, float *rows, int64_t ld, float *mom,
@@ -670,8 +747,9 @@ int sparse_step(const int64_t *idx, const int64_t *field_off, int F, const int64
              "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)w.total);
   char *base = (char *)workspace;
   uint32_t *keys = (uint32_t *)(base + w.keys_out), *vals = (uint32_t *)(base + w.vals_out);
-  uint32_t *long_list = (uint32_t *)(base + w.long_list);
-  uint32_t *long_count = (uint32_t *)base;
+  uint4 *seg_list = (uint4 *)(base + w.seg_list), *multi_list = (uint4 *)(base + w.multi_list);
+  float4 *partials = (float4 *)(base + w.partials);
+  uint32_t *hdr = (uint32_t *)base;
   const int GE = D / 4;
   int G = 2;
   while (G < GE + 2) G <<= 1;
@@ -681,9 +759,11 @@ int sparse_step(const int64_t *idx, const int64_t *field_off, int F, const int64
 #define RM_OPT_LAUNCH(G_, GE_)                                                                               \
   {                                                                                                          \
     hipLaunchKernelGGL((sparse_apply_kernel<G_, GE_>), grid, dim3(kBlock), 0, st, keys, vals, n, (uint32_t)R, \
-                       src, D, rows, ld, mom, a, long_list, long_count);                                     \
-    hipLaunchKernelGGL((sparse_apply_long_kernel<G_, GE_>), dim3(1024), dim3(kBlock), 0, st, keys, vals, n, src, \
-                       D, rows, ld, mom, a, long_list, long_count);                                          \
+                       src, D, rows, ld, mom, a, seg_list, multi_list, hdr);                                 \
+    hipLaunchKernelGGL((sparse_apply_long_kernel<G_, GE_>), dim3(8192), dim3(kBlock), 0, st, keys, vals, src, \
+                       D, rows, ld, mom, a, seg_list, partials, hdr);                                        \
+    hipLaunchKernelGGL((sparse_apply_combine_kernel<G_, GE_>), dim3(64), dim3(kBlock), 0, st, D, rows, ld,   \
+                       mom, a, multi_list, partials, hdr);                                                   \
   }
   switch (GE) {
     case 2: RM_OPT_LAUNCH(4, 2) break;
