@@ -424,6 +424,20 @@ int rm_pool_rows(const float *rows, int64_t row0, int LD, int D, const int64_t *
 int rm_pool_rows_bwd(const float *d_rows, int64_t dr_stride, const float *g_bias, const float *g_lin,
                      int D, const int64_t *offsets, const int64_t *ids, const float *vals, int64_t B,
                      int64_t row0, float *d_table, float *d_bias, float *d_lin, rm_stream_t stream);
+/* The same pooling in PADDED form, for the row-sharded table's fixed-capacity exchange (recman_amd/dist.py): the
+ * tags of a feature are T columns of the occurrence matrix - ids[b * ids_ld + t], -1 = no tag - and the row of tag
+ * (b, t) is rows[pos[b * pos_ld + t]] (a position among the rows received from their owners; rows are LD floats).
+ * vals[b * vals_ld + t] or NULL as above.  rm_pool_rows_padded writes the pooled rows out [B, LD] (same sums,
+ * same order as rm_pool_rows); rm_pack_pooled_grad_rows writes each tag's gradient row
+ * [d_rows[b] * we | g_bias[b] * wb | g_lin[b] * wl | 0 ..] (width floats; the factors of rm_pool_rows_bwd) at
+ * out[pos[b, t]]: the send buffer of the backward all_to_all, every tag its own slot, no atomics. */
+int rm_pool_rows_padded(const float *rows, int LD, int D, const int64_t *pos, int64_t pos_ld, const int64_t *ids,
+                        int64_t ids_ld, const float *vals, int64_t vals_ld, int64_t B, int T, float *out,
+                        rm_stream_t stream);
+int rm_pack_pooled_grad_rows(const float *d_rows, int64_t dr_stride, const float *g_bias, const float *g_lin,
+                             int D, const int64_t *pos, int64_t pos_ld, const int64_t *ids, int64_t ids_ld,
+                             const float *vals, int64_t vals_ld, int64_t B, int T, int width, float *out,
+                             rm_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer steps.  Replace optimizer.minimize(...) of xDeepFM.py:121-126 / create_optimizer
@@ -486,8 +500,9 @@ int rm_dense_optimizer_step(float *p, const float *g, float *m, float *v, int64_
 /* Buckets the n = B*F occurrences (b,f) by the owner rank of their global row
  * g = field_off[f] + idx[b,f] (owner g % world, local row g / world) - a deterministic
  * counting sort:  pos[o] = position of occurrence o in the bucketed order,
- * send_ids[pos[o]] = g / world, counts[w] = occurrences owned by rank w.
- * workspace: rm_shard_route_workspace(world) int32 words.  world <= 16. */
+ * send_ids[pos[o]] = g / world, counts[w] = occurrences owned by rank w.  An EMPTY occurrence (idx < 0: the
+ * padding of a multi-valued feature's tag columns, see rm_pool_rows_padded) takes no slot: pos[o] = -1, counted
+ * nowhere.  workspace: rm_shard_route_workspace(world) int32 words.  world <= 16. */
 int64_t rm_shard_route_workspace(int world);
 int rm_shard_route(const int64_t *idx, const int64_t *field_off, int64_t B, int F, int world,
                    int64_t *pos, int64_t *send_ids, int64_t *counts, int32_t *workspace,

@@ -65,6 +65,8 @@ SIGNATURES = {
                          c_int, P, c_int, P, I64, P, P, P, I64, P],
     "rm_pool_rows": [P, I64, c_int, c_int, P, P, P, I64, P, P],
     "rm_pool_rows_bwd": [P, I64, P, P, c_int, P, P, P, I64, I64, P, P, P, P],
+    "rm_pool_rows_padded": [P, c_int, c_int, P, I64, P, I64, P, I64, I64, c_int, P, P],
+    "rm_pack_pooled_grad_rows": [P, I64, P, P, c_int, P, I64, P, I64, P, I64, I64, c_int, c_int, P, P],
     "rm_sparse_optimizer_prepare": [P, P, P, I64, c_int, I64, I64, P, I64, P],
     "rm_sparse_optimizer_step": [P, P, P, P, P, I64, c_int, c_int, I64, P, I64, P, c_int, c_int,
                                  c_float, c_float, c_float, c_float, c_int, c_float, c_float, P, I64, c_int, P, I64, P],

@@ -70,6 +70,76 @@ __global__ __launch_bounds__(kBlock) void pool_rows_bwd_kernel(
   }
 }
 
+
+// ---- padded form (the row-sharded table's fixed-capacity exchange, recman_amd/dist.py) ----------------------
+// There the tags of a feature are T extra COLUMNS of the occurrence matrix: ids[b * ids_ld + t] (-1 = no tag),
+// and the row of tag (b, t) sits at position pos[b * pos_ld + t] of `rows` (the rows received from the owners).
+// Static shapes: micro-batches are row slices, the step can be captured in hipGraph segments.  Same sums in the
+// same order as the CSR kernels above (tags in list order; n = the number of tags present).
+__device__ __forceinline__ int padded_count(const int64_t *ids, int T) {
+  int n = 0;
+  for (int t = 0; t < T; ++t) n += ids[t] >= 0;
+  return n;
+}
+
+__global__ __launch_bounds__(kBlock) void pool_rows_padded_kernel(
+    const float *__restrict__ rows, int LD, int D, const int64_t *__restrict__ pos, int64_t pos_ld,
+    const int64_t *__restrict__ ids, int64_t ids_ld, const float *__restrict__ vals, int64_t vals_ld, int64_t B,
+    int T, float *__restrict__ out) {
+  const int lane = threadIdx.x & 15;
+  const int64_t b = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
+  if (b >= B) return;
+  const int64_t *id = ids + b * ids_ld, *ps = pos + b * pos_ld;
+  const int n = padded_count(id, T);
+  const float inv = n > 0 ? rsqrtf((float)n) : 0.f;
+  for (int k = lane; k < LD; k += 16) {
+    float acc = 0.f;
+    if (k < D + 2) {
+      for (int t = 0; t < T; ++t) {
+        if (id[t] < 0) continue;
+        const float x = rows[ps[t] * LD + k];
+        if (vals != nullptr) {
+          acc += k == D ? x : vals[b * vals_ld + t] * x;
+        } else if (k != D + 1 || id[t] >= 1) {
+          acc += x;
+        }
+      }
+      if (vals == nullptr && k <= D) acc *= inv;
+    }
+    out[b * LD + k] = acc;
+  }
+}
+
+// the tags' gradient rows [dE * we | g_bias * wb | g_lin * wl | 0 ..] written at their positions in the send
+// buffer of the backward exchange (the factors of pool_rows_bwd_kernel; no atomics: every tag has its own slot)
+__global__ __launch_bounds__(kBlock) void pack_pooled_grad_rows_kernel(
+    const float *__restrict__ d_rows, int64_t dr_stride, const float *__restrict__ g_bias,
+    const float *__restrict__ g_lin, int D, const int64_t *__restrict__ pos, int64_t pos_ld,
+    const int64_t *__restrict__ ids, int64_t ids_ld, const float *__restrict__ vals, int64_t vals_ld, int64_t B,
+    int T, int GW, float *__restrict__ out) {
+  const int lane = threadIdx.x & 15;
+  const int64_t b = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
+  if (b >= B) return;
+  const int64_t *id = ids + b * ids_ld, *ps = pos + b * pos_ld;
+  const int n = padded_count(id, T);
+  const float inv = n > 0 ? rsqrtf((float)n) : 0.f;
+  for (int t = 0; t < T; ++t) {
+    if (id[t] < 0 || ps[t] < 0) continue;
+    const float v = vals != nullptr ? vals[b * vals_ld + t] : 0.f;
+    const float we = vals != nullptr ? v : inv;
+    const float wb = vals != nullptr ? 1.f : inv;
+    const float wl = vals != nullptr ? v : (id[t] >= 1 ? 1.f : 0.f);
+    float *o = out + ps[t] * GW;
+    for (int k = lane; k < GW; k += 16) {
+      float x = 0.f;
+      if (k < D) x = d_rows[b * dr_stride + k] * we;
+      else if (k == D) x = g_bias != nullptr ? g_bias[b] * wb : 0.f;
+      else if (k == D + 1) x = g_lin != nullptr ? g_lin[b] * wl : 0.f;
+      o[k] = x;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int rm_pool_rows(const float *rows, int64_t row0, int LD, int D, const int64_t *offsets,
@@ -95,5 +165,34 @@ extern "C" int rm_pool_rows_bwd(const float *d_rows, int64_t dr_stride, const fl
                      0, (hipStream_t)stream, d_rows, dr_stride, g_bias, g_lin, D, offsets, ids, vals, B, row0,
                      d_table, d_bias, d_lin);
   RM_CHECK_LAUNCH("rm_pool_rows_bwd");
+  return RM_OK;
+}
+
+extern "C" int rm_pool_rows_padded(const float *rows, int LD, int D, const int64_t *pos, int64_t pos_ld,
+                                   const int64_t *ids, int64_t ids_ld, const float *vals, int64_t vals_ld,
+                                   int64_t B, int T, float *out, rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && D > 0 && LD >= D + 2 && T > 0 && pos_ld >= T && ids_ld >= T && (!vals || vals_ld >= T),
+             "rm_pool_rows_padded: bad sizes");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(rows && pos && ids && out, "rm_pool_rows_padded: NULL argument");
+  hipLaunchKernelGGL(pool_rows_padded_kernel, dim3((unsigned)((B * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, rows, LD, D, pos, pos_ld, ids, ids_ld, vals, vals_ld, B, T, out);
+  RM_CHECK_LAUNCH("rm_pool_rows_padded");
+  return RM_OK;
+}
+
+extern "C" int rm_pack_pooled_grad_rows(const float *d_rows, int64_t dr_stride, const float *g_bias,
+                                        const float *g_lin, int D, const int64_t *pos, int64_t pos_ld,
+                                        const int64_t *ids, int64_t ids_ld, const float *vals, int64_t vals_ld,
+                                        int64_t B, int T, int width, float *out, rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && D > 0 && dr_stride >= D && width >= D + 2 && T > 0 && pos_ld >= T && ids_ld >= T &&
+                 (!vals || vals_ld >= T),
+             "rm_pack_pooled_grad_rows: bad sizes");
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(d_rows && pos && ids && out, "rm_pack_pooled_grad_rows: NULL argument");
+  hipLaunchKernelGGL(pack_pooled_grad_rows_kernel, dim3((unsigned)((B * 16 + kBlock - 1) / kBlock)), dim3(kBlock),
+                     0, (hipStream_t)stream, d_rows, dr_stride, g_bias, g_lin, D, pos, pos_ld, ids, ids_ld, vals,
+                     vals_ld, B, T, width, out);
+  RM_CHECK_LAUNCH("rm_pack_pooled_grad_rows");
   return RM_OK;
 }

@@ -13,6 +13,9 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxW = 16;
+constexpr int kMaxB = kMaxW + 1;  // buckets: one per owner + one BEHIND them for the empty occurrences (idx < 0:
+                                  // the padding of a multi-valued feature's tag columns) - they get pos = -1 and
+                                  // take no slot
 
 __global__ __launch_bounds__(kBlock) void route_count_kernel(
     const int64_t *__restrict__ idx, const int64_t *__restrict__ field_off, int64_t n, int F, int W,
@@ -23,29 +26,29 @@ __global__ __launch_bounds__(kBlock) void route_count_kernel(
   // hipGraphs and a kernel node is the one node type every kernel of this library already is.
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nfill; i += (int64_t)gridDim.x * kBlock)
     fill[i] = -1;
-  __shared__ int sc[kMaxW];
-  if (threadIdx.x < kMaxW) sc[threadIdx.x] = 0;
+  __shared__ int sc[kMaxB];
+  if (threadIdx.x < kMaxB) sc[threadIdx.x] = 0;
   __syncthreads();
   const int64_t o0 = (int64_t)blockIdx.x * per_block;
   const int64_t o1 = o0 + per_block < n ? o0 + per_block : n;
-  int local[kMaxW];
+  int local[kMaxB];
 #pragma unroll
-  for (int w = 0; w < kMaxW; ++w) local[w] = 0;
+  for (int w = 0; w < kMaxB; ++w) local[w] = 0;
   for (int64_t o = o0 + threadIdx.x; o < o1; o += kBlock) {
-    const int64_t g = field_off[o % F] + idx[o];
-    const int w = (int)(g % W);
+    const int64_t id = idx[o];
+    const int w = id < 0 ? W : (int)((field_off[o % F] + id) % W);
 #pragma unroll
-    for (int q = 0; q < kMaxW; ++q) local[q] += (q == w);
+    for (int q = 0; q < kMaxB; ++q) local[q] += (q == w);
   }
 #pragma unroll
-  for (int w = 0; w < kMaxW; ++w) {
-    if (w < W) {
+  for (int w = 0; w < kMaxB; ++w) {
+    if (w <= W) {
       const int s = (int)rm_wave_sum((float)local[w]);  // exact: counts < 2^24
       if ((threadIdx.x & 63) == 0 && s) atomicAdd(&sc[w], s);
     }
   }
   __syncthreads();
-  if ((int)threadIdx.x < W) cnt[threadIdx.x * gridDim.x + blockIdx.x] = sc[threadIdx.x];
+  if ((int)threadIdx.x <= W) cnt[threadIdx.x * gridDim.x + blockIdx.x] = sc[threadIdx.x];
 }
 
 // exclusive scan over the w-major (w, block) grid; one block, sequential chunks
@@ -71,17 +74,7 @@ __global__ __launch_bounds__(1024) void route_scan_kernel(int *__restrict__ cnt,
     run += v;
   }
   __syncthreads();
-  if (tid < W) {
-    const int begin = cnt[tid * nblk];
-    const int end = tid + 1 < W ? cnt[(tid + 1) * nblk] : -1;
-    counts[tid] = end >= 0 ? end - begin : 0;
-  }
-}
-
-__global__ void route_last_count_kernel(const int *__restrict__ cnt, int nblk, int W, int64_t n,
-                                        int64_t *__restrict__ counts) {
-  // counts[W-1] = n - start of the last bucket
-  if (threadIdx.x == 0) counts[W - 1] = n - cnt[(W - 1) * nblk];
+  if (tid < W) counts[tid] = cnt[(tid + 1) * nblk] - cnt[tid * nblk];  // (bucket W, the empty ones, follows)
 }
 
 __global__ __launch_bounds__(kBlock) void route_place_kernel(
@@ -91,6 +84,7 @@ __global__ __launch_bounds__(kBlock) void route_place_kernel(
     int32_t *__restrict__ overflow) {
   __shared__ int run[kMaxW];          // running offset of each bucket within this block
   __shared__ int wcnt[kBlock / 64][kMaxW];
+  // (empty occurrences - idx < 0 - belong to no bucket here: w = -1, pos = -1)
   // cap > 0 (fixed-capacity layout): bucket w starts at w*cap instead of at the packed offset
   if ((int)threadIdx.x < W) {
     const int w = threadIdx.x;
@@ -107,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void route_place_kernel(
     const bool valid = o < o1;
     int64_t g = 0;
     int w = -1;
-    if (valid) {
+    if (valid && idx[o] >= 0) {
       g = field_off[o % F] + idx[o];
       w = (int)(g % W);
     }
@@ -119,7 +113,8 @@ __global__ __launch_bounds__(kBlock) void route_place_kernel(
     }
     (void)my_wave_total;
     __syncthreads();
-    if (valid) {
+    if (valid && w < 0) pos[o] = -1;
+    if (w >= 0) {
       int off = run[w];
       for (int v = 0; v < wave; ++v) off += wcnt[v][w];
       int64_t p = off + rank_in_wave;
@@ -150,6 +145,7 @@ __global__ __launch_bounds__(kBlock) void pack_grad_rows_kernel(
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const int64_t o = t / GW;
     const int sub = (int)(t - o * GW);
+    if (pos[o] < 0) continue;  // an empty occurrence: no slot
     float4 v;
     if (sub < GD) {
       v = d_rows[o * GD + sub];
@@ -166,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void pack_grad_rows_kernel(
 
 }  // namespace
 
-extern "C" int64_t rm_shard_route_workspace(int world) { return (int64_t)world * 1024 + 64; }
+extern "C" int64_t rm_shard_route_workspace(int world) { return (int64_t)(world + 1) * 1024 + 64; }
 
 static int shard_route_impl(const int64_t *idx, const int64_t *field_off, int64_t B, int F, int world,
                             int64_t cap, int64_t *pos, int64_t *send_ids, int64_t *counts,
@@ -180,9 +176,8 @@ static int shard_route_impl(const int64_t *idx, const int64_t *field_off, int64_
   const int64_t per_block = ((n + nblk - 1) / nblk + kBlock - 1) / kBlock * kBlock;
   hipLaunchKernelGGL(route_count_kernel, dim3(nblk), dim3(kBlock), 0, st, idx, field_off, n, F, world,
                      per_block, workspace, cap > 0 ? send_ids : nullptr, cap > 0 ? world * cap : 0);
-  hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, st, workspace, world * nblk, nblk, world,
+  hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, st, workspace, (world + 1) * nblk, nblk, world,
                      counts);
-  hipLaunchKernelGGL(route_last_count_kernel, dim3(1), dim3(64), 0, st, workspace, nblk, world, n, counts);
   hipLaunchKernelGGL(route_place_kernel, dim3(nblk), dim3(kBlock), 0, st, idx, field_off, n, F, world,
                      per_block, workspace, pos, send_ids, cap, overflow);
   RM_CHECK_LAUNCH("rm_shard_route");

@@ -31,6 +31,11 @@ Two exchange layouts:
                       redone with the dynamic layout.  Cyclic sharding keeps uniform / hashed
                       ids within a few sigma of n/W; heavily skewed ids need the dynamic path.
 
+Multi-valued / value features (their pooled row per example is built from several table rows): with exact split
+sizes the tags travel as an expanded occurrence list behind the plain fields' occurrences (_lookup_mv); with fixed
+capacity as T padded COLUMNS of the occurrence matrix (widen / _lookup_mv_fixed; id -1 = no tag, an empty occurrence
+takes no slot) - static shapes, so micro-batches and captured segments work.
+
 The routing/exchange logic below is device- and backend-agnostic torch code (it is the
 same on gloo/CPU, where tests/test_dist.py runs it with world_size 2); the row gather and
 routing are injected callables - HIP kernels in the product, plain torch indexing only in
@@ -94,20 +99,23 @@ def route_torch(idx, field_off, world, cap=0):
     cap > 0: fixed-capacity layout - bucket w owns slots [w*cap, (w+1)*cap), send_ids has
     world*cap entries (-1 = empty); returns a 4th value, the overflow flag tensor."""
     g = (idx + field_off).reshape(-1)
-    owner = g % world
+    valid = (idx >= 0).reshape(-1)  # (an EMPTY occurrence - the padding of a tag column - takes no slot: pos -1)
+    owner = torch.where(valid, g % world, torch.full_like(g, world))
     order = torch.argsort(owner, stable=True)
-    counts = torch.bincount(owner, minlength=world)
+    counts = torch.bincount(owner, minlength=world + 1)[:world]
     pos = torch.empty_like(order)
     pos[order] = torch.arange(g.numel(), device=g.device)
     if not cap:
-        return pos, counts, (g // world)[order]
+        nv = int(valid.sum()) if not bool(valid.all()) else g.numel()
+        return torch.where(valid, pos, torch.full_like(pos, -1)), counts, (g // world)[order][:nv]
     starts = torch.cumsum(counts, 0) - counts
-    rank_in = pos - starts[owner]
-    over = (rank_in >= cap).any().to(torch.int32).reshape(1)
-    ppos = owner * cap + torch.clamp(rank_in, max=cap - 1)
+    own = owner.clamp(max=world - 1)
+    rank_in = pos - starts[own]
+    over = ((rank_in >= cap) & valid).any().to(torch.int32).reshape(1)
+    ppos = own * cap + torch.clamp(rank_in, max=cap - 1)
     send = torch.full((world * cap,), -1, dtype=g.dtype, device=g.device)
-    send[ppos] = g // world
-    return ppos, counts, send, over
+    send[ppos[valid]] = (g // world)[valid]
+    return torch.where(valid, ppos, torch.full_like(ppos, -1)), counts, send, over
 
 
 class RowExchange:
@@ -395,11 +403,13 @@ class HipRouter:
 
 
 def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, capacity_factor=None,
-                        micro_batches=1):
+                        micro_batches=1, mv_capacity=None):
     """An engine whose embedding table is row-sharded over `world` ranks (bench.py --gpus N).
     capacity_factor: fixed-capacity exchange layout, see the module doc.  micro_batches > 1:
     the step is software-pipelined over that many micro-batches so that the row / gradient-row
-    exchanges overlap the dense compute."""
+    exchanges overlap the dense compute.  mv_capacity: name -> T, the most tags an example carries in a
+    multi-valued feature (the SAME numbers on every rank; value features: 1): with the fixed-capacity layout
+    the tags travel as T padded columns of the occurrence matrix (set_mv_capacity)."""
     from . import engine as eng
 
     base = eng.ENGINES[model]
@@ -409,12 +419,14 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
         step_fusable = False  # (DeepFM's one-kernel step reads a LOCAL table; here the rows arrive by exchange)
 
         def __init__(self):
-            if spec.scratch_names and (capacity_factor or int(micro_batches) > 1):
-                # their tags travel as an expanded occurrence list whose length changes from batch to batch:
-                # dynamic split sizes only (no fixed-capacity buckets, no captured segments, no micro-batches)
+            if spec.scratch_names and int(micro_batches) > 1 and not capacity_factor:
+                # with exact split sizes their tags travel as an expanded occurrence list whose length changes
+                # from batch to batch: no micro-batch pipeline there (the fixed-capacity layout has one)
                 raise NotImplementedError(
-                    f"row-sharded table: multi-valued / value features {sorted(spec.scratch_names)} need the "
-                    "dynamic exchange layout (capacity_factor=None) and micro_batches=1")
+                    f"row-sharded table: multi-valued / value features {sorted(spec.scratch_names)} with "
+                    "micro_batches > 1 need the fixed-capacity exchange layout (capacity_factor)")
+            self._mv_T = dict(mv_capacity or {})
+            self._wide = None
             for k in ("embedding_l2_reg", "linear_l2_reg"):
                 if hp.get(k, 0.0) and not hp.get("lazy_l2", True):
                     # the reference's DENSE l2 term on the table makes EVERY row's gradient non-zero
@@ -449,6 +461,73 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             # (no scratch block beside a local table: the pooled rows are built behind the received rows)
             self._arange = torch.arange(B, dtype=torch.int64, device=self.device)
             self._fix_cols = [f for f in range(self.F) if f not in self.mv_fields]
+            self._mv_layout()
+
+        # ---- multi-valued / value features under the fixed-capacity layout: tags as padded COLUMNS ----
+        def set_mv_capacity(self, caps):
+            """name -> T (most tags per example; the same on every rank).  Buffers are re-made on the next batch."""
+            caps = dict(caps)
+            if caps != self._mv_T:
+                self._mv_T, self._B, self._segs = caps, None, None
+
+        def _mv_fixed(self):
+            return bool(getattr(self, "mv_fields", None)) and bool(self.st.capacity_factor)
+
+        def exchange_columns(self):
+            """Columns of the occurrence matrix one example sends through the exchange: F, or F_wide (the plain
+            fields + the padded tag columns) for scratch-row features under the fixed-capacity layout."""
+            names = self.spec.sparse_names
+            scratch = [n for n in names if n in self.spec.scratch_names]
+            if not (scratch and self.st.capacity_factor):
+                return self.F
+            return (self.F - len(scratch)
+                    + sum(1 if n in self.spec.value_names else int(self._mv_T.get(n, 0)) for n in scratch))
+
+        def _mv_layout(self):
+            """The WIDE occurrence matrix [B, F_wide]: the plain fields' columns, then T_f columns per scratch-row
+            feature f holding its tags (-1 = none).  Every column has a field offset, so routing, the exchange,
+            the owner side and the optimizer treat a tag like any other occurrence; shapes are static - micro-
+            batches are row slices and the step can be captured."""
+            names = self.spec.sparse_names
+            self._mv_cols, c = [], len(self._fix_cols)
+            foff = [int(self.field_off[f]) for f in self._fix_cols]
+            for f in self.mv_fields:
+                T = 1 if names[f] in self.spec.value_names else int(self._mv_T.get(names[f], 0))
+                self._mv_cols.append((c, T))
+                foff += [int(self.field_off[f])] * T
+                c += T
+            self.F_wide = c
+            self._lin_mask_host = self.spec.lin_masks()[0]  # (host copy: no device read inside captured segments)
+            self._foff_wide = torch.tensor(foff, dtype=torch.int64, device=self.device)
+            self._fix_t = torch.tensor(self._fix_cols, dtype=torch.int64, device=self.device)
+
+        def widen(self, idx, mv, out=None):
+            """(idx [B, F], mv dict of CSR entries) -> (idx_wide [B, F_wide] int64, vals_wide [B, F_wide] float32):
+            tag t of example b of feature f in column c0_f + t.  torch ops over the CSR (its length varies): this
+            runs OUTSIDE the captured segments, which read the static wide buffers."""
+            B = idx.shape[0]
+            if out is None:
+                out = (torch.empty(B, self.F_wide, dtype=torch.int64, device=self.device),
+                       torch.zeros(B, self.F_wide, dtype=torch.float32, device=self.device))
+            iw, vw = out
+            nfix = len(self._fix_cols)
+            iw[:, :nfix] = idx.index_select(1, self._fix_t)
+            iw[:, nfix:] = -1
+            vw[:, nfix:] = 0
+            self._mv = mv
+            rows = torch.arange(B, dtype=torch.int64, device=self.device)
+            for (c0, T), f in zip(self._mv_cols, self.mv_fields):
+                offsets, ids, vals = self._mv_entry(f)
+                n = offsets[1:] - offsets[:-1]
+                if ids.numel() and int(n.max()) > T:
+                    raise ValueError(f"feature {self.spec.sparse_names[f]}: an example carries {int(n.max())} tags, "
+                                     f"mv_capacity allows {T}")
+                seg = torch.repeat_interleave(rows, n)
+                col = c0 + torch.arange(ids.numel(), dtype=torch.int64, device=self.device) - offsets[seg]
+                iw[seg, col] = ids
+                if vals is not None:
+                    vw[seg, col] = vals
+            return iw, vw
 
         def _alloc(self, B):
             first = self._B != B
@@ -456,8 +535,11 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             if first:
                 self._zoff = torch.zeros(self.F, dtype=torch.int64, device=self.device)
                 self._zoff1 = torch.zeros(1, dtype=torch.int64, device=self.device)
-                slots = world * self.st.capacity(B * self.F) or B * self.F
-                self.grad_rows = torch.empty(slots, self.D + PAD, dtype=torch.float32, device=self.device)
+                Fx = self.F_wide if self._mv_fixed() else self.F
+                slots = world * self.st.capacity(B * Fx) or B * Fx
+                extra = len(self.mv_fields) * B if self._mv_fixed() else 0  # (the pooled rows' own gradients stay home)
+                self.grad_rows = torch.zeros(slots + extra, self.D + PAD, dtype=torch.float32, device=self.device)
+                self._pos_model = torch.empty(B, self.F, dtype=torch.int64, device=self.device)
                 # one send buffer per micro-batch: its exchange is still in flight while the
                 # next micro-batch packs
                 self.grad_rows_m = [self.grad_rows] + [torch.empty_like(self.grad_rows)
@@ -480,7 +562,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             occurrence (b, f) is row pos[b, f] of self.rows."""
             B = idx.shape[0]
             if self.mv_fields:
-                pos = self._lookup_mv(idx)
+                pos = self._lookup_mv_fixed(idx) if (self._mv_fixed() and self._wide is not None) else self._lookup_mv(idx)
             elif self._slot is not None:      # captured segment: static buffers, exchange done by the caller
                 self.ex, self.rows = self._slot, self._slot.rows
                 pos = self.ex.pos.view(B, self.F)
@@ -533,7 +615,11 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 lists.append(ids + self.field_off[f])
             flat = torch.cat(lists).view(-1, 1)
             nmv = len(self.mv_fields)
-            self.rows, self.ex = self.st.lookup(flat, self._zoff1, extra_rows=nmv * B)
+            cf, self.st.capacity_factor = self.st.capacity_factor, None  # (a list of varying length: exact splits)
+            try:
+                self.rows, self.ex = self.st.lookup(flat, self._zoff1, extra_rows=nmv * B)
+            finally:
+                self.st.capacity_factor = cf
             slots = self.ex.slots
             pos = torch.empty(B, self.F, dtype=torch.int64, device=idx.device)
             nfix = B * len(fix)
@@ -551,6 +637,50 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                               self.rows[slots + j * B: slots + (j + 1) * B], vals=vals)
                 pos[:, f] = slots + j * B + self._arange
             return pos
+
+        def _lookup_mv_fixed(self, idx):
+            """The fixed-capacity form of _lookup_mv: the exchange carried the WIDE occurrence matrix (self._wide);
+            the pooled rows are built by rm_pool_rows_padded behind the received rows."""
+            from . import ops
+
+            B, D = idx.shape[0], self.D
+            nmv = len(self.mv_fields)
+            iw, vw = self._wide
+            if self._slot is not None:        # captured segment: static buffers, exchange done by the caller
+                self.ex, self.rows = self._slot, self._slot.rows
+            elif self._pending is not None:   # a micro-batch whose exchange was started earlier
+                self.ex, self._pending = self._pending, None
+                self.rows = self.st.lookup_finish(self.ex)
+            else:
+                self.rows, self.ex = self.st.lookup(iw, self._foff_wide, extra_rows=nmv * B)
+            slots = self.ex.slots
+            posw = self.ex.pos.view(B, self.F_wide)
+            pos = self._pos_model
+            pos.index_copy_(1, self._fix_t, posw[:, : len(self._fix_cols)])
+            names = self.spec.sparse_names
+            for j, ((c0, T), f) in enumerate(zip(self._mv_cols, self.mv_fields)):
+                ops.pool_rows_padded(self.rows, D, posw[:, c0: c0 + T], iw[:, c0: c0 + T],
+                                     self.rows[slots + j * B: slots + (j + 1) * B],
+                                     vals=vw[:, c0: c0 + T] if names[f] in self.spec.value_names else None)
+                pos[:, f] = self._arange + (slots + j * B)
+            self._posw = posw
+            return pos
+
+        def _pack_mv_fixed(self, grad_rows):
+            """Gradient rows of one (micro-)batch into the send buffer: the plain fields' (and, behind the slots,
+            the pooled rows' own) by rm_pack_grad_rows, every tag's by rm_pack_pooled_grad_rows."""
+            from . import ops
+
+            g_fm = self.dlogit if self._has_fm() else None
+            ops.pack_grad_rows(self.d_rows, g_fm, self.dlogit if self.use_linear else None,
+                               self._pos_model.reshape(-1), grad_rows, lin_field_mask=self.lin_field_mask)
+            iw, vw = self._wide
+            names = self.spec.sparse_names
+            for (c0, T), f in zip(self._mv_cols, self.mv_fields):
+                lin_on = self.use_linear and (self._lin_mask_host is None or float(self._lin_mask_host[f]) != 0.0)
+                ops.pack_pooled_grad_rows(self.d_rows[:, f, :], g_fm, self.dlogit if lin_on else None, self.D,
+                                          self._posw[:, c0: c0 + T], iw[:, c0: c0 + T], grad_rows,
+                                          vals=vw[:, c0: c0 + T] if names[f] in self.spec.value_names else None)
 
         def _pack_mv(self, grad_rows):
             """Gradient rows of the tags: each tag occurrence has its own slot; its row is the pooled row's
@@ -628,6 +758,8 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 return self._add_l2(self.loss)
             loss = base.fwd_bwd(self, idx, dense, y, masks, mv=mv) if mv is not None else base.fwd_bwd(self, idx, dense, y, masks)
             if self.mv_fields:
+                if self._mv_fixed() and self._wide is not None:
+                    self._pack_mv_fixed(grad_rows)
                 return loss
             ops.pack_grad_rows(self.d_rows, self.dlogit if self._has_fm() else None,
                                self.dlogit if self.use_linear else None,
@@ -641,6 +773,9 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             from . import ops
 
             loss = self._fwd_bwd_packed(idx, dense, y, masks, grad_rows, mv=mv)
+            if self.mv_fields and self._mv_fixed() and self._wide is not None:
+                out, work = self.ex.push(grad_rows[: self.ex.slots], async_op=True)
+                return loss, self.ex.recv_ids, out, work
             if self.mv_fields:
                 # (slots + pooled-row region; the pooled rows' own gradients land behind the slots and stay home)
                 grad_rows = torch.zeros(self.rows.shape[0], self.D + PAD, dtype=torch.float32, device=self.device)
@@ -665,8 +800,10 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             M = self.micro_batches
             B = idx.shape[0]
             if self._segs is not None and masks is None and weight is None:
-                return self._replay_segments(idx, dense, y)
+                return self._replay_segments(idx, dense, y, mv)
             self._alloc(B if M <= 1 else B // M)
+            # scratch-row features under the fixed-capacity layout: their tags as padded columns (widen)
+            wide = self.widen(idx, mv) if (self._mv_fixed() and mv is not None) else None
             # every gradient is the gradient of the GLOBAL batch mean: each rank's (micro-)batch
             # carries its share `weight` / M (1 / world for equal per-rank batches), the owners sum the
             # rows they receive, the dense all_reduce sums.  The l2 terms of the dense parameters are
@@ -677,9 +814,11 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             self.hp = dict(self._hp_full, **{k: self._hp_full.get(k, 0.0) * self.grad_scale for k in _DENSE_L2})
             if M <= 1:
                 try:
+                    self._wide = wide
                     loss, ids, rows, work = self._one(idx, dense, y, masks, self.grad_rows, mv=mv)
                 finally:
                     self.hp = self._hp_full
+                    self._wide = None
                 if work is not None:
                     work.wait()
                 self.shard_grad_ids, self.shard_grad_rows = ids, rows
@@ -689,17 +828,30 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 raise ValueError("micro-batching needs a batch divisible by micro_batches and no dropout masks")
             b = B // M
             parts = [(idx[c * b: (c + 1) * b], dense[c * b: (c + 1) * b], y[c * b: (c + 1) * b]) for c in range(M)]
-            started = self.st.lookup_start(parts[0][0], self.field_off)
+            if self.mv_fields and wide is None:
+                raise ValueError("micro-batching with multi-valued / value features needs their mv= entries")
+            wides = [None] * M if wide is None else [(wide[0][c * b: (c + 1) * b], wide[1][c * b: (c + 1) * b])
+                                                     for c in range(M)]
+
+            def start(c):
+                if wides[c] is None:
+                    return self.st.lookup_start(parts[c][0], self.field_off)
+                return self.st.lookup_start(wides[c][0], self._foff_wide, extra_rows=len(self.mv_fields) * b)
+
+            started = start(0)
             outs, total = [], None
             for c in range(M):
                 self._pending = started
                 # start the NEXT micro-batch's exchange before this one's compute is enqueued
-                started = self.st.lookup_start(parts[c + 1][0], self.field_off) if c + 1 < M else None
+                started = start(c + 1) if c + 1 < M else None
                 try:
+                    self._wide = wides[c]
                     loss, ids, rows, work = self._one(*parts[c], None, self.grad_rows_m[c])
                 except BaseException:
                     self.hp = self._hp_full
                     raise
+                finally:
+                    self._wide = None
                 outs.append((ids, rows, work))
                 if c == 0:
                     self._acc.copy_(self._flat_grads)
@@ -731,7 +883,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 self.hp = keep
 
         # ---- hipGraph segments (fixed-capacity layout): the compute BETWEEN the collectives ----
-        def capture_segments(self, idx, dense, y):
+        def capture_segments(self, idx, dense, y, mv=None):
             """Fixed-capacity layout only.  Captures the three compute stretches of every
             micro-batch - route | owner-side gather | embed..loss..backward..pack - as hipGraphs
             over static buffers; fwd_bwd then replays them with the RCCL calls issued eagerly in
@@ -752,7 +904,13 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             b = B // M
             self._segs = None
             self._alloc(b)
-            dev, W, F = self.device, self.D + PAD, self.F
+            mvf = self._mv_fixed()
+            if self.mv_fields and mv is None:
+                raise ValueError("capture_segments: multi-valued / value features need their mv= entries")
+            dev, W = self.device, self.D + PAD
+            F = self.F_wide if mvf else self.F    # columns of the occurrence matrix the exchange carries
+            extra = len(self.mv_fields) * b if mvf else 0  # pooled rows behind the received ones
+            self._seg_wide = self.widen(idx, mv) if mvf else None
             cap = self.st.capacity(b * F)
             slots = world * cap
             router = self.st.route_fn
@@ -766,29 +924,36 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             for c in range(M):
                 s = SimpleNamespace(idx=idx[c * b: (c + 1) * b], dense=dense[c * b: (c + 1) * b],
                                     y=y[c * b: (c + 1) * b])
+                if mvf:
+                    s.iw, s.vw = (t[c * b: (c + 1) * b] for t in self._seg_wide)
+                s.slots = slots
                 s.pos = torch.empty(b * F, dtype=torch.int64, device=dev)
                 s.send_ids = torch.empty(slots, dtype=torch.int64, device=dev)
                 s.counts = torch.empty(world, dtype=torch.int64, device=dev)
                 s.recv_ids = torch.empty_like(s.send_ids) if coll else s.send_ids
-                s.served = torch.empty(slots, W, dtype=torch.float32, device=dev)
-                s.rows = torch.empty_like(s.served) if coll else s.served
-                s.grad_rows = torch.zeros(slots, W, dtype=torch.float32, device=dev)
-                s.grad_out = torch.empty_like(s.grad_rows) if coll else s.grad_rows
+                served = torch.empty(slots + extra, W, dtype=torch.float32, device=dev)
+                s.served = served[:slots]
+                s.rows = torch.empty_like(served) if coll else served
+                s.rows_recv = s.rows[:slots]
+                s.grad_rows = torch.zeros(slots + extra, W, dtype=torch.float32, device=dev)
+                s.grad_send = s.grad_rows[:slots]
+                s.grad_out = torch.empty_like(s.grad_send) if coll else s.grad_send
                 segs.append(s)
 
             def route(s, c):
-                ops.shard_route_padded(s.idx, self.field_off, world, cap, s.pos, s.send_ids, s.counts,
-                                       router.overflow, router.ws)
+                ops.shard_route_padded(s.iw if mvf else s.idx, self._foff_wide if mvf else self.field_off, world, cap,
+                                       s.pos, s.send_ids, s.counts, router.overflow, router.ws)
 
             def gather(s, c):
                 ops.gather_rows(self.st.shard[:, : self.st.W], s.recv_ids, s.served)
 
             def compute(s, c):
                 self._slot = s
+                self._wide = (s.iw, s.vw) if mvf else None
                 try:
                     loss = self._fwd_bwd_packed(s.idx, s.dense, s.y, None, s.grad_rows, pos=s.pos)
                 finally:
-                    self._slot = None
+                    self._slot = self._wide = None
                 if c == 0:
                     self._seg_loss.copy_(loss)
                 else:
@@ -805,6 +970,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             # eager rehearsal first (lazy workspaces, RCCL buffers), collectives included so the
             # static buffers hold real rows; then the captures, which only record
             self._segs, self._seg_coll, self._seg_in = segs, coll, (idx, dense, y)
+            self._mv = mv
             self._seg_bodies = (route, gather, compute)
             self._run_segments(eager=True)
             torch.cuda.synchronize()
@@ -851,7 +1017,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                 if coll:
                     _all_to_all(s.recv_ids, s.send_ids, group=group)
                 run(s, c, 1)
-                return _all_to_all(s.rows, s.served, group=group, async_op=True) if coll else None
+                return _all_to_all(s.rows_recv, s.served, group=group, async_op=True) if coll else None
 
             rows_work = start(0)
             works = []
@@ -862,7 +1028,7 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
                     rows_work.wait()
                 run(s, c, 2)
                 if coll:
-                    works.append(_all_to_all(s.grad_out, s.grad_rows, group=group, async_op=True))
+                    works.append(_all_to_all(s.grad_out, s.grad_send, group=group, async_op=True))
                 rows_work = nxt
             for w in works:
                 w.wait()
@@ -874,12 +1040,16 @@ def make_sharded_engine(model, spec, D, hp, device, rank, world, group=None, cap
             allreduce_dense(self.grads, world, group, self._flat_grads, average=False)
             return self._seg_loss + self._l2_once()
 
-        def _replay_segments(self, idx, dense, y):
+        def _replay_segments(self, idx, dense, y, mv=None):
             for src, dst in zip((idx, dense, y), self._seg_in):
                 if src.shape != dst.shape:
                     raise ValueError("captured segments: batch shape differs from the captured one")
                 if src.data_ptr() != dst.data_ptr():
                     dst.copy_(src)
+            if self._seg_wide is not None:
+                if mv is None:
+                    raise ValueError("captured segments: multi-valued / value features need their mv= entries")
+                self.widen(idx, mv, out=self._seg_wide)  # (the tags of THIS batch into the static wide buffers)
             return self._run_segments()
 
         def roofline_probes(self, idx, dense, y):

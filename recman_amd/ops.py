@@ -593,6 +593,42 @@ def pool_rows_bwd(d_rows_f, g_bias, g_lin, D, offsets, ids, row0, d_table, d_bia
               _stream())
 
 
+def _cols(t, name, dtype, B, T):
+    """(data pointer, row stride) of a [B, T] view with unit-stride columns (a column block of a wider matrix)."""
+    if t is None:
+        return None, 0
+    if not t.is_cuda or t.dtype != dtype or tuple(t.shape) != (B, T) or (T > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name}: expected a cuda {dtype} [B={B}, T={T}] view with unit-stride columns, got "
+                         f"{t.dtype} {tuple(t.shape)} strides {t.stride()} on {t.device}")
+    return t.data_ptr(), t.stride(0)
+
+
+def pool_rows_padded(rows, D, pos, ids, out, vals=None):
+    """rm_pool_rows_padded: pooled rows out [B, LD] from the tag rows rows[pos[b, t]] (ids[b, t] < 0: no tag);
+    pos / ids / vals are [B, T] views (column blocks of the occurrence matrix)."""
+    B, T = ids.shape
+    LD = rows.shape[1]
+    pp, pl = _cols(pos, "pos", I64, B, T)
+    ip, il = _cols(ids, "ids", I64, B, T)
+    vp, vl = _cols(vals, "vals", F32, B, T)
+    _lib.call("rm_pool_rows_padded", _chk(rows, "rows", F32), LD, D, pp, pl, ip, il, vp, vl, B, T,
+              _chk(out, "out", F32, (B, LD)), _stream())
+
+
+def pack_pooled_grad_rows(d_rows_f, g_bias, g_lin, D, pos, ids, out, vals=None):
+    """rm_pack_pooled_grad_rows: the tags' gradient rows written at out[pos[b, t]] (out [slots, width]);
+    d_rows_f: [B, D] view (row stride may be larger) of the pooled rows' gradient."""
+    B, T = ids.shape
+    if d_rows_f.stride(1) != 1:
+        raise ValueError("pack_pooled_grad_rows: d_rows_f must be unit-stride along D")
+    pp, pl = _cols(pos, "pos", I64, B, T)
+    ip, il = _cols(ids, "ids", I64, B, T)
+    vp, vl = _cols(vals, "vals", F32, B, T)
+    _lib.call("rm_pack_pooled_grad_rows", d_rows_f.data_ptr(), d_rows_f.stride(0),
+              _chk(g_bias, "g_bias", F32, (B,), allow_none=True), _chk(g_lin, "g_lin", F32, (B,), allow_none=True),
+              D, pp, pl, ip, il, vp, vl, B, T, out.shape[1], _chk(out, "out", F32), _stream())
+
+
 def bias_act_(x, bias, act):
     B, N = x.shape
     _lib.call("rm_bias_act", _chk(x, "x", F32), _chk(bias, "bias", F32, (N,), allow_none=True), B, N,

@@ -178,12 +178,29 @@ class DeepModel(BaseEstimator, TransformerMixin):
         ragged = lo != hi or lo % M != 0
         st = e.st
         fixed = st.capacity_factor
+        if fixed and mv and e.spec.multi_names and not getattr(self, "_mv_caps_global", False):
+            # the padded tag columns of the fixed-capacity layout need ONE width per multi-valued feature on every
+            # rank: the most tags any example of this batch carries on any rank (fit() knows the whole dataset and
+            # sets it once; here - fit_on_batch - it can only grow)
+            names = list(e.spec.multi_names)
+            t = torch.tensor([int((mv[n][0][1:] - mv[n][0][:-1]).max()) if mv[n][1].numel() else 0 for n in names],
+                             dtype=torch.int64)
+            if self._shard[1] > 1:
+                import torch.distributed as dist
+
+                if dist.get_backend() == "nccl":
+                    t = t.to(e.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            caps = dict(e._mv_T)
+            for n, v in zip(names, t.tolist()):
+                caps[n] = max(int(caps.get(n, 0)), int(v), 1)
+            e.set_mv_capacity(caps)
         redone = False
         try:
             if ragged or masks is not None:  # (dropout masks: no micro-batch pipeline, dist.py)
                 e.micro_batches = 1
             if fixed:
-                st.cap_occurrences = hi * e.F  # the same bucket size on every rank
+                st.cap_occurrences = hi * e.exchange_columns()  # the same bucket size on every rank
             loss = e.fwd_bwd(idx, dense, yt, masks=masks, weight=self._w, mv=mv)
             if fixed and self._any_rank(e.overflowed()):
                 # skewed ids: occurrences were clamped onto the last slot of a bucket - this step's rows and
@@ -376,6 +393,11 @@ class DeepModel(BaseEstimator, TransformerMixin):
         pinned = self._use_feeder(len(y_train))
         idx, dense, yt = self._encode(X_train, y_train, on_host=pinned)
         mv_host = self._mv_host
+        if self._shard is not None and mv_host and getattr(self._engine.st, "capacity_factor", None):
+            # every rank encodes the whole frame: the widest tag list of the dataset, the same number everywhere
+            self._engine.set_mv_capacity({n: max(1, int(np.diff(c.offsets).max()) if len(c.ids) else 1)
+                                          for n, c in mv_host.items() if n in self._engine.spec.multi_names})
+            self._mv_caps_global = True
         n = len(y_train)
         if pinned:
             return self._fit_pinned(idx, dense, yt, mv_host, y_train, enc_valid, y_valid,

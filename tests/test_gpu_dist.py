@@ -303,7 +303,7 @@ def _mv_slice(mvt, vt, sl, names):
             names[1]: (torch.arange(b + 1).cuda(), vids[sl].cuda(), vals[sl].cuda())}
 
 
-def _mv_worker(rank, world, port, out_path):
+def _mv_worker(rank, world, port, out_path, fixed=False, micro=1, segments=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.pop("RECMAN_FORCE_COLLECTIVES", None)
@@ -320,7 +320,8 @@ def _mv_worker(rank, world, port, out_path):
         names = (spec.sparse_names[1], spec.sparse_names[3])
         espec = eng.FeatureSpec(spec.sparse_names, spec.feat_sizes, spec.dense_names, [names[0]], [names[1]])
         dev = torch.device("cuda", 0)
-        s = rd.make_sharded_engine("deepfm", espec, 16, hp, dev, rank, world)
+        s = rd.make_sharded_engine("deepfm", espec, 16, hp, dev, rank, world, capacity_factor=2.0 if fixed else None,
+                                   micro_batches=micro, mv_capacity={names[0]: 3})
         s.load_params({k: v for k, v in p.items() if k in s.params})
         full = torch.cat([p[f"{n}_feat_embed"] for n in spec.sparse_names])
         bias = torch.cat([p[f"{n}_feat_bias"].reshape(-1) for n in spec.sparse_names])
@@ -329,10 +330,14 @@ def _mv_worker(rank, world, port, out_path):
         sl = slice(rank * Bl, (rank + 1) * Bl)
         il, dl, yl = idx[sl].cuda(), dense[sl].cuda(), y[sl].cuda()
         mv = _mv_slice(mvt, vt, sl, names)
+        if segments:
+            s.capture_segments(il.clone(), dl.clone(), yl.clone(), mv=mv)
         losses, logits = [], None
         for _ in range(3):
             losses.append(float(s.fwd_bwd(il, dl, yl, mv=mv)))
+            assert not (fixed and s.overflowed())
             if logits is None:
+                # (micro-batches: s.logit holds the LAST micro-batch's examples)
                 logits = s.logit.clone().cpu()
             opt.step()
         torch.save({"rows": s.st.shard[:, : 16 + 2].cpu(), "losses": losses, "logit0": logits,
@@ -342,18 +347,24 @@ def _mv_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_two_ranks_multi_valued_and_value_features_train_like_single_gpu(hip_lib, tmp_path):
+@pytest.mark.parametrize("fixed,micro,segments", [(False, 1, False), (True, 1, False), (True, 2, False),
+                                                  (True, 2, True)],
+                         ids=["exact", "fixed", "fixed-micro2", "fixed-micro2-segments"])
+def test_two_ranks_multi_valued_and_value_features_train_like_single_gpu(hip_lib, tmp_path, fixed, micro, segments):
     """Scratch-row features on the row-sharded table: the tags of a MultiValCsvFeat field and the ids of a
-    SparseValueFeat field travel as an expanded occurrence list behind the plain fields' occurrences, the
-    pooled rows are built from the received tag rows, the tags' gradient rows go back to their owners - three
-    training steps on two ranks equal three steps of the single-GPU engine (which pools from its local table
-    and steps the tag rows through optim.SparseTableOptimizer) to 1e-6."""
+    SparseValueFeat field travel through the exchange - as an expanded occurrence list behind the plain fields'
+    occurrences (exact split sizes), or as padded tag COLUMNS of the occurrence matrix (fixed-capacity layout:
+    static shapes, so the micro-batch pipeline and the hipGraph segments work; rm_pool_rows_padded /
+    rm_pack_pooled_grad_rows) - the pooled rows are built from the received tag rows, the tags' gradient rows go
+    back to their owners: three training steps on two ranks equal three steps of the single-GPU engine (which
+    pools from its local table and steps the tag rows through optim.SparseTableOptimizer) to 1e-6."""
     from recman_amd import engine as eng
     from recman_amd.optim import FusedDenseOptimizer, SparseTableOptimizer
 
     world, Bl = 2, 24
     out = str(tmp_path / "mv")
-    mp.spawn(_mv_worker, args=(world, 29871, out), nprocs=world, join=True)
+    port = 29871 + [(False, 1, False), (True, 1, False), (True, 2, False), (True, 2, True)].index((fixed, micro, segments))
+    mp.spawn(_mv_worker, args=(world, port, out, fixed, micro, segments), nprocs=world, join=True)
     res = [torch.load(f"{out}.{r}", weights_only=True) for r in range(world)]
     spec, p, idx, dense, y, hp, mvt, vt = _mv_case(world, Bl)
     names = (spec.sparse_names[1], spec.sparse_names[3])
@@ -371,7 +382,12 @@ def test_two_ranks_multi_valued_and_value_features_train_like_single_gpu(hip_lib
         sopt.step(ib)
         dopt.step()
     got0 = torch.cat([res[r]["logit0"] for r in range(world)])
-    assert float((got0 - logit0).abs().max()) <= 1e-6, "first-step logits"
+    if micro == 1:
+        assert float((got0 - logit0).abs().max()) <= 1e-6, "first-step logits"
+    else:  # each rank's logit buffer holds its LAST micro-batch
+        b = Bl // micro
+        want0 = torch.cat([logit0[r * Bl + Bl - b: (r + 1) * Bl] for r in range(world)])
+        assert float((got0 - want0).abs().max()) <= 1e-6, "first-step logits (last micro-batch of each rank)"
     for r in range(world):
         want = e.rows[r::world, : 16 + 2].cpu()
         err = float((res[r]["rows"] - want).abs().max())
@@ -401,12 +417,13 @@ def _fit_worker(rank, world, port, model, out_path):
         from tests.test_gpu_models import ml_features, ml_frame
 
         df = ml_frame().iloc[:1000].copy()   # 1000 rows, batch 96: a ragged last batch (40 rows -> 20 + 20)
-        if model == "deepfm_genres":         # + the multi-valued `genres` feature (its tags travel through the exchange)
+        genres = model in ("deepfm_genres", "deepfm_genres_fixed")
+        if genres:                           # + the multi-valued `genres` feature (its tags travel through the exchange)
             from tests.test_gpu_models import GOLD
 
             df["genres"] = GOLD["raw_genres"][:1000].astype(object)
         fd = ml_features(df)
-        if model == "deepfm_genres":
+        if genres:
             fd["genres"] = th.MultiValCsvFeat(name="genres", tags=tuple(GOLD["genre_tags"].tolist()))
         hp = {"embedding_size": 16, "deep_dropout": (1, 1, 1), "cin_cross_layer_units": [16, 16],
               "cin_dropout": [1, 1, 1], "learning_rate": 0.01, "embedding_l2_reg": 0.0, "linear_l2_reg": 0.0,
@@ -424,10 +441,16 @@ def _fit_worker(rank, world, port, model, out_path):
             assert hp["embedding_l2_reg"] == 1e-5 and hp["linear_l2_reg"] == 1e-5
         if model in ("xdeepfm", "xdeepfm_defaults", "xdeepfm_ragged_fixed"):
             m = th.xDeepFM(fd, hp, epoch=2, batch_size=96)
-        elif model == "deepfm_genres":
+        elif genres:
+            # "deepfm_genres_fixed": fixed-capacity buckets + the micro-batch pipeline - the tags as padded columns
+            # of the occurrence matrix, their width = the widest genre list of the frame (set by fit())
+            extra = dict(exchange_capacity_factor=2.0, micro_batches=2) if model == "deepfm_genres_fixed" else {}
             m = th.DeepFM(fd, embedding_size=16, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_dropout=(1, 1, 1),
                           learning_rate=0.01, epoch=2, batch_size=96)
+            m.hparams.update(extra)  # (DeepFM's signature is the reference's: the exchange knobs are hparams)
             assert m._build().spec.multi_names == ["genres"]
+            if extra:
+                assert m._engine.st.capacity_factor == 2.0 and m._engine.micro_batches == 2
         else:
             m = th.DeepFM(fd, embedding_size=16, embedding_l2_reg=0.0, linear_l2_reg=0.0, deep_dropout=(1, 1, 1),
                           learning_rate=0.01, epoch=2, batch_size=96)
@@ -435,6 +458,8 @@ def _fit_worker(rank, world, port, model, out_path):
         before = log_loss(yv, m.predict(df).astype(np.float64))
         assert m._shard == (rank, world) and m._engine.st.shard.shape[0] < m._engine.spec.rows
         m.fit(df, yv, random_seed_for_mini_batch=True)   # the shuffle seed is rank 0's on every rank
+        if model == "deepfm_genres_fixed":
+            assert m._engine._mv_T.get("genres", 0) >= 2 and m._engine.F_wide > m._engine.F  # (tags as columns)
         pred = m.predict(df)
         after = log_loss(yv, pred.astype(np.float64))
         path = f"{out_path}.ckpt"
@@ -453,7 +478,8 @@ def _fit_worker(rank, world, port, model, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model", ["deepfm", "xdeepfm", "deepfm_genres", "xdeepfm_defaults", "xdeepfm_ragged_fixed"])
+@pytest.mark.parametrize("model", ["deepfm", "xdeepfm", "deepfm_genres", "xdeepfm_defaults", "xdeepfm_ragged_fixed",
+                                   "deepfm_genres_fixed"])
 def test_model_fit_predict_save_restore_with_a_row_sharded_table_on_two_ranks(hip_lib, tmp_path, model):
     """The model classes under a two-rank torch.distributed job: the table row-sharded, fit() data parallel
     (ragged last batch, micro-batches, dense l2; "deepfm_genres": with ml-100k's multi-valued `genres`, whose tags
@@ -461,7 +487,8 @@ def test_model_fit_predict_save_restore_with_a_row_sharded_table_on_two_ranks(hi
     went down, a restored model predicts the same."""
     world = 2
     out = str(tmp_path / "f")
-    port = 29990 + ["deepfm", "xdeepfm", "deepfm_genres", "xdeepfm_defaults", "xdeepfm_ragged_fixed"].index(model)
+    port = 29990 + ["deepfm", "xdeepfm", "deepfm_genres", "xdeepfm_defaults", "xdeepfm_ragged_fixed",
+                    "deepfm_genres_fixed"].index(model)
     mp.spawn(_fit_worker, args=(world, port, model, out), nprocs=world, join=True)
     res = [torch.load(f"{out}.{r}", weights_only=True) for r in range(world)]
     assert res[0]["after"] < res[0]["before"] - 0.01
@@ -471,3 +498,72 @@ def test_model_fit_predict_save_restore_with_a_row_sharded_table_on_two_ranks(hi
     for r in range(world):
         assert float((res[r]["pred"] - res[r]["pred_restored"]).abs().max()) < 1e-6
     assert os.path.exists(f"{out}.ckpt.shard0of2.pt") and os.path.exists(f"{out}.ckpt.shard1of2.pt")
+
+
+def test_padded_pooling_kernels_equal_the_csr_ones(hip_lib):
+    """rm_pool_rows_padded / rm_pack_pooled_grad_rows (tags as padded columns, rows addressed through positions)
+    against rm_pool_rows / a torch restatement of the tags' gradient rows; the router gives an empty occurrence
+    (id -1) no slot."""
+    from recman_amd import ops
+
+    B, T, D, W, R = 37, 4, 16, 20, 50
+    g = torch.Generator().manual_seed(4)
+    n = torch.randint(0, T + 1, (B,), generator=g)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), n.cumsum(0)]).cuda()
+    ids = torch.randint(0, R, (int(n.sum()),), generator=g).cuda()
+    rows = torch.randn(R, W, generator=g).cuda()
+    # padded columns inside a wider occurrence matrix, rows permuted (as after an exchange)
+    wide = torch.full((B, 2 + T), -1, dtype=torch.int64).cuda()
+    wide[:, :2] = 7
+    seg = torch.repeat_interleave(torch.arange(B).cuda(), n.cuda())
+    col = 2 + torch.arange(ids.numel()).cuda() - offsets[seg]
+    wide[seg, col] = ids
+    perm = torch.randperm(R, generator=g).cuda()
+    recv = torch.empty_like(rows)
+    recv[perm] = rows                       # row r of the table sits at position perm[r]
+    pos = torch.where(wide >= 0, perm[wide.clamp(min=0)], torch.full_like(wide, -1))
+    for vals in (None, torch.randn(ids.numel(), generator=g).cuda()):
+        want = torch.empty(B, W).cuda()
+        ops.pool_rows(rows, 0, D, offsets, ids, want, vals=vals)
+        vw = None
+        if vals is not None:
+            vw = torch.zeros(B, 2 + T).cuda()
+            vw[seg, col] = vals
+        got = torch.empty(B, W).cuda()
+        ops.pool_rows_padded(recv, D, pos[:, 2:], wide[:, 2:], got, vals=None if vw is None else vw[:, 2:])
+        assert torch.equal(got, want)
+        # gradient rows of the tags
+        d_rows = torch.randn(B, 3, D, generator=g).cuda()
+        gb, gl = torch.randn(B, generator=g).cuda(), torch.randn(B, generator=g).cuda()
+        out = torch.zeros(R, W).cuda()
+        ops.pack_pooled_grad_rows(d_rows[:, 1, :], gb, gl, D, pos[:, 2:], wide[:, 2:], out,
+                                  vals=None if vw is None else vw[:, 2:])
+        inv = n.clamp(min=1).float().rsqrt().cuda()[seg]
+        we = vals if vals is not None else inv
+        wb = torch.ones_like(inv) if vals is not None else inv
+        wl = vals if vals is not None else (ids >= 1).float()
+        ref = torch.zeros(R, W).cuda()
+        p = perm[ids]
+        # (a table row may occur twice among the tags: the LAST writer wins in both)
+        for k in range(ids.numel()):
+            ref[p[k], :D] = d_rows[seg[k], 1, :] * we[k]
+            ref[p[k], D] = gb[seg[k]] * wb[k]
+            ref[p[k], D + 1] = gl[seg[k]] * wl[k]
+        uniq = torch.ones(R, dtype=torch.bool).cuda()
+        cnt = torch.bincount(p, minlength=R)
+        uniq[cnt > 1] = False                # rows written twice: either writer may be last on the GPU
+        assert torch.allclose(out[uniq], ref[uniq], rtol=0, atol=1e-6)
+    # the router: empty occurrences take no slot
+    foff = torch.zeros(2 + T, dtype=torch.int64).cuda()
+    world, cap = 2, 128
+    p2 = torch.empty(B * (2 + T), dtype=torch.int64).cuda()
+    send = torch.empty(world * cap, dtype=torch.int64).cuda()
+    counts = torch.empty(world, dtype=torch.int64).cuda()
+    over = torch.zeros(1, dtype=torch.int32).cuda()
+    ws = torch.empty(ops._lib.lib().rm_shard_route_workspace(world), dtype=torch.int32).cuda()
+    ops.shard_route_padded(wide, foff, world, cap, p2, send, counts, over, ws)
+    from recman_amd.dist import route_torch
+
+    pr, cr, sr, _ = route_torch(wide, foff, world, cap)
+    assert torch.equal(p2, pr) and torch.equal(counts, cr) and torch.equal(send, sr) and int(over) == 0
+    assert int((p2 < 0).sum()) == int((wide < 0).sum()) and int(counts.sum()) == int((wide >= 0).sum())
