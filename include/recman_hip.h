@@ -397,6 +397,22 @@ int rm_dense_fwd(const float *A1, int64_t lda1, int K1, const float *A2, int64_t
                  int act, const float *aux1, int64_t ld_aux1, const float *aux2, int64_t ld_aux2,
                  int64_t M, float *C, int64_t ldc, float *C2, int64_t ldc2, float *filter_ws,
                  rm_stream_t stream);
+/* rm_dense_fwd6: rm_dense_fwd's GEMM with every fp32 operand SPLIT into three bf16 pieces (x = h + m + l, 8 + 8 + 8
+ * significant bits) and six of the nine piece products formed on the bf16 matrix pipe, fp32 accumulate
+ * (csrc/gemm6.hip): the kept products are exact in fp32, the dropped ones are below 3 * 2^-24 of |x y| - the
+ * result carries fp32-level error (measured against float64 it is SMALLER than the f32-MFMA kernel's, whose
+ * k-chunked sums are longer chains).  gfx950 has no tf32; its f32 MFMA runs at 1/16 of the bf16 rate.
+ * Arguments as rm_dense_fwd; epilogues RM_DENSE_BIAS_ACT / MUL_ACTGRAD / ADD; A1 rows 16-byte aligned (lda1 % 4 ==
+ * 0); K1 % 32 + K2 <= 32 (the ragged end of [A1 | A2] is copied into one padded slab), otherwise
+ * RM_EUNSUPPORTED.  dot_w [N] + dot_out [M] (or both NULL; dot_w0 [1] or NULL): also dot_out[b] = C[b, :] . dot_w
+ * + dot_w0 from the epilogue's registers - the [*, 1] output projection of the DNN (rm_rowdot) without another
+ * pass over C; fixed summation order.  workspace: rm_dense6_workspace(K, N, M) floats, 16-byte aligned. */
+int64_t rm_dense6_workspace(int K, int N, int64_t M);
+int rm_dense_fwd6(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2, const float *W,
+                  int64_t ldw, int w_transposed, int N, const float *bias, int epilogue, int act,
+                  const float *aux1, int64_t ld_aux1, int64_t M, float *C, int64_t ldc, const float *dot_w,
+                  const float *dot_w0, float *dot_out, float *workspace, rm_stream_t stream);
+
 int64_t rm_dense_wgrad_workspace(int K, int N, int64_t M);
 int rm_dense_wgrad(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2,
                    const float *G, int64_t ldg, int N, int64_t M, float *dW, int64_t lddw,

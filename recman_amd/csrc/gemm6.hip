@@ -1,0 +1,434 @@
+// Wide dense layers, "NN" GEMM C[M,N] = epilogue([A1 | A2][M,K] . op(W)), with fp32 operands SPLIT into three
+// bf16 pieces each and the products formed on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
+//
+//   x = h + m + l,  h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)   (8 + 8 + 8 = the 24 significant bits)
+//   x y ~= hx hy + hx my + mx hy + mx my + hx ly + lx hy               (dropped: m l, l m, l l <= 3 * 2^-24 |x y|)
+//
+// Every kept product of two bf16 values is EXACT in fp32 (16 significant bits), the sum runs in fp32 as on the
+// f32 MFMA: the result carries fp32-level rounding error (tests/test_gpu_dense.py holds it to the same bound
+// against float64 as the f32-MFMA kernel of gemm.hip; it is not bit-identical to it - neither kernel is to the
+// CPU oracle, whose sums run in another order).  Why: gfx950 has no tf32 / xf32; the f32 MFMA runs at 1/16 of
+// the bf16 rate, so six bf16 MFMAs per k-step are 2.7x the f32 pipe's speed-of-light.  gemm.hip's NN kernel
+// sits at 0.74-0.80 of THAT pipe (DCN configs[3]: 4 launches x 355-382 us of a 2.85 ms step).
+//
+// Replaces tf.matmul + bias + activation of DNN.__call__ (recman/tf/core/layers.py:594-602) and the
+// data-gradient GEMM of its backward, like rm_dense_fwd's f32 path.
+//
+// Block = 8 waves = 256 batch rows x ONE column group of NT <= 13 16-column tiles; wave w owns rows
+// [32 w, 32 w + 32) (two 16-row MFMA tiles) and all NT column tiles: 2 x NT x 4 accumulator registers.
+//   A   never touches LDS: a lane's operand fragment is 8 consecutive k of one row = 32 contiguous bytes of the
+//       row-major activations, loaded straight from global memory one k-slab (32 k) ahead and split in registers.
+//   W   is split and laid out in fragment order once per call by dense6_prep_kernel (bf16 [group][slab][piece]
+//       [tile][lane][8]); a block copies its group's 3 x NT KiB per slab into LDS with LDS-DMA (a linear image:
+//       lane l of a fragment read takes bytes 16 l .. 16 l + 15, conflict-free), double-buffered, one barrier
+//       per slab.
+#include <type_traits>
+
+#include "rm_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ablation builds (WRONG results; tools/probe/nn6_time.py): 1 no epilogue stores, 2 no A loads in the loop,
+// 4 no splitting in the loop, 8 one B fragment triple per slab, 16 no staging in the loop, 32 no MFMAs
+#ifndef RM_NN6_ABL
+#define RM_NN6_ABL 0
+#endif
+#ifdef RM_NN6_STAMP
+__device__ unsigned long long rm_nn6_stamp_buf[4 * 4096];
+#endif
+constexpr int kRows6 = 256;     // batch rows per block
+constexpr int kThreads6 = 512;  // 8 waves, 2 per SIMD
+constexpr int kSlabK = 32;      // k per slab = one 16x16x32 MFMA step
+constexpr int kMaxNT6 = 13;     // 16-column tiles per column group (N = 400 / 416: two groups of 13)
+
+struct NN6Args {
+  const float *A1, *Atail;  // A1 [M, >= 32 nfull] (16-byte aligned rows); the padded ragged end [M, 32] or NULL
+  int64_t lda1;
+  int nfull;         // whole slabs inside A1
+  int tail_k0;       // Atail == NULL and a ragged K: the last slab re-reads A1's columns [tail_k0, tail_k0 + 32)
+  const float *dot_w;  // or NULL: also dot_part[g * M + row] = sum over the group's columns of C[row, col] * dot_w[col]
+  float *dot_part;
+  const __bf16 *Wp;  // prepped weights
+  int N, nslab, ngroups;
+  const float *bias;
+  int epi, act;
+  const float *aux1;
+  int64_t ld1;
+  int64_t M;
+  float *C;
+  int64_t ldc;
+};
+
+__device__ __forceinline__ float act6(float v, int act) {
+  if (act == RM_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ float actgrad6(float o, int act) {
+  if (act == RM_ACT_RELU) return o > 0.f ? 1.f : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return o > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+
+// Wp[g][s][p][j][lane][e] = piece p of op(W)[k = 32 s + 8 (lane >> 4) + e][col = 16 (NT g + j) + (lane & 15)]
+template <int NT>
+__global__ void dense6_prep_kernel(const float *__restrict__ W, int64_t ldw, int trans, int K, int N, int nslab,
+                                   int ngroups, int overlap_k0, __bf16 *__restrict__ Wp) {
+  const int64_t total = (int64_t)ngroups * nslab * NT * 64 * 8;  // elements per piece
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = t & 7, lane = (t >> 3) & 63;
+    const int64_t u = t >> 9;
+    const int j = (int)(u % NT);
+    const int s = (int)((u / NT) % nslab), g = (int)(u / NT / nslab);
+    int k = kSlabK * s + 8 * (lane >> 4) + e;
+    const int col = 16 * (NT * g + j) + (lane & 15);
+    bool live = k < K;
+    if (overlap_k0 >= 0 && s == nslab - 1) {
+      // the last slab of a ragged K re-reads the activations' columns [K - 32, K): the weights of those the
+      // slab before has already covered are zero here
+      k = overlap_k0 + 8 * (lane >> 4) + e;
+      live = k >= kSlabK * (nslab - 1);
+    }
+    float x = 0.f;
+    if (live && col < N) x = trans ? W[(int64_t)col * ldw + k] : W[(int64_t)k * ldw + col];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    constexpr int kPieces = (3 * NT + 7) / 8 * 8;  // (padded: every wave issues the same number of DMA pieces)
+    const int64_t base = (int64_t)(g * (nslab + 2) + s) * kPieces * 512 + (int64_t)j * 512 + lane * 8 + e;
+    Wp[base] = h;
+    Wp[base + (int64_t)NT * 512] = m;
+    Wp[base + (int64_t)2 * NT * 512] = l;
+  }
+}
+
+// The ragged end of [A1 | A2] - A1's columns past its last whole slab and all of A2 - copied into Atail [M, 32]
+// (zero padded): every slab of the main kernel is then two unconditional float4 loads per row.  (A per-lane branch
+// around a load costs the overlap: hipcc answers it with s_waitcnt vmcnt(0) at the join or sinks the load to its
+// use.)  13 dense columns at DCN's layer 0: 17 MB written and read, ~8 us of a 300 us launch.
+__global__ void dense6_tail_kernel(const float *__restrict__ A1, int64_t lda1, int K1, const float *__restrict__ A2,
+                                   int64_t lda2, int K2, int kfull, int64_t M, float *__restrict__ Atail) {
+  const int64_t total = M * kSlabK;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / kSlabK;
+    const int k = kfull + (int)(t % kSlabK);
+    float v = 0.f;
+    if (k < K1) v = A1[row * lda1 + k];
+    else if (k < K1 + K2) v = A2[row * lda2 + (k - K1)];
+    Atail[t] = v;
+  }
+}
+
+__device__ __forceinline__ void load_a8(const float *base, int64_t ld, int64_t row, int k0, float (&x)[8]) {
+  const float4 *p = reinterpret_cast<const float4 *>(base + row * ld + k0);
+  const float4 u = p[0], v = p[1];
+  x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hh = (__bf16)x[e];
+    const float r1 = x[e] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const __bf16 ll = (__bf16)(r1 - (float)mm);
+    h[e] = hh; m[e] = mm; l[e] = ll;
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kThreads6) void dense_nn6_kernel(NN6Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+  constexpr int kPieces = (3 * NT + 7) / 8 * 8;  // 1 KiB pieces per slab, padded to 8 per DMA round
+  constexpr int kSlabBytes = kPieces * 1024;
+  constexpr int kVmPerSlab = kPieces / 8 + 4;    // vector-memory operations a wave issues per slab
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = blockIdx.x % a.ngroups;
+  const int64_t row0 = (int64_t)(blockIdx.x / a.ngroups) * kRows6 + 32 * w;
+  const int r = lane & 15, q = lane >> 4;
+  const unsigned char *Wg = reinterpret_cast<const unsigned char *>(a.Wp) + (int64_t)g * (a.nslab + 2) * kSlabBytes;
+
+  // LDS-DMA of one slab into ring buffer buf: kPieces pieces of 1 KiB, piece 8 i + w by wave w - the same count
+  // for every wave, no branch.  (The prepped weights carry two zero slabs behind the last: the loop never asks.)
+  auto stage = [&](int s, int buf) {
+    const unsigned char *src = Wg + (int64_t)s * kSlabBytes + lane * 16;
+    unsigned char *dst = smem6 + buf * kSlabBytes;
+#pragma unroll
+    for (int i = 0; i < kPieces / 8; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (8 * i + w) * 1024),
+                                       (__attribute__((address_space(3))) void *)(dst + (8 * i + w) * 1024), 16, 0, 0);
+  };
+  // slab s of this lane's two rows: out of A1 (whole slabs), the padded tail copy, or - past the end - the last
+  // slab again (a wasted, in-range load: the loop body stays one basic block)
+  const int64_t ra0 = row0 + r < a.M ? row0 + r : a.M - 1, ra1 = row0 + 16 + r < a.M ? row0 + 16 + r : a.M - 1;
+  auto load_slab = [&](int s, float (&x0)[8], float (&x1)[8]) {
+    const int sc = s < a.nslab ? s : a.nslab - 1;
+    const bool tail = sc >= a.nfull;  // (wave-uniform: scalar selects)
+    const bool copy = tail && a.Atail != nullptr;
+    const float *base = copy ? a.Atail : a.A1;
+    const int64_t ld = copy ? kSlabK : a.lda1;
+    const int k0 = (copy ? 0 : (tail ? a.tail_k0 : kSlabK * sc)) + 8 * q;
+    load_a8(base, ld, ra0, k0, x0);
+    load_a8(base, ld, ra1, k0, x1);
+  };
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef RM_NN6_STAMP
+  if (tid == 0 && blockIdx.x < 4096) {
+    rm_nn6_stamp_buf[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+    rm_nn6_stamp_buf[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+  }
+#endif
+
+  // prologue: the A rows of slabs 0, 1 (register sets P, Q) and 2 (P again, once slab 0 is split) and the weights
+  // of slabs 0 and 1 (ring buffers 0, 1) on their way
+  float xp[2][8], xq[2][8];
+  bf16x8 fr[2][6];  // the split A fragments of two slabs: [slab parity][h0 m0 l0 h1 m1 l1]
+  load_slab(0, xp[0], xp[1]);
+  stage(0, 0);
+  load_slab(1, xq[0], xq[1]);
+  stage(1, 1);
+  split8(xp[0], fr[0][0], fr[0][1], fr[0][2]);
+  split8(xp[1], fr[0][3], fr[0][4], fr[0][5]);
+  load_slab(2, xp[0], xp[1]);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kVmPerSlab) : "memory");  // weights of slab 0 landed (slab 1's, the rows of 2: later)
+  __builtin_amdgcn_s_barrier();
+
+  // One slab s (CUR = its parity): MFMAs on the fragments split during the PREVIOUS slab, and between them - the
+  // matrix pipe holds the vector issue for only half of an MFMA's 16 cycles - the splitting of slab s + 1's rows
+  // (loaded two slabs ago); then slab s + 3's rows into the registers just split and slab s + 2's weights into the
+  // ring buffer read during slab s - 1.  (With the split ahead of the MFMAs all 8 waves of the block - in step
+  // behind the barrier - did their ~130 vector instructions while the matrix pipe idled: 2,600 of 7,600 cycles
+  // per slab.)
+  auto slab = [&](int s, auto cur, float (&xn0)[8], float (&xn1)[8]) {
+    constexpr int C = decltype(cur)::value, Nx = C ^ 1;
+    if (!(RM_NN6_ABL & 16)) stage(s + 2, (s + 2) % 3);
+    const unsigned char *ws = smem6 + (s % 3) * kSlabBytes + lane * 16;
+    if (!(RM_NN6_ABL & 4)) {
+      split8(xn0, fr[Nx][0], fr[Nx][1], fr[Nx][2]);
+      split8(xn1, fr[Nx][3], fr[Nx][4], fr[Nx][5]);
+    }
+    if (!(RM_NN6_ABL & 2)) load_slab(s + 3, xn0, xn1);
+    // the weight fragments of column tile j + 1 are read while tile j's MFMAs run
+    bf16x8 bw[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bw[0][p] = *reinterpret_cast<const bf16x8 *>(ws + (p * NT) * 1024);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int jn = (RM_NN6_ABL & 8) ? 0 : (j + 1 < NT ? j + 1 : j);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bw[(j + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(ws + (p * NT + jn) * 1024);
+      const bf16x8 bh = bw[j & 1][0], bm = bw[j & 1][1], bl = bw[j & 1][2];
+      // the small products first, the leading one last.  The WEIGHT fragment is the MFMA's A operand: the result
+      // tile is D[m = column 4 q + i of the tile][n = batch row r] - a lane ends up with four CONSECUTIVE output
+      // columns of one batch row (one 16-byte store, bias / aux as one 16-byte load).  The two row tiles'
+      // accumulators alternate: no MFMA reads the result of the one issued just before it.
+      const bf16x8 ah0 = fr[C][0], am0 = fr[C][1], al0 = fr[C][2], ah1 = fr[C][3], am1 = fr[C][4], al1 = fr[C][5];
+      f32x4 c0 = acc[0][j], c1 = acc[1][j];
+      if (RM_NN6_ABL & 32) {
+        c0[0] += (float)al0[0] + (float)bh[0] + (float)bm[1] + (float)bl[2] + (float)ah0[1] + (float)am0[2];
+        c1[0] += (float)al1[0] + (float)bh[0] + (float)bm[1] + (float)bl[2] + (float)ah1[1] + (float)am1[2];
+      } else {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al1, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah1, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am1, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am1, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah1, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah1, c1, 0, 0, 0);
+      }
+      acc[0][j] = c0;
+      acc[1][j] = c1;
+    }
+    // the order hipcc is to emit: after every MFMA one vector instruction of the next slab's split (an MFMA holds
+    // the vector issue for half of its 16 cycles; left alone the scheduler puts the ~130 split instructions in
+    // front of the 156 MFMAs, and the two waves of a SIMD - in step behind the barrier - then both leave the
+    // matrix pipe idle), the three fragment reads of the next tile behind each tile's twelve
+    if (!(RM_NN6_ABL & 64)) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // VALU
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);    // DS read
+      }
+    }
+    // (a raw barrier: __syncthreads() carries a fence, i.e. s_waitcnt vmcnt(0) - it would wait for the rows and
+    // weights just requested for the slabs ahead)
+    if (RM_NN6_ABL & (2 | 16)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kVmPerSlab) : "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  int s = 0;
+  for (; s + 1 < a.nslab; s += 2) {
+    slab(s, std::integral_constant<int, 0>{}, xq[0], xq[1]);      // (splits slab s + 1 = Q, refills Q with s + 3)
+    slab(s + 1, std::integral_constant<int, 1>{}, xp[0], xp[1]);  // (splits slab s + 2 = P, refills P with s + 4)
+  }
+  if (s < a.nslab) slab(s, std::integral_constant<int, 0>{}, xq[0], xq[1]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the wasted loads past the last slab)
+#ifdef RM_NN6_STAMP
+  if (tid == 0 && blockIdx.x < 4096) {
+    rm_nn6_stamp_buf[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    rm_nn6_stamp_buf[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
+  }
+#endif
+
+  // epilogue: lane (r, q) holds columns 4 q .. 4 q + 3 of every tile for batch rows r (t = 0) and 16 + r (t = 1)
+  const bool vec4 = (a.ldc & 3) == 0 && (a.N & 3) == 0 && (a.aux1 == nullptr || (a.ld1 & 3) == 0);
+  float dot[2] = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int64_t row = row0 + 16 * t + r;
+    if (row >= a.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = 16 * (NT * g + j) + 4 * q;
+      if (col >= a.N) continue;
+      float v[4], b[4] = {0.f, 0.f, 0.f, 0.f}, x[4] = {0.f, 0.f, 0.f, 0.f};
+      const bool whole = vec4 && col + 4 <= a.N;
+      if (whole) {
+        if (a.bias != nullptr) *reinterpret_cast<float4 *>(b) = *reinterpret_cast<const float4 *>(a.bias + col);
+        if (a.aux1 != nullptr) *reinterpret_cast<float4 *>(x) = *reinterpret_cast<const float4 *>(a.aux1 + row * a.ld1 + col);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (col + i >= a.N) continue;
+          if (a.bias != nullptr) b[i] = a.bias[col + i];
+          if (a.aux1 != nullptr) x[i] = a.aux1[row * a.ld1 + col + i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float u = acc[t][j][i] + b[i];
+        if (a.epi == RM_DENSE_BIAS_ACT) u = act6(u, a.act);
+        else if (a.epi == RM_DENSE_MUL_ACTGRAD) u *= actgrad6(x[i], a.act);
+        else u += x[i];
+        v[i] = u;
+      }
+      if (a.dot_w != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (col + i < a.N) dot[t] += v[i] * a.dot_w[col + i];
+      }
+      if ((RM_NN6_ABL & 1) && v[0] != 12345.678f) continue;
+      if (whole) {
+        *reinterpret_cast<float4 *>(a.C + row * a.ldc + col) = *reinterpret_cast<const float4 *>(v);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (col + i < a.N) a.C[row * a.ldc + col + i] = v[i];
+      }
+    }
+  }
+  if (a.dot_w != nullptr) {
+    // the row's dot product over this group's columns: the four column quarters (q) of a row sit 16 lanes apart
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float d = dot[t];
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      const int64_t row = row0 + 16 * t + r;
+      if (q == 0 && row < a.M) a.dot_part[(int64_t)g * a.M + row] = d;
+    }
+  }
+}
+
+// out[b] = w0 + the groups' partial dot products in group order
+__global__ void dense6_dot_finish_kernel(const float *__restrict__ part, int ngroups, int64_t M,
+                                         const float *__restrict__ w0, float *__restrict__ out) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < M; b += (int64_t)gridDim.x * blockDim.x) {
+    float v = w0 != nullptr ? w0[0] : 0.f;
+    for (int g = 0; g < ngroups; ++g) v += part[(int64_t)g * M + b];
+    out[b] = v;
+  }
+}
+
+}  // namespace
+
+#ifdef RM_NN6_STAMP
+extern "C" int rm_debug_nn6_stamps(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rm_nn6_stamp_buf), sizeof(unsigned long long) * n);
+}
+#endif
+
+static inline int64_t dense6_w_floats(int K, int N) {
+  const int nslab = (K + kSlabK - 1) / kSlabK;
+  const int nt = (N + 15) / 16;
+  const int ngroups = (nt + kMaxNT6 - 1) / kMaxNT6;
+  return ((int64_t)ngroups * (nslab + 2) * ((3 * kMaxNT6 + 7) / 8 * 8) * 1024 + 3) / 4;
+}
+
+// floats of workspace: the split weights + the padded copy of the ragged end of the activations [M, 32] (a second
+// piece A2) + the per-group partial row dots
+extern "C" int64_t rm_dense6_workspace(int K, int N, int64_t M) {
+  if (K <= 0 || N <= 0 || M < 0) return 0;
+  const int ngroups = ((N + 15) / 16 + kMaxNT6 - 1) / kMaxNT6;
+  return dense6_w_floats(K, N) + M * kSlabK + (int64_t)ngroups * M + 64;
+}
+
+extern "C" int rm_dense_fwd6(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2,
+                             const float *W, int64_t ldw, int w_transposed, int N, const float *bias, int epilogue,
+                             int act, const float *aux1, int64_t ld_aux1, int64_t M, float *C, int64_t ldc,
+                             const float *dot_w, const float *dot_w0, float *dot_out, float *workspace,
+                             rm_stream_t stream) {
+  RM_REQUIRE(M >= 0 && K1 > 0 && K2 >= 0 && N > 0, "rm_dense_fwd6: bad sizes");
+  if (M == 0) return RM_OK;
+  RM_REQUIRE(A1 && W && C && workspace && rm_aligned16(workspace), "rm_dense_fwd6: NULL / unaligned argument");
+  RM_REQUIRE(K2 == 0 || A2, "rm_dense_fwd6: a second piece needs A2");
+  RM_REQUIRE(epilogue >= RM_DENSE_BIAS_ACT && epilogue <= RM_DENSE_ADD, "rm_dense_fwd6: epilogue not covered");
+  RM_REQUIRE(epilogue != RM_DENSE_MUL_ACTGRAD || aux1, "rm_dense_fwd6: MUL_ACTGRAD needs aux1");
+  RM_REQUIRE(rm_aligned16(A1) && lda1 % 4 == 0, "rm_dense_fwd6: A1 rows must be 16-byte aligned");
+  RM_REQUIRE(!dot_w == !dot_out, "rm_dense_fwd6: dot_w and dot_out come together");
+  const int K = K1 + K2;
+  const int nslab = (K + kSlabK - 1) / kSlabK;
+  const int nfull = K1 / kSlabK;  // whole slabs of A1
+  if (nslab - nfull > 1) {
+    rm_set_error("rm_dense_fwd6: the ragged end (K1 %% 32 columns + K2) must fit one slab of 32");
+    return RM_EUNSUPPORTED;
+  }
+  // the ragged end: one piece with at least a slab of 4-aligned columns -> the last slab re-reads [K - 32, K) in
+  // place (its weights zeroed where the slab before has been); otherwise a padded copy
+  const bool ragged = nslab > nfull;
+  const bool overlap = ragged && K2 == 0 && K1 >= kSlabK && K1 % 4 == 0;
+  const int nt = (N + 15) / 16;
+  const int ngroups = (nt + kMaxNT6 - 1) / kMaxNT6;
+  hipStream_t st = (hipStream_t)stream;
+  __bf16 *Wp = reinterpret_cast<__bf16 *>(workspace);
+  float *Atail = workspace + (dense6_w_floats(K, N) + 3) / 4 * 4;
+  float *dot_part = Atail + M * kSlabK;
+  hipLaunchKernelGGL((dense6_prep_kernel<kMaxNT6>),
+                     dim3(rm_grid_cap(((int64_t)ngroups * nslab * kMaxNT6 * 512 + 255) / 256, 2048)), dim3(256), 0,
+                     st, W, ldw, w_transposed, K, N, nslab, ngroups, overlap ? K - kSlabK : -1, Wp);
+  if (ragged && !overlap)
+    hipLaunchKernelGGL(dense6_tail_kernel, dim3(rm_grid_cap((M * kSlabK + 255) / 256, 256 * 8)), dim3(256), 0, st, A1,
+                       lda1, K1, A2, lda2, K2, nfull * kSlabK, M, Atail);
+  NN6Args a{A1, (ragged && !overlap) ? Atail : nullptr, lda1, nfull, overlap ? K - kSlabK : 0, dot_w,
+            dot_part, Wp, N, nslab, ngroups, bias, epilogue, act, aux1, ld_aux1, M, C, ldc};
+  const int64_t ntiles = (M + kRows6 - 1) / kRows6;
+  const size_t smem = 3 * ((3 * kMaxNT6 + 7) / 8 * 8) * 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_nn6_kernel<kMaxNT6>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((dense_nn6_kernel<kMaxNT6>), dim3((unsigned)(ntiles * ngroups)), dim3(kThreads6), smem, st, a);
+  if (dot_w)
+    hipLaunchKernelGGL(dense6_dot_finish_kernel, dim3(rm_grid_cap((M + 255) / 256, 1024)), dim3(256), 0, st, dot_part,
+                       ngroups, M, dot_w0, dot_out);
+  RM_CHECK_LAUNCH("rm_dense_fwd6");
+  return RM_OK;
+}

@@ -202,16 +202,23 @@ class MLP:
             xd = xd * m[:, self.FD:] if xd is not None else None
             self.xe, self.xd = xe, xd
         self._alloc_dense(xe.device)
+        dotted = False
         for i in range(n):
             W, b = p[f"{pre}dnn_layer_{i}_weights"], p[f"{pre}dnn_layer_{i}_bias"]
             a = self.a[i]
             if i == 0:
-                ops.dense_fwd(xe, xd if self.Dn else None, W, a, self._fws, bias=b, act=self.act)
+                ops.dense_fwd(xe, xd if self.Dn else None, W, a, self._fws, bias=b, act=self.act, ws6=self._fws6)
             else:
-                ops.dense_fwd(self.a[i - 1], None, W, a, self._fws, bias=b, act=self.act)
+                # the last layer's kernel also forms the output projection a . dnn_w + dnn_w0 from its registers
+                dot = None
+                if i == n - 1 and not (self.keep[n] < 1 and self.masks[n] is not None):
+                    dot = (p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"], self.out.view(B))
+                dotted = ops.dense_fwd(self.a[i - 1], None, W, a, self._fws, bias=b, act=self.act, ws6=self._fws6,
+                                       dot=dot) and dot is not None
             if self.keep[i + 1] < 1 and self.masks[i + 1] is not None:
                 a.mul_(self.masks[i + 1] / self.keep[i + 1])
-        ops.rowdot(self.a[-1], p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"], self.out.view(B))
+        if not dotted:
+            ops.rowdot(self.a[-1], p[f"{pre}dnn_w"].view(-1), p[f"{pre}dnn_w0"], self.out.view(B))
         return self.out.view(B)
 
     def _alloc_dense(self, device):
@@ -222,6 +229,12 @@ class MLP:
                  for i in range(len(self.hidden)))
         ww = max(ops.dense_wgrad_workspace(dims[i], dims[i + 1], self._B) for i in range(len(self.hidden)))
         self._fws = torch.empty(fw, dtype=F32, device=device)
+        # wide layers on the bf16 matrix pipe with split fp32 operands (rm_dense_fwd6, csrc/gemm6.hip) unless
+        # dense_gemm = "f32" asks for the f32 MFMA kernel
+        self._fws6 = None
+        if getattr(self, "dense_gemm", "bf16x6") == "bf16x6":
+            kmax = max(dims)
+            self._fws6 = torch.empty(ops.dense6_workspace(kmax, kmax, self._B), dtype=F32, device=device)
         self._wws = torch.empty(max(ww, 1), dtype=F32, device=device)
         self._wws_B = self._B
         self._ws = torch.empty(256 * 1024, dtype=F32, device=device)
@@ -289,7 +302,8 @@ class MLP:
             if i == 0:
                 ops.dense_wgrad(self.xe, self.xd if self.Dn else None, da, gW, self._wws, db=db)
                 # dLoss/dxe = da W[:FD]^T (the dense inputs need no gradient)
-                ops.dense_fwd(da, None, W[: self.FD], dxe, self._fws, transposed=True, epilogue=ops.DENSE_ADD)
+                ops.dense_fwd(da, None, W[: self.FD], dxe, self._fws, transposed=True, epilogue=ops.DENSE_ADD,
+                              ws6=self._fws6)
                 if self.keep[0] < 1 and self.masks[0] is not None:
                     dxe.mul_(self.masks[0][:, : self.FD] / self.keep[0])
             else:
@@ -300,7 +314,7 @@ class MLP:
                 # post-activation values (dropped positions are zeroed by the mask)
                 ops.dense_fwd(da, None, W, self.da[i - 1], self._fws, transposed=True,
                               epilogue=ops.DENSE_MUL_ACTGRAD if self.act != "identity" else ops.DENSE_ADD,
-                              act=self.act, aux1=prev if self.act != "identity" else None)
+                              act=self.act, aux1=prev if self.act != "identity" else None, ws6=self._fws6)
                 da = self.da[i - 1]
                 if dropped:
                     da.mul_(self.masks[i] / self.keep[i])
@@ -717,13 +731,16 @@ class Engine:
             if p["bound"] == "hbm":
                 achieved, peak, unit = p["work"] / (ms * 1e-3) / 1e9, 8000.0, "GB/s"
             else:
-                achieved, peak, unit = p["work"] / (ms * 1e-3) / 1e12, 157.3, "TFLOP/s"
+                # (peak: the dense f32 MFMA rate, or the probe's own - the bf16 pipe for the split-operand GEMM)
+                achieved, peak, unit = p["work"] / (ms * 1e-3) / 1e12, p.get("peak", 157.3), "TFLOP/s"
             rec = {"kernel": p["name"], "symbol": p["symbol"], "bound": p["bound"],
                    "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                    "frac": round(achieved / peak, 4), "traffic": None,
                    "avg_launch_us": round(ms * 1e3, 2), "min_launch_us": round(ts[0] * 1e3, 2),
                    "median_launch_us": round(ts[len(ts) // 2] * 1e3, 2), "algorithmic_per_launch": p["work"],
                    "timing": f"hipEvent pairs, {iters_p} launches (mean; min and median beside it)"}
+            if "extra" in p:
+                rec.update(p["extra"](ms))
             if "work_min" in p:
                 # the same launch priced on the bytes the fused kernel itself has to move
                 rec["algorithmic_min_per_launch"] = p["work_min"]
@@ -887,6 +904,7 @@ class DeepFMEngine(Engine):
             self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
                            hp.get("deep_activation", "relu"), self.device)
             self.mlp.stream_d_rows = hp.get("d_rows_reuse", "cache") == "stream"
+            self.mlp.dense_gemm = hp.get("dense_gemm", "bf16x6")
 
     def _has_fm(self):
         return self.use_fm
@@ -1097,6 +1115,7 @@ class DCNEngine(Engine):
         self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
                        hp.get("deep_activation", "relu"), dev)
         self.mlp.stream_d_rows = hp.get("d_rows_reuse", "cache") == "stream"
+        self.mlp.dense_gemm = hp.get("dense_gemm", "bf16x6")
         self.cross_type = hp.get("cross_type", "vector")
         if self.cross_type not in ("vector", "matrix"):
             raise ValueError(f"cross_type {self.cross_type!r}: 'vector' or 'matrix'")
@@ -1225,10 +1244,25 @@ class DCNEngine(Engine):
         W, b = self.params["dnn_layer_0_weights"], self.params["dnn_layer_0_bias"]
         m, p, L, d = self.mlp, self.params, self.L, self.FD + self.Dn
         K, N = W.shape
-        probes = [dict(name=f"dense_nn_kernel (rm_dense_fwd, DNN layer 0: [{B},{K}] x [{K},{N}] + bias + {m.act})",
-                       symbol="dense_nn_kernel",
-                       fn=lambda: ops.dense_fwd(xe, xd, W, m.a[0], m._fws, bias=b, act=m.act),
-                       work=2.0 * B * K * N, bound="mfma")]
+        m._alloc_dense(xe.device)
+        if m._fws6 is not None and ops.dense_fwd6_supported(xe, xd):
+            # the product path: fp32 operands split into three bf16 pieces, SIX bf16 MFMAs per k-step (csrc/gemm6.hip)
+            # - priced on the bf16 pipe with the six products counted; the fp32 GEMM it stands for beside it
+            flops = 2.0 * B * K * N
+            probes = [dict(name=f"dense_nn6_kernel (rm_dense_fwd6, DNN layer 0: [{B},{K}] x [{K},{N}] + bias + {m.act}; "
+                                "fp32 operands as 3 bf16 pieces, 6 piece products per k-step on the bf16 matrix pipe)",
+                           symbol="dense_nn6_kernel",
+                           fn=lambda: ops.dense_fwd(xe, xd, W, m.a[0], m._fws, bias=b, act=m.act, ws6=m._fws6),
+                           work=6.0 * flops, bound="mfma", peak=2500.0,
+                           extra=lambda ms: {"fp32_gemm_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                                             "fp32_gemm_vs_f32_mfma_peak_157": round(flops / (ms * 1e-3) / 1e12 / 157.3, 4),
+                                             "note": "peak = dense bf16 MFMA (2.5 PFLOP/s); achieved counts the six "
+                                                     "bf16 products per fp32 product; fp32_gemm_tflops = 2 M K N / time"})]
+        else:
+            probes = [dict(name=f"dense_nn_kernel (rm_dense_fwd, DNN layer 0: [{B},{K}] x [{K},{N}] + bias + {m.act})",
+                           symbol="dense_nn_kernel",
+                           fn=lambda: ops.dense_fwd(xe, xd, W, m.a[0], m._fws, bias=b, act=m.act),
+                           work=2.0 * B * K * N, bound="mfma")]
         if not self.matrix:
             probes.append(dict(
                 name=f"cross_fwd_kernel (rm_cross_fwd, {L} layers fused: x0 [{B},{d}] read once -> logit, p)",
@@ -1286,6 +1320,7 @@ class XDeepFMEngine(Engine):
         self.mlp = MLP(self.params, self.grads, self.FD, self.Dn, hp["deep_hidden_units"],
                        hp.get("deep_activation", "leaky_relu"), dev)
         self.mlp.stream_d_rows = hp.get("d_rows_reuse", "cache") == "stream"
+        self.mlp.dense_gemm = hp.get("dense_gemm", "bf16x6")
         m = self.F
         self.Hs, self.pool_from, self.pool_col0 = [m], [], []
         final = 0

@@ -689,9 +689,48 @@ def dense_wgrad_workspace(K, N, M):
     return int(_lib.lib().rm_dense_wgrad_workspace(int(K), int(N), int(M)))
 
 
+def dense6_workspace(K, N, M):
+    """Floats of workspace for the bf16x6 form of dense_fwd (rm_dense6_workspace)."""
+    return int(_lib.lib().rm_dense6_workspace(int(K), int(N), int(M)))
+
+
+def dense_fwd6_supported(a1, a2, epilogue=DENSE_BIAS_ACT, aux2=None, out2=None):
+    """Does rm_dense_fwd6 (fp32 operands split into bf16 pieces, csrc/gemm6.hip) take this call?"""
+    K1 = a1.shape[1]
+    K2 = 0 if a2 is None else a2.shape[1]
+    return (epilogue in (DENSE_BIAS_ACT, DENSE_MUL_ACTGRAD, DENSE_ADD) and aux2 is None and out2 is None
+            and a1.stride(1) == 1 and a1.stride(0) % 4 == 0 and a1.data_ptr() % 16 == 0 and K1 % 32 + K2 <= 32)
+
+
 def dense_fwd(a1, a2, W, out, filter_ws, *, transposed=False, bias=None, epilogue=DENSE_BIAS_ACT,
-              act="identity", aux1=None, aux2=None, out2=None):
-    """out[M,N] = epilogue([a1 | a2] @ (W.T if transposed else W)) (rm_dense_fwd)."""
+              act="identity", aux1=None, aux2=None, out2=None, ws6=None, dot=None):
+    """out[M,N] = epilogue([a1 | a2] @ (W.T if transposed else W)) (rm_dense_fwd).  ws6 (dense6_workspace floats):
+    the call runs on the bf16 matrix pipe with split operands (rm_dense_fwd6) when that kernel takes it; returns
+    True when it did.  dot = (w [N], w0 [1] or None, out [M]): with rm_dense_fwd6 also out[b] = out_row(b) . w + w0
+    (otherwise the caller runs rowdot)."""
+    if ws6 is not None and dense_fwd6_supported(a1, a2, epilogue, aux2, out2):
+        p1, lda1, K1 = _rows2d(a1, "a1")
+        p2, lda2, K2 = _rows2d(a2, "a2", allow_none=True)
+        M = a1.shape[0]
+        pw, ldw, wc = _rows2d(W, "W")
+        K = K1 + K2
+        N = W.shape[0] if transposed else wc
+        if (wc if transposed else W.shape[0]) != K:
+            raise ValueError(f"W {tuple(W.shape)} does not match K={K} (transposed={transposed})")
+        pc, ldc, nc = _rows2d(out, "out")
+        if out.shape[0] != M or nc != N:
+            raise ValueError(f"out {tuple(out.shape)} must be [{M},{N}]")
+        px1, ld1, _ = _rows2d(aux1, "aux1", allow_none=True)
+        if aux1 is not None and tuple(aux1.shape) != (M, N):
+            raise ValueError(f"aux1 {tuple(aux1.shape)} must be [{M},{N}]")
+        if ws6.numel() < dense6_workspace(K, N, M):
+            raise ValueError("ws6 too small (rm_dense6_workspace)")
+        dw, dw0, dout = dot if dot is not None else (None, None, None)
+        _lib.call("rm_dense_fwd6", p1, lda1, K1, p2, lda2, K2, pw, ldw, int(bool(transposed)), N,
+                  _chk(bias, "bias", F32, (N,), allow_none=True), int(epilogue), ACT_IDS[act], px1, ld1, M, pc, ldc,
+                  _chk(dw, "dot w", F32, (N,), allow_none=True), _chk(dw0, "dot w0", F32, (1,), allow_none=True),
+                  _chk(dout, "dot out", F32, (M,), allow_none=True), _chk(ws6, "ws6", F32), _stream())
+        return True
     p1, lda1, K1 = _rows2d(a1, "a1")
     p2, lda2, K2 = _rows2d(a2, "a2", allow_none=True)
     M = a1.shape[0]

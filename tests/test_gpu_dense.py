@@ -202,3 +202,85 @@ def test_outer_actgrad_sums(hip_lib, B, N, act):
     _close(d_w, (g.double()[:, None] * a.double()).sum(0).float())
     _close(d_w0, g.double().sum().reshape(1).float())
     _close(db, want_da.sum(0).float())
+
+
+SHAPES6 = [  # M, K1, K2, N: what rm_dense_fwd6 takes (K1 % 32 + K2 <= 32)
+    (300, 416, 13, 400),    # DCN layer 0: 13 whole slabs of E + the dense inputs as a padded copy
+    (129, 400, 0, 400),     # DCN layer 1: ragged K, the last slab re-reads [368, 400) in place; M tail
+    (777, 400, 0, 416),     # DCN's dX0 (transposed weights below), two full column groups, 4 row tiles
+    (37, 40, 3, 50),        # everything ragged, one column group
+    (64, 64, 0, 900),       # five column groups
+    (5, 8, 0, 8),           # less than a slab: all of it through the copy
+]
+
+
+@pytest.mark.parametrize("M,K1,K2,N", SHAPES6)
+def test_dense_fwd6_split_operands_match_float64_at_least_as_well_as_the_f32_kernel(hip_lib, M, K1, K2, N):
+    """rm_dense_fwd6 (fp32 operands split into three bf16 pieces, six piece products on the bf16 matrix pipe, fp32
+    accumulate): every epilogue it covers, both weight layouts and the fused output projection against float64 -
+    to the f32 kernel's tolerance, and never worse than 1.5x the f32-MFMA kernel's own error on the same input."""
+    from recman_amd import ops
+
+    a1, a2, W, bias = _inputs(M, K1, K2, N, seed=3)
+    g = torch.Generator().manual_seed(6)
+    aux1 = torch.randn(M, N, generator=g)
+    wdot, w0 = torch.randn(N, generator=g), torch.randn(1, generator=g)
+    x = torch.cat([a1] + ([a2] if a2 is not None else []), dim=1).double()
+    z = x @ W.double()
+    a1d, a2d = _dev_padded(a1), (a2.cuda() if a2 is not None else None)
+    assert ops.dense_fwd6_supported(a1d, a2d)
+    ws = torch.empty(ops.dense_filter_workspace(K1 + K2, N), device="cuda")
+    ws6 = torch.empty(ops.dense6_workspace(K1 + K2, N, M), device="cuda")
+    out6 = torch.full((M, N), float("nan"), device="cuda")
+    out32 = torch.empty(M, N, device="cuda")
+    dot = torch.full((M,), float("nan"), device="cuda")
+    want = torch.relu(z + bias.double())
+    took = ops.dense_fwd(a1d, a2d, W.cuda(), out6, ws, bias=bias.cuda(), act="relu", ws6=ws6,
+                         dot=(wdot.cuda(), w0.cuda(), dot))
+    assert took is True
+    ops.dense_fwd(a1d, a2d, W.cuda(), out32, ws, bias=bias.cuda(), act="relu")
+    _close(out6, want, what="bias + relu")
+    _close(dot, want @ wdot.double() + w0.double(), what="fused output projection")
+    e6 = float((out6.cpu().double() - want).abs().max())
+    e32 = float((out32.cpu().double() - want).abs().max())
+    assert e6 <= 1.5 * e32 + 1e-7, (e6, e32)
+    # transposed weights, padded output rows
+    outp = torch.zeros(M, N + 4, device="cuda")
+    assert ops.dense_fwd(a1d, a2d, W.t().contiguous().cuda(), outp[:, :N], ws, transposed=True, bias=bias.cuda(),
+                         act="leaky_relu", ws6=ws6)
+    _close(outp[:, :N], torch.nn.functional.leaky_relu(z + bias.double(), 0.2), what="transposed W")
+    assert float(outp[:, N:].abs().max()) == 0.0
+    # the backward's epilogues
+    assert ops.dense_fwd(a1d, a2d, W.cuda(), out6, ws, epilogue=ops.DENSE_MUL_ACTGRAD, act="leaky_relu",
+                         aux1=aux1.cuda(), ws6=ws6)
+    _close(out6, z * torch.where(aux1 > 0, 1.0, 0.2).double(), what="mul_actgrad")
+    assert ops.dense_fwd(a1d, a2d, W.cuda(), out6, ws, epilogue=ops.DENSE_ADD, aux1=aux1.cuda(), ws6=ws6)
+    _close(out6, z + aux1.double(), what="add")
+    assert ops.dense_fwd(a1d, a2d, W.cuda(), out6, ws, epilogue=ops.DENSE_ADD, ws6=ws6)
+    _close(out6, z, what="plain")
+    # deterministic
+    again = torch.empty_like(out6)
+    ops.dense_fwd(a1d, a2d, W.cuda(), again, ws, epilogue=ops.DENSE_ADD, ws6=ws6)
+    assert torch.equal(again, out6)
+
+
+def test_dense_fwd6_declines_what_it_does_not_cover_and_keeps_large_and_tiny_values(hip_lib):
+    from recman_amd import ops
+
+    a = torch.randn(16, 80, device="cuda")
+    assert not ops.dense_fwd6_supported(a[:, :48], torch.randn(16, 20, device="cuda"))   # ragged end of 36 columns
+    assert not ops.dense_fwd6_supported(a[:, 1:65], None)                                 # unaligned rows
+    assert not ops.dense_fwd6_supported(a[:, :64], None, ops.DENSE_CROSS)
+    # values across the exponent range: the three pieces follow the exponent (bf16 has fp32's range)
+    M, K, N = 64, 64, 32
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(M, K, generator=g) * torch.tensor([1e-18, 1e-6, 1.0, 1e6]).repeat(K // 4)
+    W = torch.randn(K, N, generator=g) * torch.tensor([1e12, 1.0, 1e-3, 1e-12]).repeat_interleave(K // 4)[:, None]
+    out = torch.empty(M, N, device="cuda")
+    ws = torch.empty(ops.dense_filter_workspace(K, N), device="cuda")
+    ws6 = torch.empty(ops.dense6_workspace(K, N, M), device="cuda")
+    assert ops.dense_fwd(x.cuda(), None, W.cuda(), out, ws, epilogue=ops.DENSE_ADD, ws6=ws6)
+    want = x.double() @ W.double()
+    # per element against the sum of |products| (the honest scale of a dot product's rounding error)
+    scale = (x.double().abs() @ W.double().abs())
+    assert float(((out.cpu().double() - want).abs() / scale).max()) < 2e-6
