@@ -762,9 +762,9 @@ def collect(a, rank, world, local, dist, rehearse, backend, live, pmc_note, fall
     sub_steps, sub_warm = max(5, min(a.steps, 20)), max(2, min(a.warmup, 5))
     if extras:
         out["zipf"] = _sub(measure(a, "deepfm", dev, rank, world, dist, rehearse, False, {}, {}, a.steps,
-                                   a.warmup, 0.0, zipf=1.05, want_cpu=False, want_opt=False),
+                                   a.warmup, 0.0, zipf=1.05, want_cpu=False, want_opt=True),
                            note="the DeepFM workload with Zipf(1.05) ids; SURVEY.md 8d asks for both index "
-                                "distributions")
+                                "distributions (its optimizer_step: rows with thousands of occurrences per batch)")
         out["workloads"] = {}
         for name in ("xdeepfm", "dcn"):
             out["workloads"][name] = _sub(measure(a, name, dev, rank, world, dist, rehearse, False, live,
