@@ -14,7 +14,9 @@
 // Replaces tf.matmul + bias + activation of DNN.__call__ (recman/tf/core/layers.py:594-602) and the
 // data-gradient GEMM of its backward, like rm_dense_fwd's f32 path.
 //
-// Block = 8 waves = 256 batch rows x ONE column group of NT <= 13 16-column tiles; wave w owns rows
+// Block = 4 waves (one per SIMD) = 128 batch rows x ONE column group of NT <= 13 16-column tiles, TWO blocks per CU
+// (80 KB of LDS each): the blocks drift out of phase, so one's MFMAs cover the other's splitting, staging, barrier
+// and epilogue (8 waves in ONE block ran every phase at the same time on both waves of a SIMD).  Wave w owns rows
 // [32 w, 32 w + 32) (two 16-row MFMA tiles) and all NT column tiles: 2 x NT x 4 accumulator registers.
 //   A   never touches LDS: a lane's operand fragment is 8 consecutive k of one row = 32 contiguous bytes of the
 //       row-major activations, loaded straight from global memory one k-slab (32 k) ahead and split in registers.
@@ -22,6 +24,7 @@
 //       [tile][lane][8]); a block copies its group's 3 x NT KiB per slab into LDS with LDS-DMA (a linear image:
 //       lane l of a fragment read takes bytes 16 l .. 16 l + 15, conflict-free), double-buffered, one barrier
 //       per slab.
+#include <cstdlib>
 #include <type_traits>
 
 #include "rm_common.h"
@@ -39,8 +42,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifdef RM_NN6_STAMP
 __device__ unsigned long long rm_nn6_stamp_buf[4 * 4096];
 #endif
-constexpr int kRows6 = 256;     // batch rows per block
-constexpr int kThreads6 = 512;  // 8 waves, 2 per SIMD
+#ifndef RM_NN6_WAVES
+#define RM_NN6_WAVES 4
+#endif
+constexpr int kWaves6 = RM_NN6_WAVES;       // 4: one wave per SIMD and TWO blocks per CU (80 KB of LDS each)
+constexpr int kRows6 = 32 * kWaves6;        // batch rows per block
+constexpr int kThreads6 = 64 * kWaves6;
+constexpr int kRing6 = kWaves6 == 4 ? 2 : 3;  // LDS slab buffers
 constexpr int kSlabK = 32;      // k per slab = one 16x16x32 MFMA step
 constexpr int kMaxNT6 = 13;     // 16-column tiles per column group (N = 400 / 416: two groups of 13)
 
@@ -143,11 +151,17 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &h, bf16x8 &m
 }
 
 template <int NT>
-__global__ __launch_bounds__(kThreads6) void dense_nn6_kernel(NN6Args a) {
+__global__ __launch_bounds__(kThreads6, kWaves6 == 4 ? 2 : 1) void dense_nn6_kernel(NN6Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
-  constexpr int kPieces = (3 * NT + 7) / 8 * 8;  // 1 KiB pieces per slab, padded to 8 per DMA round
+  constexpr int kPieces = (3 * NT + 7) / 8 * 8;  // 1 KiB pieces per slab in GLOBAL memory, padded to 8 per DMA round
   constexpr int kSlabBytes = kPieces * 1024;
-  constexpr int kVmPerSlab = kPieces / 8 + 4;    // vector-memory operations a wave issues per slab
+  constexpr int kLdsSlab = 3 * NT * 1024;        // in LDS only the real pieces have a slot; the padding goes to a sink
+  constexpr int kSink = kRing6 * kLdsSlab;       // (2 x (2 x 39 + 1) KiB = 158 KiB: two blocks per CU)
+  constexpr int kDmaPerWave = kPieces / kWaves6;  // LDS-DMA pieces a wave issues per slab
+  constexpr int kAhead = kRing6 - 1;              // slabs the weights run ahead
+  // a slab ends when the NEXT slab's weights have landed: with a ring of 3 everything older than this slab's own
+  // requests, with a ring of 2 this slab's own LDS-DMA pieces too (only the 4 row loads behind them may remain)
+  constexpr int kVmPerSlab = kRing6 == 3 ? kDmaPerWave + 4 : 4;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = blockIdx.x % a.ngroups;
   const int64_t row0 = (int64_t)(blockIdx.x / a.ngroups) * kRows6 + 32 * w;
@@ -158,11 +172,14 @@ __global__ __launch_bounds__(kThreads6) void dense_nn6_kernel(NN6Args a) {
   // for every wave, no branch.  (The prepped weights carry two zero slabs behind the last: the loop never asks.)
   auto stage = [&](int s, int buf) {
     const unsigned char *src = Wg + (int64_t)s * kSlabBytes + lane * 16;
-    unsigned char *dst = smem6 + buf * kSlabBytes;
+    unsigned char *dst = smem6 + buf * kLdsSlab;
 #pragma unroll
-    for (int i = 0; i < kPieces / 8; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (8 * i + w) * 1024),
-                                       (__attribute__((address_space(3))) void *)(dst + (8 * i + w) * 1024), 16, 0, 0);
+    for (int i = 0; i < kDmaPerWave; ++i) {
+      const int piece = kWaves6 * i + w;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(src + piece * 1024),
+          (__attribute__((address_space(3))) void *)(piece < 3 * NT ? dst + piece * 1024 : smem6 + kSink), 16, 0, 0);
+    }
   };
   // slab s of this lane's two rows: out of A1 (whole slabs), the padded tail copy, or - past the end - the last
   // slab again (a wasted, in-range load: the loop body stays one basic block)
@@ -197,11 +214,13 @@ __global__ __launch_bounds__(kThreads6) void dense_nn6_kernel(NN6Args a) {
   load_slab(0, xp[0], xp[1]);
   stage(0, 0);
   load_slab(1, xq[0], xq[1]);
-  stage(1, 1);
+  if (kRing6 == 3) stage(1, 1);
   split8(xp[0], fr[0][0], fr[0][1], fr[0][2]);
   split8(xp[1], fr[0][3], fr[0][4], fr[0][5]);
   load_slab(2, xp[0], xp[1]);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kVmPerSlab) : "memory");  // weights of slab 0 landed (slab 1's, the rows of 2: later)
+  // weights of slab 0 landed (what was requested behind them may still be on its way)
+  if (kRing6 == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerWave + 4) : "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   // One slab s (CUR = its parity): MFMAs on the fragments split during the PREVIOUS slab, and between them - the
@@ -212,23 +231,19 @@ __global__ __launch_bounds__(kThreads6) void dense_nn6_kernel(NN6Args a) {
   // per slab.)
   auto slab = [&](int s, auto cur, float (&xn0)[8], float (&xn1)[8]) {
     constexpr int C = decltype(cur)::value, Nx = C ^ 1;
-    if (!(RM_NN6_ABL & 16)) stage(s + 2, (s + 2) % 3);
-    const unsigned char *ws = smem6 + (s % 3) * kSlabBytes + lane * 16;
+    if (!(RM_NN6_ABL & 16)) stage(s + kAhead, (s + kAhead) % kRing6);
+    const unsigned char *ws = smem6 + (s % kRing6) * kLdsSlab + lane * 16;
     if (!(RM_NN6_ABL & 4)) {
       split8(xn0, fr[Nx][0], fr[Nx][1], fr[Nx][2]);
       split8(xn1, fr[Nx][3], fr[Nx][4], fr[Nx][5]);
     }
     if (!(RM_NN6_ABL & 2)) load_slab(s + 3, xn0, xn1);
-    // the weight fragments of column tile j + 1 are read while tile j's MFMAs run
-    bf16x8 bw[2][3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) bw[0][p] = *reinterpret_cast<const bf16x8 *>(ws + (p * NT) * 1024);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int jn = (RM_NN6_ABL & 8) ? 0 : (j + 1 < NT ? j + 1 : j);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bw[(j + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(ws + (p * NT + jn) * 1024);
-      const bf16x8 bh = bw[j & 1][0], bm = bw[j & 1][1], bl = bw[j & 1][2];
+      const int jj = (RM_NN6_ABL & 8) ? 0 : j;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(ws + (0 * NT + jj) * 1024);
+      const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(ws + (1 * NT + jj) * 1024);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(ws + (2 * NT + jj) * 1024);
       // the small products first, the leading one last.  The WEIGHT fragment is the MFMA's A operand: the result
       // tile is D[m = column 4 q + i of the tile][n = batch row r] - a lane ends up with four CONSECUTIVE output
       // columns of one batch row (one 16-byte store, bias / aux as one 16-byte load).  The two row tiles'
@@ -419,10 +434,11 @@ extern "C" int rm_dense_fwd6(const float *A1, int64_t lda1, int K1, const float 
   if (ragged && !overlap)
     hipLaunchKernelGGL(dense6_tail_kernel, dim3(rm_grid_cap((M * kSlabK + 255) / 256, 256 * 8)), dim3(256), 0, st, A1,
                        lda1, K1, A2, lda2, K2, nfull * kSlabK, M, Atail);
+  // (starting the second resident of every CU 4 .. 30 us late changed nothing: 351 .. 367 us against 355)
   NN6Args a{A1, (ragged && !overlap) ? Atail : nullptr, lda1, nfull, overlap ? K - kSlabK : 0, dot_w,
             dot_part, Wp, N, nslab, ngroups, bias, epilogue, act, aux1, ld_aux1, M, C, ldc};
   const int64_t ntiles = (M + kRows6 - 1) / kRows6;
-  const size_t smem = 3 * ((3 * kMaxNT6 + 7) / 8 * 8) * 1024;
+  const size_t smem = (size_t)kRing6 * 3 * kMaxNT6 * 1024 + 1024;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_nn6_kernel<kMaxNT6>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL((dense_nn6_kernel<kMaxNT6>), dim3((unsigned)(ntiles * ngroups)), dim3(kThreads6), smem, st, a);
