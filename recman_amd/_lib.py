@@ -83,6 +83,7 @@ SIGNATURES = {
     "rm_dense_fwd6": [P, I64, c_int, P, I64, c_int, P, I64, c_int, c_int, P, c_int, c_int, P, I64, I64, P, I64,
                       P, P, P, P, P],
     "rm_dense_wgrad": [P, I64, c_int, P, I64, c_int, P, I64, c_int, I64, P, I64, c_int, P, P, I64, P],
+    "rm_dense_wgrad6": [P, I64, c_int, P, I64, c_int, P, I64, c_int, I64, P, I64, c_int, P, P, I64, P],
 }
 
 
@@ -96,6 +97,7 @@ SIGNATURES_I64 = {
     "rm_shard_route_workspace": [c_int],
     "rm_dense_filter_workspace": [c_int, c_int],
     "rm_dense6_workspace": [c_int, c_int, I64],
+    "rm_dense_wgrad6_workspace": [c_int, c_int, I64],
     "rm_dense_wgrad_workspace": [c_int, c_int, I64],
     "rm_sparse_optimizer_workspace": [I64],
 }

@@ -448,3 +448,279 @@ extern "C" int rm_dense_fwd6(const float *A1, int64_t lda1, int K1, const float 
   RM_CHECK_LAUNCH("rm_dense_fwd6");
   return RM_OK;
 }
+
+// ---- "TN": dW[K, N] (+)= [A1 | A2]^T . G, reduction over the batch, db[N] = column sums of G ------------------
+// Replaces the weight-gradient GEMM of DNN's backward (tf.gradients of layers.py:594-602) like rm_dense_wgrad's f32
+// path.  Both operands are activations: both are split on the fly.  An MFMA operand fragment here is 8 CONSECUTIVE
+// BATCH ROWS of one column - strided in the row-major activations - so a slab (32 batch rows) goes through LDS as
+// transposed bf16 planes [piece][column][32 batch]: a thread loads one column's 8 rows (8 dword loads, coalesced
+// across the wave's 64 columns), splits them and writes three 16-byte pieces; a fragment read is one ds_read_b128
+// (16 columns x 64 bytes: a linear KiB, conflict-free).  The split is done ONCE per block and slab and shared by its
+// 8 waves.  Block = 224 K-columns (14 tiles) x 208 N-columns (13 tiles) x a range of slabs; wave (wk, wn) owns 7
+// K-tiles x the N-tiles wn, wn + 4, wn + 8 (, 12): the four G fragment triples stay in registers, the A triples
+// stream.  G is the MFMA's A operand: a lane ends with 4 consecutive N of one K row (16-byte stores).  The blocks'
+// partial tiles go to the workspace, dense6_tn_reduce_kernel adds them in split order (deterministic).
+namespace {
+
+#ifndef RM_TN6_ABL
+#define RM_TN6_ABL 0  // ablation builds (WRONG results): 1 no MFMAs, 2 no loads in the loop, 4 no split / LDS writes
+#endif
+constexpr int kTnKT = 14, kTnNT = 13;
+constexpr int kTnKC = 16 * kTnKT, kTnNC = 16 * kTnNT;           // 224, 208
+constexpr int kTnUnits = 4 * (kTnKC + kTnNC);                   // (column, 8-row group) units per slab: 1728
+constexpr int kTnPerThread = (kTnUnits + 511) / 512;            // 4 (the last round only for 192 threads)
+constexpr int kTnPlaneA = kTnKC * 64, kTnPlaneG = kTnNC * 64;   // bytes of one bf16 plane
+constexpr int kTnLds = 3 * (kTnPlaneA + kTnPlaneG);             // 82,944
+
+struct TN6Args {
+  const float *A1, *A2, *G;
+  int64_t lda1, lda2, ldg;
+  int K1, K2, N;
+  int64_t M;
+  int nkh, nnh, nsplit;
+  int64_t slabs_per_split, nslab;
+  float *part;     // [nsplit][nkh][nnh][224][208]
+  float *db_part;  // [nsplit][nnh][208] or NULL
+};
+
+template <bool RAGGED>
+__global__ __launch_bounds__(512) void dense_tn6_kernel(TN6Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  int bid = blockIdx.x;
+  const int nh = bid % a.nnh; bid /= a.nnh;
+  const int kh = bid % a.nkh;
+  const int sp = bid / a.nkh;
+  const int K = a.K1 + a.K2;
+  const int kcol0 = kTnKC * kh, ncol0 = kTnNC * nh;
+
+  // this thread's units: (column, 8-row group) of the A half or the G half - the same ones in every slab
+  const float *uptr[kTnPerThread];
+  int64_t uld[kTnPerThread];
+  float ukeep[kTnPerThread];
+  int ulds[kTnPerThread], urow[kTnPerThread];
+  bool uisg[kTnPerThread];
+#pragma unroll
+  for (int i = 0; i < kTnPerThread; ++i) {
+    int u = tid + 512 * i;
+    u = u < kTnUnits ? u : kTnUnits - 1;  // (the spare threads of the last round repeat the last unit)
+    const bool isg = u >= 4 * kTnKC;
+    const int v = isg ? u - 4 * kTnKC : u;
+    const int cols = isg ? kTnNC : kTnKC;
+    const int col = v % cols, g = v / cols;
+    const int c = (isg ? ncol0 : kcol0) + col;
+    const float *p;
+    int64_t ld;
+    bool live;
+    if (isg) { live = c < a.N; p = a.G + (live ? c : 0); ld = a.ldg; }
+    else if (c < a.K1) { live = true; p = a.A1 + c; ld = a.lda1; }
+    else if (c < K) { live = true; p = a.A2 + (c - a.K1); ld = a.lda2; }
+    else { live = false; p = a.A1; ld = a.lda1; }
+    uptr[i] = p; uld[i] = ld; ukeep[i] = live ? 1.f : 0.f; urow[i] = 8 * g; uisg[i] = isg;
+    // a column's four 16-byte pieces (8-row groups) are rotated by col / 4: the 64 columns a wave writes in one
+    // instruction (same g) then spread over all 64 banks (unrotated: 16 banks, 4x the cycles); a fragment read
+    // still covers its 16 columns x 64 bytes as one contiguous KiB
+    ulds[i] = (isg ? 3 * kTnPlaneA : 0) + col * 64 + ((g + (col >> 2)) & 3) * 16;
+  }
+  auto load_units = [&](int64_t slab, float (&x)[kTnPerThread][8]) {
+    const int64_t b0 = slab * 32;
+#pragma unroll
+    for (int i = 0; i < kTnPerThread; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t row = b0 + urow[i] + e;
+        x[i][e] = uptr[i][(RAGGED && row >= a.M ? a.M - 1 : row) * uld[i]];
+      }
+  };
+
+  // wave (wk, wn): K-tiles 7 wk .. 7 wk + 6 x N-tiles wn, wn + 4, wn + 8; the 13th N-tile's 14 tiles are dealt out:
+  // K-tile 7 wk + t goes to the wave with wn == t % 4 (23 / 23 / 23 / 22 tiles per wave; wn + 12 for wn = 0 only
+  // was 28 / 21 / 21 / 21 - the SIMD with the two big waves set the pace of every slab)
+  const int wk = w >> 2, wn = w & 3;
+  f32x4 acc[7][3], acx[2];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acx[0] = acx[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbacc[kTnPerThread] = {0.f, 0.f, 0.f, 0.f};
+  auto frag = [&](int base, int plane, int p, int tile) {
+    const int col = 16 * tile + r;
+    return *reinterpret_cast<const bf16x8 *>(smem6 + base + p * plane + col * 64 + ((q + (col >> 2)) & 3) * 16);
+  };
+  auto mma6 = [&](f32x4 c, const bf16x8 (&gq)[3], const bf16x8 (&aq)[3]) {
+    if (RM_TN6_ABL & 1) {
+      c[0] += (float)gq[0][0] + (float)gq[1][1] + (float)gq[2][2] + (float)aq[0][3] + (float)aq[1][4] + (float)aq[2][5];
+      return c;
+    }
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq[0], aq[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq[2], aq[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq[1], aq[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq[0], aq[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq[1], aq[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq[0], aq[0], c, 0, 0, 0);
+    return c;
+  };
+
+  const int64_t s0 = (int64_t)sp * a.slabs_per_split;
+  const int64_t s1 = s0 + a.slabs_per_split < a.nslab ? s0 + a.slabs_per_split : a.nslab;
+  float x[kTnPerThread][8];
+  if (s0 < s1) load_units(s0, x);
+  for (int64_t s = s0; s < s1; ++s) {
+    // split this slab's values (loaded during the previous slab's MFMAs) into the LDS planes
+    const int64_t b0 = s * 32;
+    __builtin_amdgcn_s_barrier();  // (every wave is done reading the previous slab's planes)
+#pragma unroll
+    for (int i = 0; i < kTnPerThread; ++i) {
+      if ((RM_TN6_ABL & 4) && s != s0) continue;
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (!RAGGED || b0 + urow[i] + e < a.M) ? x[i][e] * ukeep[i] : 0.f;
+      if (uisg[i] && a.db_part != nullptr && (i < kTnPerThread - 1 || tid + 512 * i < kTnUnits))
+        dbacc[i] += ((y[0] + y[1]) + (y[2] + y[3])) + ((y[4] + y[5]) + (y[6] + y[7]));
+      bf16x8 h, m, l;
+      split8(y, h, m, l);
+      unsigned char *d = smem6 + ulds[i];
+      const int plane = uisg[i] ? kTnPlaneG : kTnPlaneA;
+      *reinterpret_cast<bf16x8 *>(d) = h;
+      *reinterpret_cast<bf16x8 *>(d + plane) = m;
+      *reinterpret_cast<bf16x8 *>(d + 2 * plane) = l;
+    }
+    // the next slab's values, on their way during the MFMAs below (unconditional - the last slab is requested
+    // again - so that the loads stay in this basic block: hipcc sinks a load under an `if` to its use)
+    if (!(RM_TN6_ABL & 2)) load_units(s + 1 < s1 ? s + 1 : s, x);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // G fragment triples of this wave's N-tiles (and of the shared 13th)
+    bf16x8 gf[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) gf[j][p] = frag(3 * kTnPlaneA, kTnPlaneG, p, j < 3 ? wn + 4 * j : 12);
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      bf16x8 af[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[p] = frag(0, kTnPlaneA, p, 7 * wk + t);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[t][j] = mma6(acc[t][j], gf[j], af);
+      if ((t & 3) == wn) acx[t >> 2] = mma6(acx[t >> 2], gf[3], af);  // (wave-uniform)
+    }
+  }
+
+  // the block's partial tile: lane (r, q) holds N-columns 4 q .. 4 q + 3 of K-row r of every tile
+  float *pt = a.part + (((int64_t)sp * a.nkh + kh) * a.nnh + nh) * (int64_t)(kTnKC * kTnNC);
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int kt = 7 * wk + t;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      *reinterpret_cast<f32x4 *>(pt + (16 * kt + r) * kTnNC + 16 * (wn + 4 * j) + 4 * q) = acc[t][j];
+    if ((t & 3) == wn) *reinterpret_cast<f32x4 *>(pt + (16 * kt + r) * kTnNC + 16 * 12 + 4 * q) = acx[t >> 2];
+  }
+  if (a.db_part != nullptr && kh == 0) {
+    // column sums of G: the four 8-row groups of a column sit in four threads' accumulators -> through LDS
+    __builtin_amdgcn_s_barrier();
+    float *red = reinterpret_cast<float *>(smem6);  // [4][208]
+#pragma unroll
+    for (int i = 0; i < kTnPerThread; ++i) {
+      const int u = tid + 512 * i;
+      if (u >= 4 * kTnKC && u < kTnUnits) red[u - 4 * kTnKC] = dbacc[i];  // index = g * 208 + col
+    }
+    __syncthreads();
+    if (tid < kTnNC)
+      a.db_part[((int64_t)sp * a.nnh + nh) * kTnNC + tid] =
+          (red[tid] + red[kTnNC + tid]) + (red[2 * kTnNC + tid] + red[3 * kTnNC + tid]);
+  }
+}
+
+// dW[k][n] (+)= sum over the splits (in order) of the partial tiles; db[n] likewise
+__global__ void dense6_tn_reduce_kernel(const float *__restrict__ part, const float *__restrict__ db_part, int K,
+                                        int N, int nkh, int nnh, int nsplit, float *__restrict__ dW, int64_t lddw,
+                                        int accumulate, float *__restrict__ db) {
+  const int64_t total = (int64_t)K * N;
+  const int64_t tile = (int64_t)kTnKC * kTnNC;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total + N;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    if (t < total) {
+      const int k = (int)(t / N), n = (int)(t % N);
+      const int kh = k / kTnKC, nh = n / kTnNC;
+      const float *p = part + ((int64_t)kh * nnh + nh) * tile + (int64_t)(k % kTnKC) * kTnNC + n % kTnNC;
+      float v = 0.f;
+      for (int s = 0; s < nsplit; ++s) v += p[(int64_t)s * nkh * nnh * tile];
+      float *d = dW + (int64_t)k * lddw + n;
+      *d = accumulate ? *d + v : v;
+    } else if (db != nullptr) {
+      const int n = (int)(t - total);
+      const float *p = db_part + (int64_t)(n / kTnNC) * kTnNC + n % kTnNC;
+      float v = 0.f;
+      for (int s = 0; s < nsplit; ++s) v += p[(int64_t)s * nnh * kTnNC];
+      db[n] = v;
+    }
+  }
+}
+
+struct Tn6Plan {
+  int nkh, nnh, nsplit;
+  int64_t nslab, per;
+};
+Tn6Plan tn6_plan(int K, int N, int64_t M) {
+  Tn6Plan p;
+  p.nkh = (K + kTnKC - 1) / kTnKC;
+  p.nnh = (N + kTnNC - 1) / kTnNC;
+  p.nslab = (M + 31) / 32;
+  int64_t want = 256 / (p.nkh * p.nnh);  // one block per CU: every split costs a partial tile written and read again
+  if (want < 1) want = 1;
+  if (want > p.nslab) want = p.nslab > 0 ? p.nslab : 1;
+  p.per = (p.nslab + want - 1) / want;
+  if (p.per < 1) p.per = 1;
+  p.nsplit = (int)((p.nslab + p.per - 1) / p.per);
+  if (p.nsplit < 1) p.nsplit = 1;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int64_t rm_dense_wgrad6_workspace(int K, int N, int64_t M) {
+  if (K <= 0 || N <= 0 || M <= 0) return 0;
+  const Tn6Plan p = tn6_plan(K, N, M);
+  return (int64_t)p.nsplit * p.nkh * p.nnh * kTnKC * kTnNC + (int64_t)p.nsplit * p.nnh * kTnNC + 64;
+}
+
+extern "C" int rm_dense_wgrad6(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2,
+                               const float *G, int64_t ldg, int N, int64_t M, float *dW, int64_t lddw,
+                               int accumulate, float *db, float *workspace, int64_t workspace_floats,
+                               rm_stream_t stream) {
+  RM_REQUIRE(M >= 0 && K1 > 0 && K2 >= 0 && N > 0, "rm_dense_wgrad6: bad sizes");
+  RM_REQUIRE(A1 && G && dW && workspace && rm_aligned16(workspace), "rm_dense_wgrad6: NULL / unaligned argument");
+  RM_REQUIRE(K2 == 0 || A2, "rm_dense_wgrad6: K2 > 0 needs A2");
+  RM_REQUIRE(lda1 >= K1 && (K2 == 0 || lda2 >= K2) && ldg >= N && lddw >= N,
+             "rm_dense_wgrad6: a leading dimension is too small");
+  const int K = K1 + K2;
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    if (!accumulate) (void)hipMemset2DAsync(dW, lddw * 4, 0, (size_t)N * 4, K, st);
+    if (db) (void)hipMemsetAsync(db, 0, (size_t)N * 4, st);
+    return RM_OK;
+  }
+  RM_REQUIRE(workspace_floats >= rm_dense_wgrad6_workspace(K, N, M), "rm_dense_wgrad6: workspace too small");
+  const Tn6Plan p = tn6_plan(K, N, M);
+  float *part = workspace;
+  float *db_part = db ? workspace + (int64_t)p.nsplit * p.nkh * p.nnh * kTnKC * kTnNC : nullptr;
+  TN6Args a{A1, A2, G, lda1, lda2, ldg, K1, K2, N, M, p.nkh, p.nnh, p.nsplit, p.per, p.nslab, part, db_part};
+  const dim3 grid((unsigned)(p.nsplit * p.nkh * p.nnh));
+  if (M % 32 != 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_tn6_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kTnLds);
+    hipLaunchKernelGGL(dense_tn6_kernel<true>, grid, dim3(512), kTnLds, st, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_tn6_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kTnLds);
+    hipLaunchKernelGGL(dense_tn6_kernel<false>, grid, dim3(512), kTnLds, st, a);
+  }
+  hipLaunchKernelGGL(dense6_tn_reduce_kernel, dim3(rm_grid_cap(((int64_t)K * N + N + 255) / 256, 2048)), dim3(256), 0,
+                     st, part, db_part, K, N, p.nkh, p.nnh, p.nsplit, dW, lddw, accumulate, db);
+  RM_CHECK_LAUNCH("rm_dense_wgrad6");
+  return RM_OK;
+}

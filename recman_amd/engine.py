@@ -231,10 +231,12 @@ class MLP:
         self._fws = torch.empty(fw, dtype=F32, device=device)
         # wide layers on the bf16 matrix pipe with split fp32 operands (rm_dense_fwd6, csrc/gemm6.hip) unless
         # dense_gemm = "f32" asks for the f32 MFMA kernel
-        self._fws6 = None
+        self._fws6 = self._wws6 = None
         if getattr(self, "dense_gemm", "bf16x6") == "bf16x6":
             kmax = max(dims)
             self._fws6 = torch.empty(ops.dense6_workspace(kmax, kmax, self._B), dtype=F32, device=device)
+            self._wws6 = torch.empty(max(ops.dense_wgrad6_workspace(dims[i], dims[i + 1], self._B)
+                                         for i in range(len(self.hidden))), dtype=F32, device=device)
         self._wws = torch.empty(max(ww, 1), dtype=F32, device=device)
         self._wws_B = self._B
         self._ws = torch.empty(256 * 1024, dtype=F32, device=device)
@@ -300,7 +302,7 @@ class MLP:
             # it rides along in the weight-gradient kernel (which stages da in LDS anyway)
             db = None if (sums and i == n - 1) else gr[f"{pre}dnn_layer_{i}_bias"]
             if i == 0:
-                ops.dense_wgrad(self.xe, self.xd if self.Dn else None, da, gW, self._wws, db=db)
+                ops.dense_wgrad(self.xe, self.xd if self.Dn else None, da, gW, self._wws, db=db, ws6=self._wws6)
                 # dLoss/dxe = da W[:FD]^T (the dense inputs need no gradient)
                 ops.dense_fwd(da, None, W[: self.FD], dxe, self._fws, transposed=True, epilogue=ops.DENSE_ADD,
                               ws6=self._fws6)
@@ -308,7 +310,7 @@ class MLP:
                     dxe.mul_(self.masks[0][:, : self.FD] / self.keep[0])
             else:
                 prev = self.a[i - 1]
-                ops.dense_wgrad(prev, None, da, gW, self._wws, db=db)
+                ops.dense_wgrad(prev, None, da, gW, self._wws, db=db, ws6=self._wws6)
                 dropped = self.keep[i] < 1 and self.masks[i] is not None
                 # d(pre-activation of layer i-1) = (da W^T) o mask o act'(prev), act' from the stored
                 # post-activation values (dropped positions are zeroed by the mask)

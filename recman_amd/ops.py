@@ -757,8 +757,14 @@ def dense_fwd(a1, a2, W, out, filter_ws, *, transposed=False, bias=None, epilogu
               M, pc, ldc, pc2, ldc2, _chk(filter_ws, "filter_ws", F32), _stream())
 
 
-def dense_wgrad(a1, a2, G, dW, ws, accumulate=False, db=None):
-    """dW[K,N] (+)= [a1 | a2].T @ G (rm_dense_wgrad); db [N] = G.sum(0) when given."""
+def dense_wgrad6_workspace(K, N, M):
+    """Floats of workspace for the bf16x6 form of dense_wgrad (rm_dense_wgrad6_workspace)."""
+    return int(_lib.lib().rm_dense_wgrad6_workspace(int(K), int(N), int(M)))
+
+
+def dense_wgrad(a1, a2, G, dW, ws, accumulate=False, db=None, ws6=None):
+    """dW[K,N] (+)= [a1 | a2].T @ G (rm_dense_wgrad); db [N] = G.sum(0) when given.  ws6 (dense_wgrad6_workspace
+    floats): on the bf16 matrix pipe with split operands (rm_dense_wgrad6)."""
     p1, lda1, K1 = _rows2d(a1, "a1")
     p2, lda2, K2 = _rows2d(a2, "a2", allow_none=True)
     pg, ldg, N = _rows2d(G, "G")
@@ -768,5 +774,9 @@ def dense_wgrad(a1, a2, G, dW, ws, accumulate=False, db=None):
     pd, lddw, nd = _rows2d(dW, "dW")
     if dW.shape[0] != K1 + K2 or nd != N:
         raise ValueError(f"dW {tuple(dW.shape)} must be [{K1 + K2},{N}]")
+    if ws6 is not None:
+        _lib.call("rm_dense_wgrad6", p1, lda1, K1, p2, lda2, K2, pg, ldg, N, M, pd, lddw, int(bool(accumulate)),
+                  _chk(db, "db", F32, (N,), allow_none=True), _chk(ws6, "ws6", F32), ws6.numel(), _stream())
+        return
     _lib.call("rm_dense_wgrad", p1, lda1, K1, p2, lda2, K2, pg, ldg, N, M, pd, lddw, int(bool(accumulate)),
               _chk(db, "db", F32, (N,), allow_none=True), _chk(ws, "ws", F32), ws.numel(), _stream())

@@ -284,3 +284,36 @@ def test_dense_fwd6_declines_what_it_does_not_cover_and_keeps_large_and_tiny_val
     # per element against the sum of |products| (the honest scale of a dot product's rounding error)
     scale = (x.double().abs() @ W.double().abs())
     assert float(((out.cpu().double() - want).abs() / scale).max()) < 2e-6
+
+
+@pytest.mark.parametrize("M,K1,K2,N", SHAPES + [(5000, 416, 13, 400), (3, 8, 0, 8), (4096, 400, 0, 400),
+                                               (777, 230, 0, 210)])
+def test_dense_wgrad6_split_operands(hip_lib, M, K1, K2, N):
+    """rm_dense_wgrad6 (both activations split into bf16 pieces, transposed LDS planes) against float64: dW, the
+    accumulate form, the bias gradient; ragged batch (M % 32 != 0), K and N beyond one block tile (224 x 208);
+    two runs are bit-identical (partial tiles added in split order)."""
+    from recman_amd import ops
+
+    a1, a2, _, _ = _inputs(M, K1, K2, N, seed=2)
+    g = torch.Generator().manual_seed(9)
+    G = torch.randn(M, N, generator=g)
+    x = torch.cat([a1] + ([a2] if a2 is not None else []), dim=1).double()
+    want = x.t() @ G.double()
+    a1d, a2d = _dev_padded(a1), (a2.cuda() if a2 is not None else None)
+    K = K1 + K2
+    ws = torch.empty(ops.dense_wgrad_workspace(K, N, M), device="cuda")
+    ws6 = torch.empty(ops.dense_wgrad6_workspace(K, N, M), device="cuda")
+    dW = torch.full((K, N), float("nan"), device="cuda")
+    db = torch.full((N,), float("nan"), device="cuda")
+    ops.dense_wgrad(a1d, a2d, G.cuda(), dW, ws, db=db, ws6=ws6)
+    tol = 2e-5 * max(1.0, (M / 1000) ** 0.5)   # (fp32 sums over the batch: as the f32 kernel's test)
+    _close(dW, want, tol=tol, what="dW")
+    _close(db, G.double().sum(0), tol=tol, what="db")
+    again = torch.empty_like(dW)
+    ops.dense_wgrad(a1d, a2d, G.cuda(), again, ws, ws6=ws6)
+    assert torch.equal(again, dW)
+    base = torch.randn(K, N + 3, generator=g).cuda()
+    acc = base.clone()
+    ops.dense_wgrad(a1d, a2d, G.cuda(), acc[:, :N], ws, accumulate=True, ws6=ws6)
+    _close(acc[:, :N], want + base[:, :N].cpu().double(), tol=tol, what="accumulate")
+    assert torch.equal(acc[:, N:], base[:, N:])
