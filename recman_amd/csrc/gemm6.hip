@@ -1,5 +1,7 @@
-// Wide dense layers, "NN" GEMM C[M,N] = epilogue([A1 | A2][M,K] . op(W)), with fp32 operands SPLIT into three
-// bf16 pieces each and the products formed on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
+// Wide dense layers with fp32 operands SPLIT into three bf16 pieces each and the products formed on the bf16
+// matrix pipe (v_mfma_f32_16x16x32_bf16), fp32 accumulate: the "NN" GEMM C[M,N] = epilogue([A1 | A2][M,K] . op(W))
+// (rm_dense_fwd6, first half of this file) and the "TN" weight gradient dW[K,N] = [A1 | A2]^T . G (rm_dense_wgrad6,
+// second half).
 //
 //   x = h + m + l,  h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)   (8 + 8 + 8 = the 24 significant bits)
 //   x y ~= hx hy + hx my + mx hy + mx my + hx ly + lx hy               (dropped: m l, l m, l l <= 3 * 2^-24 |x y|)
@@ -19,7 +21,8 @@
 // and epilogue (8 waves in ONE block ran every phase at the same time on both waves of a SIMD).  Wave w owns rows
 // [32 w, 32 w + 32) (two 16-row MFMA tiles) and all NT column tiles: 2 x NT x 4 accumulator registers.
 //   A   never touches LDS: a lane's operand fragment is 8 consecutive k of one row = 32 contiguous bytes of the
-//       row-major activations, loaded straight from global memory one k-slab (32 k) ahead and split in registers.
+//       row-major activations, loaded straight from global memory three k-slabs (of 32 k) ahead and split in
+//       registers between the MFMAs of the slab before its use.
 //   W   is split and laid out in fragment order once per call by dense6_prep_kernel (bf16 [group][slab][piece]
 //       [tile][lane][8]); a block copies its group's 3 x NT KiB per slab into LDS with LDS-DMA (a linear image:
 //       lane l of a fragment read takes bytes 16 l .. 16 l + 15, conflict-free), double-buffered, one barrier
@@ -35,7 +38,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ablation builds (WRONG results; tools/probe/nn6_time.py): 1 no epilogue stores, 2 no A loads in the loop,
-// 4 no splitting in the loop, 8 one B fragment triple per slab, 16 no staging in the loop, 32 no MFMAs
+// 4 no splitting in the loop, 8 one B fragment triple per slab, 16 no staging in the loop, 32 no MFMAs,
+// 64 no sched_group_barrier pipeline
 #ifndef RM_NN6_ABL
 #define RM_NN6_ABL 0
 #endif
