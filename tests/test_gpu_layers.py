@@ -78,7 +78,7 @@ def test_xdeepfm_out_composed_from_layers(hip_lib):
     assert {"C0_feat_embed", "linear_w", "linear_w0", "dnn_layer_0_weights", "dnn_layer_1_bias", "dnn_w", "dnn_w0",
             "cin_filter_0", "cin_bias_1", "cin_w", "cin_w0"} <= set(variables)
     assert not any(k.endswith("_feat_bias") for k in variables)   # use_bias=False (xDeepFM.py:54)
-    assert float(variables["linear_w"].abs().max()) == 0.0 and float(variables["cin_w"].abs().max()) > 0
+    assert float(variables["linear_w"].detach().abs().max()) == 0.0 and float(variables["cin_w"].detach().abs().max()) > 0
     _load(variables, p)
     pred, logit, layers = out()
     loss = L.create_loss(inp.y, pred) + sum(layer.l2() for layer in layers)   # xDeepFM._loss
