@@ -350,6 +350,15 @@ int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bstride, const
                      const float *bias, int act, int64_t B, int m, int H, int N, int D,
                      float *out, float *pooled, int pool_stride, int pool_col0, int pool_from,
                      float *filter_ws, rm_stream_t stream);
+/* rm_cin_layer_fwd6: the same layer on the bf16 matrix pipe with split fp32 operands (csrc/cin6.hip; the scheme of
+ * rm_dense_fwd6): Z = fl(X0 * Xk) is formed in fp32 as the reference does, then split into three bf16 pieces; six
+ * exact piece products per k-step, fp32 accumulate - fp32-level error.  Covers H % 32 == 0, H <= 64, N <= 128, D in
+ * {16, 32, 64}, Xk != X0 (the layers behind the first); RM_EUNSUPPORTED otherwise (run rm_cin_layer_fwd).
+ * filter_ws: rm_cin_filter_workspace6(m, H, N, D) floats (0 = not covered), 16-byte aligned. */
+int64_t rm_cin_filter_workspace6(int m, int H, int N, int D);
+int rm_cin_layer_fwd6(const float *X0, const float *Xk, int64_t xk_bstride, const float *W, const float *bias,
+                      int act, int64_t B, int m, int H, int N, int D, float *out, float *pooled, int pool_stride,
+                      int pool_col0, int pool_from, float *filter_ws, rm_stream_t stream);
 
 /* Backward of one CIN layer (three MFMA passes over the same GEMM shape).
  *   out [B,N,D]: the layer's post-activation map (act' is read off its sign);

@@ -61,6 +61,8 @@ SIGNATURES = {
     "rm_cross_param_grads": [P, P, P, P, P, c_int, c_int, P, P, P, P],
     "rm_cin_layer_fwd": [P, P, I64, P, P, c_int, I64, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                          c_int, P, P],
+    "rm_cin_layer_fwd6": [P, P, I64, P, P, c_int, I64, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
+                         c_int, P, P],
     "rm_cin_layer_bwd": [P, P, I64, c_int, P, c_int, P, P, I64, P, P, c_int, I64, c_int, c_int, c_int,
                          c_int, P, c_int, P, I64, P, P, P, I64, P],
     "rm_pool_rows": [P, I64, c_int, c_int, P, P, P, I64, P, P],
@@ -90,6 +92,7 @@ SIGNATURES = {
 # int64-returning size queries
 SIGNATURES_I64 = {
     "rm_cin_filter_workspace": [c_int, c_int, c_int],
+    "rm_cin_filter_workspace6": [c_int, c_int, c_int, c_int],
     "rm_cin_bwd_workspace": [I64, c_int, c_int, c_int, c_int],
     "rm_mlp_bwd_workspace": [c_int, c_int],
     "rm_deepfm_step_workspace": [c_int, c_int],

@@ -1,0 +1,301 @@
+// CIN layer forward (xDeepFM) on the bf16 matrix pipe with split fp32 operands - the scheme of gemm6.hip applied to
+//   Z[b,d,i*H+j] = X0[b,i,d] * Xk[b,j,d];  M = Z @ W + bias;  out = act(M) laid out [B,N,D]
+// (CIN.__call__, recman/tf/core/layers.py:714-752; csrc/cin.hip is the f32-MFMA form and documents the GEMM view:
+// rows p = (b, d), K = m*H, N filters).  Z is formed in registers as the fp32 product the reference forms
+// (fl(x0 * xk)), THEN split into three bf16 pieces; the filter is split and laid out in fragment order once per
+// call; six exact piece products per k-step, fp32 accumulate: fp32-level error (tests/test_gpu_cin.py).
+//
+// Covered: the layers whose k' chunks of 32 share one i - H % 32 == 0, H <= 64 (every layer behind the first
+// with the usual unit counts: configs[2] / configs[4] layer 1 has H = 64), N <= 128, D in {16, 32, 64}; anything
+// else returns RM_EUNSUPPORTED and the caller runs rm_cin_layer_fwd.
+//
+// Block = 4 waves = 128 rows (128 / D whole examples), two blocks per CU (61 KB of LDS each).  Wave w owns rows
+// 32 w .. 32 w + 31 (two 16-row MFMA tiles) x all N / 16 column tiles.  A lane's operand fragment is (row r,
+// k = 8 q + e): j = 32 jh + 8 q + e for the slab's (i, jh) - the 8 (16 for H = 64) Xk values a lane EVER needs sit in
+// its registers for the whole block; X0's 128 x m tile sits in LDS (one value per row tile and slab).  The filter
+// streams by LDS-DMA into two slab buffers, one raw barrier per slab; the next slab's products and split run between
+// this slab's MFMAs.  Z is the MFMA's A operand: a lane ends with 4 consecutive d of one filter n - with D = 16 a
+// 16 x 16 tile is ONE contiguous KiB of out[b, 16 j .. 16 j + 15, :].
+#include <type_traits>
+
+#include "rm_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kRowsC6 = 128;   // rows (b, d) per block
+constexpr int kNTC6 = 8;       // 16-filter tiles (N <= 128)
+constexpr int kSlabC6 = 3 * kNTC6 * 1024;  // bytes of a filter slab: [piece][tile][lane][8] bf16
+
+__device__ __forceinline__ float actc6(float v, int act) {
+  if (act == RM_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == RM_ACT_LEAKY_RELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+
+// Wp[s][p][j][lane][e] = piece p of W[k' = 32 s + 8 (lane >> 4) + e][n = 16 j + (lane & 15)]; two spare slabs behind
+// the last (the loop requests them and never reads them)
+__global__ void cin6_prep_kernel(const float *__restrict__ W, int K, int N, int nslab, __bf16 *__restrict__ Wp) {
+  const int64_t total = (int64_t)(nslab + 2) * kNTC6 * 512;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = t & 7, lane = (t >> 3) & 63;
+    const int64_t u = t >> 9;
+    const int j = (int)(u % kNTC6), s = (int)(u / kNTC6);
+    const int k = 32 * s + 8 * (lane >> 4) + e, n = 16 * j + (lane & 15);
+    float x = 0.f;
+    if (s < nslab && k < K && n < N) x = W[(int64_t)k * N + n];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    const int64_t base = (int64_t)s * (kSlabC6 / 2) + (int64_t)j * 512 + lane * 8 + e;
+    Wp[base] = h;
+    Wp[base + kNTC6 * 512] = m;
+    Wp[base + 2 * kNTC6 * 512] = l;
+  }
+}
+
+__device__ __forceinline__ void split8c(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hh = (__bf16)x[e];
+    const float r1 = x[e] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const __bf16 ll = (__bf16)(r1 - (float)mm);
+    h[e] = hh; m[e] = mm; l[e] = ll;
+  }
+}
+
+struct Cin6Args {
+  const float *X0, *Xk;
+  int64_t xk_bstride;
+  const __bf16 *Wp;
+  const float *bias;
+  int act;
+  int64_t B;
+  int m, H, N, D;
+  float *out, *pooled;
+  int pool_stride, pool_col0, pool_from;
+};
+
+template <int NH>  // H / 32
+__global__ __launch_bounds__(256, 2) void cin_fwd6_kernel(Cin6Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemc6[];
+  // [2][kSlabC6] filter slabs | X0s [m][128] floats
+  float *X0s = reinterpret_cast<float *>(smemc6 + 2 * kSlabC6);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int D = a.D, m = a.m;
+  const int epb = kRowsC6 / D;
+  const int64_t b0 = (int64_t)blockIdx.x * epb;
+  const int nslab = m * NH;
+
+  auto stage = [&](int s, int buf) {
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.Wp) + (int64_t)s * kSlabC6 + lane * 16;
+    unsigned char *dst = smemc6 + buf * kSlabC6;
+#pragma unroll
+    for (int i = 0; i < 3 * kNTC6 / 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (4 * i + w) * 1024),
+                                       (__attribute__((address_space(3))) void *)(dst + (4 * i + w) * 1024), 16, 0, 0);
+  };
+  stage(0, 0);
+
+  // X0 tile -> LDS [i][row] (row = local (b, d)): float4 along d
+  {
+    const int D4 = D >> 2, total = epb * m * D4;
+    for (int t = tid; t < total; t += 256) {
+      const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+      const int64_t b = b0 + bl;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < a.B) v = *reinterpret_cast<const float4 *>(a.X0 + (b * m + i) * D + 4 * d4);
+      *reinterpret_cast<float4 *>(X0s + i * kRowsC6 + bl * D + 4 * d4) = v;
+    }
+  }
+  // this lane's rows (two tiles) and ALL the Xk values it will ever multiply: j = 32 jh + 8 q + e
+  float xk[2][NH][8];
+  int prow[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int p = 32 * w + 16 * t + r;
+    prow[t] = p;
+    const int bl = p / D, d = p - bl * D;
+    const int64_t b = b0 + bl < a.B ? b0 + bl : a.B - 1;  // (rows past B: computed, never stored)
+    const float *src = a.Xk + b * a.xk_bstride + d;
+#pragma unroll
+    for (int jh = 0; jh < NH; ++jh)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xk[t][jh][e] = src[(int64_t)(32 * jh + 8 * q + e) * D];
+  }
+
+  f32x4 acc[2][kNTC6];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < kNTC6; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // X0s and filter slab 0 in place
+
+  // fragments of slab s: z = fl(x0[i] * xk[j]) split into three pieces
+  bf16x8 fr[2][6];
+  auto make_frags = [&](int s, bf16x8 (&f)[6]) {
+    const int sc = s < nslab ? s : nslab - 1;
+    const int i = sc / NH, jh = sc - i * NH;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float x0v = X0s[i * kRowsC6 + prow[t]];
+      float z[8];
+      if (NH == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = x0v * xk[t][0][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = x0v * (jh ? xk[t][NH - 1][e] : xk[t][0][e]);
+      }
+      split8c(z, f[3 * t], f[3 * t + 1], f[3 * t + 2]);
+    }
+  };
+  make_frags(0, fr[0]);
+
+  auto slab = [&](int s, auto cur) {
+    constexpr int C = decltype(cur)::value, Nx = C ^ 1;
+    stage(s + 1, (s + 1) & 1);   // (buffer read during slab s - 1: every wave is past that slab's barrier)
+    make_frags(s + 1, fr[Nx]);
+    const unsigned char *ws = smemc6 + (s & 1) * kSlabC6 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < kNTC6; ++j) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(ws + (0 * kNTC6 + j) * 1024);
+      const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(ws + (1 * kNTC6 + j) * 1024);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(ws + (2 * kNTC6 + j) * 1024);
+      const bf16x8 ah0 = fr[C][0], am0 = fr[C][1], al0 = fr[C][2], ah1 = fr[C][3], am1 = fr[C][4], al1 = fr[C][5];
+      f32x4 c0 = acc[0][j], c1 = acc[1][j];
+      // Z is the A operand: D[m = row 4 q + i][n = filter r]; the small products first
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, bh, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, bh, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bl, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bl, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am0, bm, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am1, bm, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am0, bh, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am1, bh, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bm, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bm, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bh, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bh, c1, 0, 0, 0);
+      acc[0][j] = c0;
+      acc[1][j] = c1;
+    }
+    // one split instruction per MFMA gap, the tile's three fragment reads behind its twelve MFMAs (gemm6.hip)
+#pragma unroll
+    for (int j = 0; j < kNTC6; ++j) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the next slab's filter pieces have landed
+    __builtin_amdgcn_s_barrier();
+  };
+  int s = 0;
+  for (; s + 1 < nslab; s += 2) {
+    slab(s, std::integral_constant<int, 0>{});
+    slab(s + 1, std::integral_constant<int, 1>{});
+  }
+  if (s < nslab) slab(s, std::integral_constant<int, 0>{});
+
+  // ---- epilogue: bias + activation, [B, N, D] store, pooled sums ----
+  // lane (r, q) holds rows 16 t + 4 q .. + 3 (consecutive d of one example) of filter 16 j + r
+  float *pool_s = reinterpret_cast<float *>(smemc6);  // [8 row tiles][128] per-tile sums over their 16 d
+  const bool want_pool = a.pooled != nullptr;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int p = 32 * w + 16 * t + 4 * q;
+    const int bl = p / D, d = p - bl * D;
+    const int64_t b = b0 + bl;
+#pragma unroll
+    for (int j = 0; j < kNTC6; ++j) {
+      const int n = 16 * j + r;
+      const float bn = n < a.N ? a.bias[n] : 0.f;
+      float4 v;
+      v.x = actc6(acc[t][j][0] + bn, a.act);
+      v.y = actc6(acc[t][j][1] + bn, a.act);
+      v.z = actc6(acc[t][j][2] + bn, a.act);
+      v.w = actc6(acc[t][j][3] + bn, a.act);
+      if (b < a.B && n < a.N) *reinterpret_cast<float4 *>(a.out + (b * a.N + n) * D + d) = v;
+      if (want_pool) {
+        // sum over the tile's 16 rows: 4 here, the other 12 in the lanes 16 and 32 away - a fixed order
+        float sd = (v.x + v.y) + (v.z + v.w);
+        sd += __shfl_xor(sd, 16, 64);
+        sd += __shfl_xor(sd, 32, 64);
+        if (q == 0) pool_s[(2 * w + t) * 128 + n] = sd;
+      }
+    }
+  }
+  if (want_pool) {
+    __syncthreads();
+    const int ncols = a.N - a.pool_from, tiles = D >> 4;
+    for (int t = tid; t < epb * ncols; t += 256) {
+      const int bl = t / ncols, cidx = t - bl * ncols;
+      const int64_t b = b0 + bl;
+      if (b < a.B) {
+        float sum = pool_s[(bl * tiles) * 128 + a.pool_from + cidx];
+        for (int u = 1; u < tiles; ++u) sum += pool_s[(bl * tiles + u) * 128 + a.pool_from + cidx];
+        a.pooled[b * a.pool_stride + a.pool_col0 + cidx] = sum;
+      }
+    }
+  }
+}
+
+bool cin6_covers(int m, int H, int N, int D) {
+  return H % 32 == 0 && H <= 64 && N <= 128 && (D == 16 || D == 32 || D == 64) && m >= 1 && m <= 64;
+}
+
+}  // namespace
+
+// floats of filter workspace for rm_cin_layer_fwd6 (0: the shape is not covered)
+extern "C" int64_t rm_cin_filter_workspace6(int m, int H, int N, int D) {
+  if (!cin6_covers(m, H, N, D)) return 0;
+  const int nslab = m * (H / 32);
+  return (int64_t)(nslab + 2) * kSlabC6 / 4 + 64;
+}
+
+extern "C" int rm_cin_layer_fwd6(const float *X0, const float *Xk, int64_t xk_bstride, const float *W,
+                                 const float *bias, int act, int64_t B, int m, int H, int N, int D, float *out,
+                                 float *pooled, int pool_stride, int pool_col0, int pool_from, float *filter_ws,
+                                 rm_stream_t stream) {
+  RM_REQUIRE(B >= 0 && m > 0 && H > 0 && N > 0 && D > 0, "rm_cin_layer_fwd6: bad sizes");
+  if (!cin6_covers(m, H, N, D) || (Xk == X0 && H == m)) {
+    rm_set_error("rm_cin_layer_fwd6: shape not covered (H %% 32 == 0, H <= 64, N <= 128, D in {16, 32, 64})");
+    return RM_EUNSUPPORTED;
+  }
+  if (B == 0) return RM_OK;
+  RM_REQUIRE(X0 && Xk && W && bias && out && filter_ws, "rm_cin_layer_fwd6: NULL argument");
+  RM_REQUIRE(rm_aligned16(X0) && rm_aligned16(out) && rm_aligned16(filter_ws), "rm_cin_layer_fwd6: 16-byte alignment required");
+  RM_REQUIRE(act >= RM_ACT_IDENTITY && act <= RM_ACT_LEAKY_RELU, "rm_cin_layer_fwd6: bad activation id");
+  RM_REQUIRE(!pooled || (pool_from >= 0 && pool_from <= N && pool_stride >= pool_col0 + N - pool_from),
+             "rm_cin_layer_fwd6: bad pooled layout");
+  hipStream_t st = (hipStream_t)stream;
+  const int NH = H / 32, nslab = m * NH;
+  __bf16 *Wp = reinterpret_cast<__bf16 *>(filter_ws);
+  hipLaunchKernelGGL(cin6_prep_kernel, dim3(rm_grid_cap(((int64_t)(nslab + 2) * kNTC6 * 512 + 255) / 256, 2048)),
+                     dim3(256), 0, st, W, m * H, N, nslab, Wp);
+  Cin6Args a{X0, Xk, xk_bstride, Wp, bias, act, B, m, H, N, D, out, pooled, pool_stride, pool_col0, pool_from};
+  const int epb = kRowsC6 / D;
+  const dim3 grid((unsigned)((B + epb - 1) / epb));
+  const size_t smem = 2 * kSlabC6 + (size_t)m * kRowsC6 * 4;
+  if (NH == 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_fwd6_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(cin_fwd6_kernel<1>, grid, dim3(256), smem, st, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_fwd6_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(cin_fwd6_kernel<2>, grid, dim3(256), smem, st, a);
+  }
+  RM_CHECK_LAUNCH("rm_cin_layer_fwd6");
+  return RM_OK;
+}

@@ -1354,6 +1354,13 @@ class XDeepFMEngine(Engine):
         bw = max(ops.cin_bwd_workspace(B, m, self.Hs[i], n, D) for i, n in enumerate(self.units))
         self.cin_fws = torch.empty(fw, dtype=F32, device=dev)
         self.cin_bws = torch.empty(bw, dtype=F32, device=dev)
+        # the layers rm_cin_layer_fwd6 covers run on the bf16 matrix pipe with split fp32 operands (csrc/cin6.hip)
+        # unless cin_gemm = "f32"
+        self.cin_fws6 = None
+        if self.hp.get("cin_gemm", "bf16x6") == "bf16x6":
+            f6 = max(ops.cin_filter_workspace6(m, self.Hs[i], n, D) for i, n in enumerate(self.units))
+            if f6 > 0:
+                self.cin_fws6 = torch.empty(f6, dtype=F32, device=dev)
 
     def _cin_fwd(self, keep=None, masks=None):
         """CIN.__call__ (layers.py:697-760).  keep / masks: the L+1 keep probabilities and 0/1
@@ -1374,7 +1381,7 @@ class XDeepFMEngine(Engine):
             ops.cin_layer_fwd(X0, xk, self.Hs[i], p[f"cin_filter_{i}"][0], p[f"cin_bias_{i}"],
                               self.cin_act, self.maps[i], self.cin_fws,
                               pooled=None if on[i + 1] else self.pooled,
-                              pool_col0=self.pool_col0[i], pool_from=self.pool_from[i])
+                              pool_col0=self.pool_col0[i], pool_from=self.pool_from[i], ws6=self.cin_fws6)
             if on[i + 1]:
                 pf, c0 = self.pool_from[i], self.pool_col0[i]
                 self.maps[i].mul_(masks[i + 1] / keep[i + 1])
@@ -1462,12 +1469,24 @@ class XDeepFMEngine(Engine):
         self._cin_fwd()
 
         def fn():
-            ops.cin_layer_fwd(self.E, xk, H, p[f"cin_filter_{i}"][0], p[f"cin_bias_{i}"],
-                              self.cin_act, self.maps[i], self.cin_fws, pooled=self.pooled,
-                              pool_col0=self.pool_col0[i], pool_from=self.pool_from[i])
+            return ops.cin_layer_fwd(self.E, xk, H, p[f"cin_filter_{i}"][0], p[f"cin_bias_{i}"],
+                                     self.cin_act, self.maps[i], self.cin_fws, pooled=self.pooled,
+                                     pool_col0=self.pool_col0[i], pool_from=self.pool_from[i], ws6=self.cin_fws6)
 
+        flops = 2.0 * B * D * m * H * n
+        if fn() is True:
+            # the product path of this layer: fp32 operands as three bf16 pieces, six piece products per k-step
+            # (csrc/cin6.hip) - priced on the bf16 pipe with the six products counted, the fp32 GEMM beside it
+            return [dict(name=f"cin_fwd6_kernel (rm_cin_layer_fwd6, layer {i}: m={m} H={H} N={n}; Z = fl(x0 * xk) split "
+                              "into 3 bf16 pieces, 6 piece products per k-step on the bf16 matrix pipe)",
+                         symbol="cin_fwd6_kernel", fn=fn, work=6.0 * flops, bound="mfma", peak=2500.0,
+                         extra=lambda ms: {"fp32_gemm_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                                           "fp32_gemm_vs_f32_mfma_peak_157": round(flops / (ms * 1e-3) / 1e12 / 157.3, 4),
+                                           "note": "peak = dense bf16 MFMA (2.5 PFLOP/s); achieved counts the six bf16 "
+                                                   "products per fp32 product; the backward kernels (cin_dx / cin_dw: "
+                                                   "f32 MFMA, 0.77-0.79 of 157.3 TFLOP/s) are now the longer launches"})]
         return [dict(name=f"cin_fwd_kernel (rm_cin_layer_fwd, layer {i}: m={m} H={H} N={n})",
-                     symbol="cin_fwd_kernel", fn=fn, work=2.0 * B * D * m * H * n, bound="mfma")]
+                     symbol="cin_fwd_kernel", fn=fn, work=flops, bound="mfma")]
 
 
 ENGINES = {"deepfm": DeepFMEngine, "dcn": DCNEngine, "xdeepfm": XDeepFMEngine}

@@ -216,11 +216,30 @@ def cin_filter_workspace(m, H, N):
     return int(_lib.lib().rm_cin_filter_workspace(m, H, N))
 
 
-def cin_layer_fwd(X0, Xk, H, W, bias, act, out, filter_ws, pooled=None, pool_col0=0, pool_from=0):
+def cin_filter_workspace6(m, H, N, D):
+    """Floats of filter workspace for the bf16x6 form of cin_layer_fwd (0: the shape is not covered)."""
+    return int(_lib.lib().rm_cin_filter_workspace6(int(m), int(H), int(N), int(D)))
+
+
+def cin_layer_fwd(X0, Xk, H, W, bias, act, out, filter_ws, pooled=None, pool_col0=0, pool_from=0, ws6=None):
     """One CIN layer forward.  X0 [B,m,D]; Xk [B,Hk,D] of which rows j < H are used;
-    W [m*H, N]; out [B,N,D]; pooled [B, P] gets sum_d out[:, pool_from:, :] at pool_col0."""
+    W [m*H, N]; out [B,N,D]; pooled [B, P] gets sum_d out[:, pool_from:, :] at pool_col0.
+    ws6 (cin_filter_workspace6 floats): on the bf16 matrix pipe with split operands (rm_cin_layer_fwd6) when that
+    kernel covers the layer; returns True when it ran."""
     B, m, D = X0.shape
     N = W.shape[1]
+    if ws6 is not None and Xk.data_ptr() != X0.data_ptr():
+        need = cin_filter_workspace6(m, H, N, D)
+        if need > 0 and ws6.numel() >= need:
+            if W.shape[0] != m * H or Xk.shape[0] != B or Xk.shape[2] != D or Xk.shape[1] < H:
+                raise ValueError("cin_layer_fwd: shape mismatch")
+            _lib.call(
+                "rm_cin_layer_fwd6", _chk(X0, "X0", F32), _chk(Xk, "Xk", F32), Xk.shape[1] * D,
+                _chk(W, "W", F32), _chk(bias, "bias", F32, (N,)), ACT_IDS[act], B, m, H, N, D,
+                _chk(out, "out", F32, (B, N, D)), _chk(pooled, "pooled", F32, allow_none=True),
+                0 if pooled is None else pooled.shape[1], pool_col0, pool_from,
+                _chk(ws6, "ws6", F32), _stream())
+            return True
     if W.shape[0] != m * H:
         raise ValueError(f"cin_layer_fwd: filter has {W.shape[0]} rows, expected m*H = {m * H}")
     if Xk.shape[0] != B or Xk.shape[2] != D or Xk.shape[1] < H:

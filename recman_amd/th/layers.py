@@ -535,7 +535,7 @@ class _CINFn(torch.autograd.Function):
         for i, n in enumerate(c.units):
             ops.cin_layer_fwd(X0, xk, c.Hs[i], c.variables[c.fname(i)].detach()[0], c.variables[c.bname(i)].detach(),
                               c.act, c.maps[i], c.fws, pooled=None if on[i + 1] else c.pooled,
-                              pool_col0=c.pool_col0[i], pool_from=c.pool_from[i])
+                              pool_col0=c.pool_col0[i], pool_from=c.pool_from[i], ws6=c.fws6)
             if on[i + 1]:
                 pf, c0 = c.pool_from[i], c.pool_col0[i]
                 c.maps[i].mul_(masks[i + 1] / keep[i + 1])
@@ -641,6 +641,8 @@ class CIN:
         bw = max(ops.cin_bwd_workspace(B, m, self.Hs[i], n, D) for i, n in enumerate(self.units))
         self.fws = torch.empty(fw, dtype=F32, device=dev)
         self.bws = torch.empty(bw, dtype=F32, device=dev)
+        f6 = max(ops.cin_filter_workspace6(m, self.Hs[i], n, D) for i, n in enumerate(self.units))
+        self.fws6 = torch.empty(f6, dtype=F32, device=dev) if f6 > 0 else None  # (rm_cin_layer_fwd6, csrc/cin6.hip)
         self.ws = torch.empty(256 * 1024, dtype=F32, device=dev)
 
     def __call__(self, inputs):

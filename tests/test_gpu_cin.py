@@ -128,3 +128,50 @@ def test_cin_layer_bwd(hip_lib, B, m, H, N, D, act, first, last):
         close(dXk, Xk.grad, "dXk")
     close(dW, W.grad, "dW")
     close(dbias, bias.grad, "dbias")
+
+
+@pytest.mark.parametrize("B,m,H,N,D,act", [
+    (40, 26, 64, 128, 16, "leaky_relu"),   # configs[2] layer 1
+    (9, 26, 64, 128, 64, "leaky_relu"),    # configs[4] layer 1: an example spans four row tiles over two waves
+    (21, 7, 32, 48, 32, "relu"),           # one j half, N < 128 (zero filter tiles), two examples per wave
+    (3, 3, 64, 100, 16, "identity"),       # N not a multiple of 16, a block with 3 of its 8 examples
+    (1, 1, 32, 16, 64, "leaky_relu"),
+])
+def test_cin_layer_fwd6_split_operands(hip_lib, B, m, H, N, D, act):
+    """rm_cin_layer_fwd6 (csrc/cin6.hip: Z = fl(x0 * xk) split into three bf16 pieces, six piece products on the
+    bf16 matrix pipe) against the float64 layer to the f32 kernel's tolerance, never worse than 1.5x the f32-MFMA
+    kernel's own error; pooled columns, untouched columns, determinism; and what it declines."""
+    from recman_amd import ops
+
+    g = torch.Generator().manual_seed(B * 17 + N)
+    X0 = torch.randn(B, m, D, generator=g)
+    Xkfull = torch.randn(B, H + 3, D, generator=g)
+    W = torch.randn(m * H, N, generator=g) * 0.2
+    bias = torch.randn(N, generator=g) * 0.1
+    want = _layer_ref(X0, Xkfull[:, :H], W, bias, act)
+    pool_from = N // 2
+    want_pool = want[:, pool_from:].sum(-1)
+    need = ops.cin_filter_workspace6(m, H, N, D)
+    assert need > 0
+    ws = torch.empty(ops.cin_filter_workspace(m, H, N), device="cuda")
+    ws6 = torch.empty(need, device="cuda")
+    outs = []
+    for use6 in (True, False, True):
+        out = torch.full((B, N, D), float("nan"), device="cuda")
+        pooled = torch.full((B, 7 + N - pool_from), -1.0, device="cuda")
+        took = ops.cin_layer_fwd(X0.cuda(), Xkfull.cuda(), H, W.cuda(), bias.cuda(), act, out, ws, pooled=pooled,
+                                 pool_col0=7, pool_from=pool_from, ws6=ws6 if use6 else None)
+        assert bool(took) == use6
+        outs.append((out, pooled))
+    scale = float(want.abs().max())
+    e6 = float((outs[0][0].cpu().double() - want).abs().max())
+    e32 = float((outs[1][0].cpu().double() - want).abs().max())
+    assert e6 <= 2e-6 * max(1.0, scale) * max(1, (m * H) ** 0.5 / 4), (e6, scale)
+    assert e6 <= 1.5 * e32 + 1e-7, (e6, e32)
+    perr = float((outs[0][1][:, 7:].cpu().double() - want_pool).abs().max())
+    assert perr <= 1e-5 * max(1.0, float(want_pool.abs().max())), perr
+    assert bool((outs[0][1][:, :7] == -1).all())
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    # not covered: the first layer (Xk is X0), H not a multiple of 32, D = 8
+    assert ops.cin_filter_workspace6(26, 26, 128, 16) == 0 and ops.cin_filter_workspace6(26, 64, 128, 8) == 0
+    assert ops.cin_filter_workspace6(26, 96, 128, 16) == 0 and ops.cin_filter_workspace6(26, 64, 200, 16) == 0
