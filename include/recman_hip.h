@@ -365,7 +365,9 @@ int rm_cin_layer_fwd6(const float *X0, const float *Xk, int64_t xk_bstride, cons
  *   the gradient w.r.t. out is never materialised by the caller:
  *     n <  pool_from: d_hidden[b,n,d]  (the next layer's dXk, dh_bstride floats per example)
  *     n >= pool_from: g[b] * cin_w_direct[n - pool_from]   (reduce_sum + cin_w, layers.py:754-758)
- *   dX0 [B,m,D] (+= when accumulate_dx0) = sum_j (dM @ W^T)[.,(i,j)] * Xk[b,j,d]
+ *   dX0 [B,m,D] (+= when accumulate_dx0 & 1) = sum_j (dM @ W^T)[.,(i,j)] * Xk[b,j,d]
+ *        accumulate_dx0 & 2: the dX pass runs on the bf16 matrix pipe with split fp32 operands (csrc/cin6.hip, the
+ *        scheme of rm_cin_layer_fwd6) where it covers the layer (same shapes as rm_cin_layer_fwd6, N > 64)
  *   dXk [B,H,D] (dxk_bstride floats per example) = sum_i (dM @ W^T)[.,(i,j)] * X0[b,i,d];
  *        with xk_is_x0 (first layer: Xk is X0 itself) it is added into dX0 instead
  *   dW [m*H,N] = Z^T @ dM,  dbias [N] = colsum(dM)   (dM = d_out * act'(out))

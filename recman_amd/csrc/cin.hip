@@ -1187,6 +1187,12 @@ extern "C" int64_t rm_cin_filter_workspace(int m, int H, int N) {
   return (int64_t)cin_Kp(m, H) * 32 * NT;
 }
 
+// csrc/cin6.hip: the dX part on the bf16 matrix pipe with split fp32 operands
+int64_t rm_internal_cin_dx6_floats(int m, int H, int N, int D);
+bool rm_internal_cin_dx6(const float *X0, const float *Xk, int64_t xk_bstride, const float *W, const float *dM,
+                         int64_t B, int m, int H, int N, int D, float *dX0, int accumulate_dx0, float *dXk,
+                         int64_t dxk_bstride, float *ws6, hipStream_t st);
+
 static int cin_check(const char *fn, int64_t B, int m, int H, int N, int D) {
   RM_REQUIRE(B >= 0 && m > 0 && H > 0 && N > 0 && D > 0, "%s: bad sizes", fn);
   RM_REQUIRE(N <= 128, "%s: N=%d unsupported (<= 128 filters per layer)", fn, N);
@@ -1256,7 +1262,8 @@ static int64_t cin_part_floats(int64_t B, int m, int H, int Np, int D) {
 extern "C" int64_t rm_cin_bwd_workspace(int64_t B, int m, int H, int N, int D) {
   const int NT = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
   const int Np = 32 * NT;
-  return (int64_t)m * cin_Hp(H) * Np + B * D * Np + cin_part_floats(B, m, H, Np, D) + (int64_t)kDmBlocks * Np;
+  return (int64_t)m * cin_Hp(H) * Np + B * D * Np + cin_part_floats(B, m, H, Np, D) + (int64_t)kDmBlocks * Np +
+         rm_internal_cin_dx6_floats(m, H, N, D);
 }
 extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int xk_is_x0,
                                 const float *W, int act, const float *out, const float *d_hidden,
@@ -1316,11 +1323,16 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dx_sym_kernel<NT_>),            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
     hipLaunchKernelGGL((cin_dx_sym_kernel<NT_>), grid, dim3(512), smem, st, X0, Wq, dM, B, m, D,  \
-                       dX0, accumulate_dx0);                                                     \
+                       dX0, accumulate_dx0 & 1);                                                 \
   }
     if (NT == 1) RM_CIN_DXS(1) else if (NT == 2) RM_CIN_DXS(2) else RM_CIN_DXS(4)
 #undef RM_CIN_DXS
+  } else if ((accumulate_dx0 & 2) && !xk_is_x0 &&
+             rm_internal_cin_dx6(X0, Xk, xk_bstride, W, dM, B, m, H, N, D, dX0, accumulate_dx0 & 1, dXk, dxk_bstride,
+                                 dbias_part + (((int64_t)kDmBlocks * Np + 3) / 4 * 4), st)) {
+    // (bit 1 of accumulate_dx0: the dX part on the bf16 matrix pipe with split operands, csrc/cin6.hip)
   } else {
+    accumulate_dx0 &= 1;
     const int rows = (kRC * 2 % D == 0 && 256 % D == 0 && cin_dx_smem(m, H, NT, 256) <= 160 * 1024) ? 256 : 128;
     const size_t smem = cin_dx_smem(m, H, NT, rows);
     RM_REQUIRE(smem <= 160 * 1024, "rm_cin_layer_bwd: m=%d H=%d needs %zu B of LDS (> 160 KiB)", m, H, smem);

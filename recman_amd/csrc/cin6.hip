@@ -299,3 +299,235 @@ extern "C" int rm_cin_layer_fwd6(const float *X0, const float *Xk, int64_t xk_bs
   RM_CHECK_LAUNCH("rm_cin_layer_fwd6");
   return RM_OK;
 }
+
+// ---- backward, the dX part (cin.hip's cin_dx_kernel on the same scheme) ---------------------------------------
+//   dZ[p, (i, j)] = sum_n W[(i, j), n] dM[p, n];  dX0[b, i, d] += sum_j dZ Xk[b, j, d];  dXk[b, j, d] += sum_i dZ X0[b, i, d]
+// dZ^T tile [16 k'][16 rows] = W[k'][:] . dM[row][:]^T with the FILTER as the MFMA's A operand (split once per call:
+// cin6_prep_dx_kernel) and the lane's own dM rows as the B operand - split ONCE per block into 3 x 16 bf16 fragments
+// per row tile and kept in registers (K = N = 128 = four 32-n slabs).  A lane ends with dZ of 4 consecutive j of one
+// row: the contraction with Xk / X0 runs in registers (8 FMAs per 24 MFMAs), the Xk values and the dXk accumulators
+// of the lane's (row, j) pairs live in registers for the whole block, dX0 goes through LDS.  Filter slabs (one i,
+// 32 j, all n: 24 KiB) stream by LDS-DMA into two buffers; 4-wave blocks of 128 rows, two per CU.
+namespace {
+
+// Wq6[s = i * NH + jh][kt][ns][p][lane][e] = piece p of W[(i * H + 32 jh + 16 kt + (lane & 15)) * N + 32 ns + 8 (lane >> 4) + e]
+__global__ void cin6_prep_dx_kernel(const float *__restrict__ W, int m, int H, int N, __bf16 *__restrict__ Wp) {
+  const int NH = H / 32, nslab = m * NH;
+  const int64_t total = (int64_t)(nslab + 2) * 8 * 512;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = t & 7, lane = (t >> 3) & 63;
+    const int64_t u = t >> 9;
+    const int ns = (int)(u & 3), kt = (int)((u >> 2) & 1), s = (int)(u >> 3);
+    float x = 0.f;
+    if (s < nslab) {
+      const int i = s / NH, jh = s - i * NH;
+      const int j = 32 * jh + 16 * kt + (lane & 15), n = 32 * ns + 8 * (lane >> 4) + e;
+      if (n < N) x = W[(int64_t)(i * H + j) * N + n];
+    }
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 mm = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)mm);
+    const int64_t base = (int64_t)s * (kSlabC6 / 2) + (int64_t)((kt * 4 + ns) * 3) * 512 + lane * 8 + e;
+    Wp[base] = h;
+    Wp[base + 512] = mm;
+    Wp[base + 1024] = l;
+  }
+}
+
+struct CinDx6Args {
+  const float *X0, *Xk;
+  int64_t xk_bstride;
+  const __bf16 *Wp;
+  const float *dM;  // [B * D][128]
+  int64_t B;
+  int m, H, D;
+  float *dX0;
+  int accumulate_dx0;
+  float *dXk;
+  int64_t dxk_bstride;
+};
+
+template <int NH>
+__global__ __launch_bounds__(256, 2) void cin_dx6_kernel(CinDx6Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemc6[];
+  // [2][kSlabC6] filter slabs (later: the dXk image [H][128]) | X0s [m][128] | dX0s [m][128]
+  float *X0s = reinterpret_cast<float *>(smemc6 + 2 * kSlabC6);
+  float *dX0s = X0s + a.m * kRowsC6;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int D = a.D, m = a.m;
+  const int epb = kRowsC6 / D;
+  const int64_t b0 = (int64_t)blockIdx.x * epb;
+  constexpr int JT = 2 * NH;  // 16-j tiles
+
+  auto stage = [&](int s, int buf) {
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.Wp) + (int64_t)s * kSlabC6 + lane * 16;
+    unsigned char *dst = smemc6 + buf * kSlabC6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (4 * i + w) * 1024),
+                                       (__attribute__((address_space(3))) void *)(dst + (4 * i + w) * 1024), 16, 0, 0);
+  };
+  stage(0, 0);
+  {
+    const int D4 = D >> 2, total = epb * m * D4;
+    for (int t = tid; t < total; t += 256) {
+      const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+      const int64_t b = b0 + bl;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < a.B) v = *reinterpret_cast<const float4 *>(a.X0 + (b * m + i) * D + 4 * d4);
+      *reinterpret_cast<float4 *>(X0s + i * kRowsC6 + bl * D + 4 * d4) = v;
+    }
+  }
+  // the lane's rows: dM fragments (split once), the Xk values of its (row, j = 16 jt + 4 q + i') pairs, dXk sums
+  bf16x8 dmf[2][4][3];
+  float xkr[2][JT][4], dxk[2][JT][4];
+  int prow[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int p = 32 * w + 16 * t + r;
+    prow[t] = p;
+    const int64_t pg = b0 * D + p;
+    const bool live = pg < a.B * D;
+    const float *src = a.dM + (live ? pg : 0) * 128 + 8 * q;
+#pragma unroll
+    for (int ns = 0; ns < 4; ++ns) {
+      const float4 u = *reinterpret_cast<const float4 *>(src + 32 * ns), v = *reinterpret_cast<const float4 *>(src + 32 * ns + 4);
+      float y[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = live ? y[e] : 0.f;
+      split8c(y, dmf[t][ns][0], dmf[t][ns][1], dmf[t][ns][2]);
+    }
+    const int bl = p / D, d = p - bl * D;
+    const int64_t b = b0 + bl < a.B ? b0 + bl : a.B - 1;
+    const float *xs = a.Xk + b * a.xk_bstride + d;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2) {
+        xkr[t][jt][i2] = xs[(int64_t)(16 * jt + 4 * q + i2) * D];
+        dxk[t][jt][i2] = 0.f;
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int i = 0; i < m; ++i) {
+    const float x0v[2] = {X0s[i * kRowsC6 + prow[0]], X0s[i * kRowsC6 + prow[1]]};
+    float dx0[2] = {0.f, 0.f};
+#pragma unroll
+    for (int jh = 0; jh < NH; ++jh) {
+      const int s = i * NH + jh;
+      stage(s + 1, (s + 1) & 1);  // (two spare slabs behind the last)
+      const unsigned char *ws = smemc6 + (s & 1) * kSlabC6 + lane * 16;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) {
+          const unsigned char *wp = ws + ((kt * 4 + ns) * 3) * 1024;
+          const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(wp);
+          const bf16x8 wm = *reinterpret_cast<const bf16x8 *>(wp + 1024);
+          const bf16x8 wl = *reinterpret_cast<const bf16x8 *>(wp + 2048);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            f32x4 c = acc[t];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, dmf[t][ns][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dmf[t][ns][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, dmf[t][ns][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, dmf[t][ns][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dmf[t][ns][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dmf[t][ns][0], c, 0, 0, 0);
+            acc[t] = c;
+          }
+        }
+        // acc[t][i2] = dZ[row prow[t]][(i, j = 32 jh + 16 kt + 4 q + i2)]
+        const int jt = 2 * jh + kt;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i2 = 0; i2 < 4; ++i2) {
+            dx0[t] += acc[t][i2] * xkr[t][jt][i2];
+            dxk[t][jt][i2] += acc[t][i2] * x0v[t];
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float v = dx0[t];
+      v += __shfl_xor(v, 16, 64);  // the four lane quarters hold disjoint j
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) dX0s[i * kRowsC6 + prow[t]] = v;
+    }
+  }
+  // dXk -> LDS image [j][row] over the filter buffers (every (j, row) is owned by exactly one lane)
+  float *dXks = reinterpret_cast<float *>(smemc6);
+  if (a.dXk != nullptr) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) dXks[(16 * jt + 4 * q + i2) * kRowsC6 + prow[t]] = dxk[t][jt][i2];
+  }
+  __syncthreads();
+  const int D4 = D >> 2;
+  for (int t = tid; t < epb * m * D4; t += 256) {
+    const int d4 = t % D4, i = (t / D4) % m, bl = t / (D4 * m);
+    const int64_t b = b0 + bl;
+    if (b >= a.B) continue;
+    float4 v = *reinterpret_cast<const float4 *>(dX0s + i * kRowsC6 + bl * D + 4 * d4);
+    float4 *dst = reinterpret_cast<float4 *>(a.dX0 + (b * m + i) * D + 4 * d4);
+    if (a.accumulate_dx0) {
+      const float4 o = *dst;
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *dst = v;
+  }
+  if (a.dXk != nullptr) {
+    const int H = a.H;
+    for (int t = tid; t < epb * H * D4; t += 256) {
+      const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
+      const int64_t b = b0 + bl;
+      if (b >= a.B) continue;
+      *reinterpret_cast<float4 *>(a.dXk + b * a.dxk_bstride + (int64_t)j * D + 4 * d4) =
+          *reinterpret_cast<const float4 *>(dXks + j * kRowsC6 + bl * D + 4 * d4);
+    }
+  }
+}
+
+}  // namespace
+
+// floats rm_cin_layer_bwd's workspace needs for the split filter of the dX kernel (0: not covered)
+int64_t rm_internal_cin_dx6_floats(int m, int H, int N, int D) {
+  if (!cin6_covers(m, H, N, D) || N <= 64) return 0;
+  return (int64_t)(m * (H / 32) + 2) * kSlabC6 / 4 + 64;
+}
+
+// the dX part of rm_cin_layer_bwd on the bf16 pipe: returns false when the shape is not covered (nothing launched)
+bool rm_internal_cin_dx6(const float *X0, const float *Xk, int64_t xk_bstride, const float *W, const float *dM,
+                         int64_t B, int m, int H, int N, int D, float *dX0, int accumulate_dx0, float *dXk,
+                         int64_t dxk_bstride, float *ws6, hipStream_t st) {
+  if (rm_internal_cin_dx6_floats(m, H, N, D) == 0 || !rm_aligned16(ws6)) return false;
+  const int NH = H / 32, nslab = m * NH;
+  __bf16 *Wp = reinterpret_cast<__bf16 *>(ws6);
+  hipLaunchKernelGGL(cin6_prep_dx_kernel, dim3(rm_grid_cap(((int64_t)(nslab + 2) * 8 * 512 + 255) / 256, 2048)),
+                     dim3(256), 0, st, W, m, H, N, Wp);
+  CinDx6Args a{X0, Xk, xk_bstride, Wp, dM, B, m, H, D, dX0, accumulate_dx0, dXk, dxk_bstride};
+  const int epb = kRowsC6 / D;
+  const dim3 grid((unsigned)((B + epb - 1) / epb));
+  const size_t smem = 2 * kSlabC6 + (size_t)2 * m * kRowsC6 * 4;
+  if (NH == 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dx6_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(cin_dx6_kernel<1>, grid, dim3(256), smem, st, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dx6_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(cin_dx6_kernel<2>, grid, dim3(256), smem, st, a);
+  }
+  return true;
+}

@@ -1435,7 +1435,7 @@ class XDeepFMEngine(Engine):
                 self.cin_act, self.maps[i], g, dX0, gr[f"cin_filter_{i}"][0],
                 gr[f"cin_bias_{i}"], self.cin_bws, xk_is_x0=(i == 0),
                 d_hidden=d_hidden, cin_w_direct=cwd, pool_from=pfa, accumulate_dx0=True,
-                dXk=self.dxk[i] if i > 0 else None)
+                dXk=self.dxk[i] if i > 0 else None, split=self.hp.get("cin_gemm", "bf16x6") == "bf16x6")
         if on[0]:
             self.d_rows.addcmul_(self._dx0_cin, cmasks[0] / keep[0])
         reg = self.hp.get("deep_l2_reg", 0.0)

@@ -81,9 +81,14 @@ def test_cin_notebook_kat_on_gpu(hip_lib):
     (6, 4, 4, 64, 64, "relu", True, False),         # first layer (symmetric dX) at D = 64
     (9, 7, 7, 100, 32, "leaky_relu", True, True),   # ... odd m, D = 32, N not a multiple of 32
     (300, 26, 26, 128, 16, "leaky_relu", True, False),  # ... many blocks, ragged last block
+    (37, 26, 64, 128, 16, "leaky_relu", False, False),  # configs[2] layer 1 (the split-operand dX kernel's shape)
+    (7, 5, 32, 100, 64, "relu", False, True),           # ... one j half, D = 64, N not a multiple of 16
+    (13, 3, 64, 128, 32, "identity", False, False),     # ... D = 32
 ])
-def test_cin_layer_bwd(hip_lib, B, m, H, N, D, act, first, last):
-    """autograd (float64) of the oracle's layer formula vs rm_cin_layer_bwd."""
+@pytest.mark.parametrize("split", [False, True], ids=["f32", "split"])
+def test_cin_layer_bwd(hip_lib, B, m, H, N, D, act, first, last, split):
+    """autograd (float64) of the oracle's layer formula vs rm_cin_layer_bwd; split: the dX pass on the bf16 matrix
+    pipe with split fp32 operands where csrc/cin6.hip covers the layer (elsewhere the flag changes nothing)."""
     from recman_amd import ops
 
     g_ = torch.Generator().manual_seed(B * 7 + N)
@@ -114,7 +119,7 @@ def test_cin_layer_bwd(hip_lib, B, m, H, N, D, act, first, last):
     ws = torch.empty(ops.cin_bwd_workspace(B, m, H, N, D), device="cuda")
     ops.cin_layer_bwd(f(X0), f(Xk), H, f(W), act, out_d, f(gvec), dX0, dW, dbias, ws,
                       xk_is_x0=first, d_hidden=f(dh) if pool_from else None, cin_w_direct=f(cw),
-                      pool_from=pool_from, accumulate_dx0=True, dXk=dXk)
+                      pool_from=pool_from, accumulate_dx0=True, dXk=dXk, split=split)
     torch.cuda.synchronize()
 
     def close(got, want, what):
