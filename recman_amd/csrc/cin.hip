@@ -1192,6 +1192,9 @@ int64_t rm_internal_cin_dx6_floats(int m, int H, int N, int D);
 bool rm_internal_cin_dx6(const float *X0, const float *Xk, int64_t xk_bstride, const float *W, const float *dM,
                          int64_t B, int m, int H, int N, int D, float *dX0, int accumulate_dx0, float *dXk,
                          int64_t dxk_bstride, float *ws6, hipStream_t st);
+int64_t rm_internal_cin_dw6_floats(int64_t B, int m, int H, int N, int D);
+bool rm_internal_cin_dw6(const float *X0, const float *Xk, int64_t xk_bstride, const float *dM, int64_t B, int m, int H,
+                         int N, int D, float *dW, float *ws6, hipStream_t st);
 
 static int cin_check(const char *fn, int64_t B, int m, int H, int N, int D) {
   RM_REQUIRE(B >= 0 && m > 0 && H > 0 && N > 0 && D > 0, "%s: bad sizes", fn);
@@ -1263,7 +1266,7 @@ extern "C" int64_t rm_cin_bwd_workspace(int64_t B, int m, int H, int N, int D) {
   const int NT = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
   const int Np = 32 * NT;
   return (int64_t)m * cin_Hp(H) * Np + B * D * Np + cin_part_floats(B, m, H, Np, D) + (int64_t)kDmBlocks * Np +
-         rm_internal_cin_dx6_floats(m, H, N, D);
+         rm_internal_cin_dx6_floats(m, H, N, D) + rm_internal_cin_dw6_floats(B, m, H, N, D);
 }
 extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bstride, int xk_is_x0,
                                 const float *W, int act, const float *out, const float *d_hidden,
@@ -1300,6 +1303,7 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
 #define RM_CIN_DX_SYM 1
 #endif
   // first layer: the symmetric-pair dX kernel (about half the MFMA work), when its LDS images fit
+  const bool split = (accumulate_dx0 & 2) != 0;  // bit 1: dX / dW on the bf16 pipe where csrc/cin6.hip covers the layer
   const bool dx_sym = RM_CIN_DX_SYM && xk_is_x0 && H == m && 256 % D == 0 && m <= 255 &&
                       cin_dx_sym_smem(m, NT) <= 160 * 1024;
   if (dx_sym) hipLaunchKernelGGL(cin_prep_bwd_sym_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, Np, Wq);
@@ -1357,7 +1361,10 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
 #undef RM_CIN_DX_JB
 #undef RM_CIN_DX
   }
-  {
+  float *ws_dw6 = dbias_part + (((int64_t)kDmBlocks * Np + 3) / 4 * 4) + (rm_internal_cin_dx6_floats(m, H, N, D) + 3) / 4 * 4;
+  if (split && !xk_is_x0 && rm_internal_cin_dw6(X0, Xk, xk_bstride, dM, B, m, H, N, D, dW, ws_dw6, st)) {
+    // (the dW pass on the bf16 matrix pipe with split operands, csrc/cin6.hip)
+  } else {
     const size_t smem = cin_dw_smem(m, H, NT);
     const int64_t chunks_total = (B * D + kRC - 1) / kRC;
     const int sym = xk_is_x0 ? 1 : 0;  // first layer: symmetric k' ordering (half the tiles)

@@ -531,3 +531,226 @@ bool rm_internal_cin_dx6(const float *X0, const float *Xk, int64_t xk_bstride, c
   }
   return true;
 }
+
+// ---- backward, the dW part:  dW[(i, j), n] = sum over rows p = (b, d) of Z[p, (i, j)] dM[p, n] ---------------------
+// A reduction over the 1 M rows: a slab is 32 ROWS.  An operand fragment is 8 consecutive rows of one column:
+//   Z   8 consecutive rows = 8 consecutive d of one example: x0[i] and xk[j] are each 32 contiguous bytes of X0 / Xk -
+//       loaded straight from global memory (a slab ahead), multiplied in fp32, split in registers;
+//   dM  strided in its row-major [rows][128] image: a slab goes through LDS as transposed bf16 planes
+//       [piece][n][32 rows] (a thread loads one column's 8 rows - coalesced across the wave's 64 columns - splits
+//       them, writes three rotated 16-byte pieces; gemm6.hip's TN kernel), double-buffered: one barrier per slab.
+// Block = 4 waves = 3 fields i x all 64 j x all 128 n (wave w = the 16 j of tile w for the block's 3 i: 3 x 8
+// accumulator tiles), two blocks per CU; dM is read once per group of 3 fields (9 times at m = 26: 4.8 GB per layer,
+// streaming).  dM is the MFMA's A operand: a lane ends with 4 consecutive n of one (i, j).  Partial sums per row split
+// go to the workspace; cin6_dw_reduce_kernel adds them in split order (deterministic).
+namespace {
+
+constexpr int kDwI = 3;                    // fields per block
+constexpr int kDwPlane = 128 * 64;         // bytes of one bf16 plane [128 n][32 rows]
+constexpr int kDwBuf = 3 * kDwPlane;       // 24 KiB
+
+struct CinDw6Args {
+  const float *X0, *Xk, *dM;
+  int64_t xk_bstride;
+  int64_t B;
+  int m, H, D;
+  int ngroups, nsplit;
+  int64_t slabs_per_split, nslab;
+  float *part;  // [nsplit][m * H][128]
+};
+
+template <int NH>
+__global__ __launch_bounds__(256, 2) void cin_dw6_kernel(CinDw6Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemc6[];  // [2][kDwBuf]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int D = a.D, H = 32 * NH;
+  const int grp = blockIdx.x % a.ngroups, sp = blockIdx.x / a.ngroups;
+  const int i0 = kDwI * grp;
+  const int64_t rows_total = a.B * D;
+  constexpr int JW = NH * 2 / 4 > 0 ? NH * 2 / 4 : 1;  // 16-j tiles per wave: H = 64 -> 1, H = 32 -> waves 2, 3 idle
+  const bool wave_on = 16 * w < H;
+
+  // dM units of this thread: (column n, 8-row group g), two per slab
+  int un[2], ug[2], ulds[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int u = tid + 256 * k;
+    un[k] = u & 127;
+    ug[k] = u >> 7;
+    ulds[k] = un[k] * 64 + ((ug[k] + (un[k] >> 2)) & 3) * 16;  // (pieces rotated by n / 4: gemm6.hip)
+  }
+  auto load_dm = [&](int64_t slab, float (&x)[2][8]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t row = slab * 32 + 8 * ug[k] + e;
+        x[k][e] = a.dM[(row < rows_total ? row : rows_total - 1) * 128 + un[k]];
+      }
+  };
+  // Z sources of this lane: rows 8 q .. 8 q + 7 of the slab = 8 consecutive d of one example
+  auto load_z = [&](int64_t slab, float (&xkv)[8], float (&x0v)[kDwI][8]) {
+    int64_t row = slab * 32 + 8 * q;
+    row = row < rows_total ? row : rows_total - 8;  // (rows past the end: dM is zeroed there, any finite value does)
+    const int64_t b = row / D;
+    const int d = (int)(row - b * D);
+    const int j = 16 * (wave_on ? w : 0) + r;
+    const float4 *pk = reinterpret_cast<const float4 *>(a.Xk + b * a.xk_bstride + (int64_t)j * D + d);
+    const float4 k0 = pk[0], k1 = pk[1];
+    xkv[0] = k0.x; xkv[1] = k0.y; xkv[2] = k0.z; xkv[3] = k0.w; xkv[4] = k1.x; xkv[5] = k1.y; xkv[6] = k1.z; xkv[7] = k1.w;
+#pragma unroll
+    for (int u = 0; u < kDwI; ++u) {
+      const int i = i0 + u < a.m ? i0 + u : a.m - 1;
+      const float4 *p0 = reinterpret_cast<const float4 *>(a.X0 + (b * a.m + i) * D + d);
+      const float4 v0 = p0[0], v1 = p0[1];
+      x0v[u][0] = v0.x; x0v[u][1] = v0.y; x0v[u][2] = v0.z; x0v[u][3] = v0.w;
+      x0v[u][4] = v1.x; x0v[u][5] = v1.y; x0v[u][6] = v1.z; x0v[u][7] = v1.w;
+    }
+  };
+  auto write_dm = [&](int64_t slab, const float (&x)[2][8], int buf) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (slab * 32 + 8 * ug[k] + e < rows_total) ? x[k][e] : 0.f;
+      bf16x8 h, mm, l;
+      split8c(y, h, mm, l);
+      unsigned char *dst = smemc6 + buf * kDwBuf + ulds[k];
+      *reinterpret_cast<bf16x8 *>(dst) = h;
+      *reinterpret_cast<bf16x8 *>(dst + kDwPlane) = mm;
+      *reinterpret_cast<bf16x8 *>(dst + 2 * kDwPlane) = l;
+    }
+  };
+
+  f32x4 acc[kDwI][8];
+#pragma unroll
+  for (int u = 0; u < kDwI; ++u)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) acc[u][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t s0 = (int64_t)sp * a.slabs_per_split;
+  const int64_t s1 = s0 + a.slabs_per_split < a.nslab ? s0 + a.slabs_per_split : a.nslab;
+  float dmr[2][8], xkv[8], x0v[kDwI][8];
+  if (s0 < s1) {
+    load_dm(s0, dmr);
+    load_z(s0, xkv, x0v);
+    write_dm(s0, dmr, 0);
+    load_dm(s0 + 1 < s1 ? s0 + 1 : s0, dmr);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int64_t s = s0; s < s1; ++s) {
+    const int buf = (int)((s - s0) & 1);
+    // this slab's Z fragments (values loaded a slab ago), then the next slab's on their way
+    bf16x8 zf[kDwI][3];
+#pragma unroll
+    for (int u = 0; u < kDwI; ++u) {
+      float z[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = x0v[u][e] * xkv[e];
+      split8c(z, zf[u][0], zf[u][1], zf[u][2]);
+    }
+    const int64_t sn = s + 1 < s1 ? s + 1 : s;
+    load_z(sn, xkv, x0v);
+    // the next slab's dM planes into the other buffer (its raw values were requested a slab ago), the one after
+    write_dm(sn, dmr, buf ^ 1);
+    load_dm(s + 2 < s1 ? s + 2 : sn, dmr);
+    if (wave_on) {
+      const unsigned char *ws = smemc6 + buf * kDwBuf;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const int n = 16 * nt + r;
+        const unsigned char *p = ws + n * 64 + ((q + (n >> 2)) & 3) * 16;
+        const bf16x8 gh = *reinterpret_cast<const bf16x8 *>(p);
+        const bf16x8 gm = *reinterpret_cast<const bf16x8 *>(p + kDwPlane);
+        const bf16x8 gl = *reinterpret_cast<const bf16x8 *>(p + 2 * kDwPlane);
+#pragma unroll
+        for (int u = 0; u < kDwI; ++u) {
+          // dM is the A operand: D[m = n 4 q + i'][col = j r]
+          f32x4 c = acc[u][nt];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, zf[u][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, zf[u][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm, zf[u][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm, zf[u][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, zf[u][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, zf[u][0], c, 0, 0, 0);
+          acc[u][nt] = c;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // partial tile: lane (r, q) holds n = 16 nt + 4 q .. + 3 of k' = (i0 + u) * H + 16 w + r
+  if (wave_on) {
+    float *pt = a.part + (int64_t)sp * a.m * H * 128;
+#pragma unroll
+    for (int u = 0; u < kDwI; ++u) {
+      if (i0 + u >= a.m) continue;
+      const int64_t kp = (int64_t)(i0 + u) * H + 16 * w + r;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) *reinterpret_cast<f32x4 *>(pt + kp * 128 + 16 * nt + 4 * q) = acc[u][nt];
+    }
+  }
+  (void)JW;
+}
+
+__global__ void cin6_dw_reduce_kernel(const float *__restrict__ part, int K, int N, int nsplit, float *__restrict__ dW) {
+  const int64_t total = (int64_t)K * N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = t / N;
+    const int n = (int)(t - k * N);
+    const float *p = part + k * 128 + n;
+    float v = 0.f;
+    for (int s = 0; s < nsplit; ++s) v += p[(int64_t)s * K * 128];
+    dW[t] = v;
+  }
+}
+
+struct Dw6Plan {
+  int ngroups, nsplit;
+  int64_t nslab, per;
+};
+Dw6Plan dw6_plan(int64_t B, int m, int D) {
+  Dw6Plan p;
+  p.ngroups = (m + kDwI - 1) / kDwI;
+  p.nslab = (B * D + 31) / 32;
+  int64_t want = 512 / p.ngroups;  // two blocks per CU, one round
+  if (want < 1) want = 1;
+  if (want > p.nslab) want = p.nslab;
+  p.per = (p.nslab + want - 1) / want;
+  p.nsplit = (int)((p.nslab + p.per - 1) / p.per);
+  return p;
+}
+
+}  // namespace
+
+// floats of workspace for the dW part (0: not covered)
+int64_t rm_internal_cin_dw6_floats(int64_t B, int m, int H, int N, int D) {
+  if (!cin6_covers(m, H, N, D) || N <= 64 || B <= 0) return 0;
+  const Dw6Plan p = dw6_plan(B, m, D);
+  return (int64_t)p.nsplit * m * H * 128 + 64;
+}
+
+bool rm_internal_cin_dw6(const float *X0, const float *Xk, int64_t xk_bstride, const float *dM, int64_t B, int m, int H,
+                         int N, int D, float *dW, float *ws6, hipStream_t st) {
+  if (rm_internal_cin_dw6_floats(B, m, H, N, D) == 0 || !rm_aligned16(ws6) || !rm_aligned16(X0) || !rm_aligned16(Xk) ||
+      xk_bstride % 4 != 0)
+    return false;
+  const Dw6Plan p = dw6_plan(B, m, D);
+  CinDw6Args a{X0, Xk, dM, xk_bstride, B, m, H, D, p.ngroups, p.nsplit, p.per, p.nslab, ws6};
+  const dim3 grid((unsigned)(p.ngroups * p.nsplit));
+  const size_t smem = 2 * kDwBuf;
+  if (H == 32) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dw6_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(cin_dw6_kernel<1>, grid, dim3(256), smem, st, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dw6_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(cin_dw6_kernel<2>, grid, dim3(256), smem, st, a);
+  }
+  hipLaunchKernelGGL(cin6_dw_reduce_kernel, dim3(rm_grid_cap(((int64_t)m * H * N + 255) / 256, 2048)), dim3(256), 0, st,
+                     ws6, m * H, N, p.nsplit, dW);
+  return true;
+}
