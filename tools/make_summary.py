@@ -61,7 +61,7 @@ Whole DeepFM step on SURVEY 8d's embed+FM bytes: {sh['algorithmic_bytes'] / 1e6:
 
 `train_step` (what fit() achieves at configs[1]: new batch -> fwd+bwd -> row-wise lazy Adam, sort on a side stream -> dense Adam): {ts.get('ms_per_step_dataset_in_hbm')} ms per step with the dataset in HBM, {ts.get('ms_per_step_pinned_feeder')} ms through the zero-copy pinned feeder (PCIe floor {ts.get('pcie_floor_ms_at_63GBs')} ms for the int64 ids).
 
-Round 2 -> round 3 on the same command: DeepFM 380 M -> {d['value'] / 1e6:.0f} M examples/s (the whole training step as ONE kernel, rm_deepfm_step: profiles/r03_deepfm_step.md); optimizer step 0.39 -> {o['ms']:.2f} ms (field-segmented sort 152 -> 62 us, long runs in segments: Zipf 0.66 -> 0.34 ms; profiles/r03_optimizer.md); DCN 45.7 M -> {d['workloads']['dcn']['value'] / 1e6:.1f} M (the NN GEMMs on the bf16 matrix pipe with split fp32 operands, rm_dense_fwd6: profiles/r03_dense_bf16x6.md); xDeepFM {d['workloads']['xdeepfm']['value'] / 1e6:.2f} M (unchanged kernels); the row-sharded DeepFM step at world size 1 0.366 -> 0.25 ms (profiles/r03_sharded_step.md).
+Round 2 -> round 3 on the same command: DeepFM 380 M -> {d['value'] / 1e6:.0f} M examples/s (the whole training step as ONE kernel, rm_deepfm_step: profiles/r03_deepfm_step.md); optimizer step 0.39 -> {o['ms']:.2f} ms (field-segmented sort 152 -> 62 us, long runs in segments: Zipf 0.66 -> 0.34 ms; profiles/r03_optimizer.md); DCN 45.7 M -> {d['workloads']['dcn']['value'] / 1e6:.1f} M (all six dense GEMMs on the bf16 matrix pipe with split fp32 operands, rm_dense_fwd6 / rm_dense_wgrad6: profiles/r03_dense_bf16x6.md); xDeepFM 4.33 M -> {d['workloads']['xdeepfm']['value'] / 1e6:.2f} M (CIN's second layer - forward, dX, dW - on the same scheme, csrc/cin6.hip); configs[4] through the sharded engine at world size 1, per-GPU batch 8192: 7.96 -> {d['workloads']['xdeepfm_100m']['ms_per_step']:.2f} ms; the row-sharded DeepFM step at world size 1 0.366 -> 0.25 ms (profiles/r03_sharded_step.md).
 """
 open(f"profiles/{tag}_summary.md", "w").write(s)
 json.dump(d, open(f"profiles/{tag}_bench_default.json", "w"), indent=1)
