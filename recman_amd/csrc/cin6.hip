@@ -545,7 +545,14 @@ bool rm_internal_cin_dx6(const float *X0, const float *Xk, int64_t xk_bstride, c
 // go to the workspace; cin6_dw_reduce_kernel adds them in split order (deterministic).
 namespace {
 
-constexpr int kDwI = 3;                    // fields per block
+#ifndef RM_CIN_DW6_WAVES
+#define RM_CIN_DW6_WAVES 4  // (8: dM staged half as often, but one block per CU - 2.64 ms against 2.54 ms)
+#endif
+constexpr int kDwI = 3;                    // fields per wave
+constexpr int kDwWaves = RM_CIN_DW6_WAVES; // 4: one block = 3 fields, two blocks per CU; 8: one block = 6 fields (waves
+                                           // 4 .. 7 take the second three), one per CU - dM staged and split half as often
+constexpr int kDwFields = kDwI * (kDwWaves / 4);
+constexpr int kDwUnits = 512 / (64 * kDwWaves);  // dM units (column, 8-row group) per thread and slab
 constexpr int kDwPlane = 128 * 64;         // bytes of one bf16 plane [128 n][32 rows]
 constexpr int kDwBuf = 3 * kDwPlane;       // 24 KiB
 
@@ -560,28 +567,28 @@ struct CinDw6Args {
 };
 
 template <int NH>
-__global__ __launch_bounds__(256, 2) void cin_dw6_kernel(CinDw6Args a) {
+__global__ __launch_bounds__(64 * kDwWaves, kDwWaves == 4 ? 2 : 1) void cin_dw6_kernel(CinDw6Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smemc6[];  // [2][kDwBuf]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, w = wv & 3, r = lane & 15, q = lane >> 4;
   const int D = a.D, H = 32 * NH;
   const int grp = blockIdx.x % a.ngroups, sp = blockIdx.x / a.ngroups;
-  const int i0 = kDwI * grp;
+  const int i0 = kDwFields * grp + kDwI * (wv >> 2);
   const int64_t rows_total = a.B * D;
   constexpr int JW = NH * 2 / 4 > 0 ? NH * 2 / 4 : 1;  // 16-j tiles per wave: H = 64 -> 1, H = 32 -> waves 2, 3 idle
-  const bool wave_on = 16 * w < H;
+  const bool wave_on = 16 * w < H && i0 < a.m;
 
   // dM units of this thread: (column n, 8-row group g), two per slab
-  int un[2], ug[2], ulds[2];
+  int un[kDwUnits], ug[kDwUnits], ulds[kDwUnits];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int u = tid + 256 * k;
+  for (int k = 0; k < kDwUnits; ++k) {
+    const int u = tid + 64 * kDwWaves * k;
     un[k] = u & 127;
     ug[k] = u >> 7;
     ulds[k] = un[k] * 64 + ((ug[k] + (un[k] >> 2)) & 3) * 16;  // (pieces rotated by n / 4: gemm6.hip)
   }
-  auto load_dm = [&](int64_t slab, float (&x)[2][8]) {
+  auto load_dm = [&](int64_t slab, float (&x)[kDwUnits][8]) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < kDwUnits; ++k)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int64_t row = slab * 32 + 8 * ug[k] + e;
@@ -607,9 +614,9 @@ __global__ __launch_bounds__(256, 2) void cin_dw6_kernel(CinDw6Args a) {
       x0v[u][4] = v1.x; x0v[u][5] = v1.y; x0v[u][6] = v1.z; x0v[u][7] = v1.w;
     }
   };
-  auto write_dm = [&](int64_t slab, const float (&x)[2][8], int buf) {
+  auto write_dm = [&](int64_t slab, const float (&x)[kDwUnits][8], int buf) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < kDwUnits; ++k) {
       float y[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) y[e] = (slab * 32 + 8 * ug[k] + e < rows_total) ? x[k][e] : 0.f;
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void cin_dw6_kernel(CinDw6Args a) {
 
   const int64_t s0 = (int64_t)sp * a.slabs_per_split;
   const int64_t s1 = s0 + a.slabs_per_split < a.nslab ? s0 + a.slabs_per_split : a.nslab;
-  float dmr[2][8], xkv[8], x0v[kDwI][8];
+  float dmr[kDwUnits][8], xkv[8], x0v[kDwI][8];
   if (s0 < s1) {
     load_dm(s0, dmr);
     load_z(s0, xkv, x0v);
@@ -713,9 +720,9 @@ struct Dw6Plan {
 };
 Dw6Plan dw6_plan(int64_t B, int m, int D) {
   Dw6Plan p;
-  p.ngroups = (m + kDwI - 1) / kDwI;
+  p.ngroups = (m + kDwFields - 1) / kDwFields;
   p.nslab = (B * D + 31) / 32;
-  int64_t want = 512 / p.ngroups;  // two blocks per CU, one round
+  int64_t want = (kDwWaves == 4 ? 512 : 256) / p.ngroups;  // one round of blocks
   if (want < 1) want = 1;
   if (want > p.nslab) want = p.nslab;
   p.per = (p.nslab + want - 1) / want;
@@ -744,11 +751,11 @@ bool rm_internal_cin_dw6(const float *X0, const float *Xk, int64_t xk_bstride, c
   if (H == 32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dw6_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(cin_dw6_kernel<1>, grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL(cin_dw6_kernel<1>, grid, dim3(64 * kDwWaves), smem, st, a);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dw6_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(cin_dw6_kernel<2>, grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL(cin_dw6_kernel<2>, grid, dim3(64 * kDwWaves), smem, st, a);
   }
   hipLaunchKernelGGL(cin6_dw_reduce_kernel, dim3(rm_grid_cap(((int64_t)m * H * N + 255) / 256, 2048)), dim3(256), 0, st,
                      ws6, m * H, N, p.nsplit, dW);
