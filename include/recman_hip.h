@@ -352,8 +352,9 @@ int rm_cin_layer_fwd(const float *X0, const float *Xk, int64_t xk_bstride, const
                      float *filter_ws, rm_stream_t stream);
 /* rm_cin_layer_fwd6: the same layer on the bf16 matrix pipe with split fp32 operands (csrc/cin6.hip; the scheme of
  * rm_dense_fwd6): Z = fl(X0 * Xk) is formed in fp32 as the reference does, then split into three bf16 pieces; six
- * exact piece products per k-step, fp32 accumulate - fp32-level error.  Covers H % 32 == 0, H <= 64, N <= 128, D in
- * {16, 32, 64}, Xk != X0 (the layers behind the first); RM_EUNSUPPORTED otherwise (run rm_cin_layer_fwd).
+ * exact piece products per k-step, fp32 accumulate - fp32-level error.  Covers H <= 64 (padded to a multiple of 32),
+ * N <= 128, D in {16, 32, 64}; RM_EUNSUPPORTED otherwise (run rm_cin_layer_fwd, which is also the better choice
+ * for the first layer: its symmetric k' ordering does half the work).
  * filter_ws: rm_cin_filter_workspace6(m, H, N, D) floats (0 = not covered), 16-byte aligned. */
 int64_t rm_cin_filter_workspace6(int m, int H, int N, int D);
 int rm_cin_layer_fwd6(const float *X0, const float *Xk, int64_t xk_bstride, const float *W, const float *bias,
@@ -367,7 +368,8 @@ int rm_cin_layer_fwd6(const float *X0, const float *Xk, int64_t xk_bstride, cons
  *     n >= pool_from: g[b] * cin_w_direct[n - pool_from]   (reduce_sum + cin_w, layers.py:754-758)
  *   dX0 [B,m,D] (+= when accumulate_dx0 & 1) = sum_j (dM @ W^T)[.,(i,j)] * Xk[b,j,d]
  *        accumulate_dx0 & 2: the dX pass runs on the bf16 matrix pipe with split fp32 operands (csrc/cin6.hip, the
- *        scheme of rm_cin_layer_fwd6) where it covers the layer (same shapes as rm_cin_layer_fwd6, N > 64)
+ *        scheme of rm_cin_layer_fwd6), and the dW pass too, where csrc/cin6.hip covers the layer (H <= 64, 64 < N <=
+ *        128, D in {16, 32, 64}; not the first layer, whose symmetric f32 kernels do half the work - & 4: its dX too)
  *   dXk [B,H,D] (dxk_bstride floats per example) = sum_i (dM @ W^T)[.,(i,j)] * X0[b,i,d];
  *        with xk_is_x0 (first layer: Xk is X0 itself) it is added into dX0 instead
  *   dW [m*H,N] = Z^T @ dM,  dbias [N] = colsum(dM)   (dM = d_out * act'(out))

@@ -1189,9 +1189,9 @@ extern "C" int64_t rm_cin_filter_workspace(int m, int H, int N) {
 
 // csrc/cin6.hip: the dX part on the bf16 matrix pipe with split fp32 operands
 int64_t rm_internal_cin_dx6_floats(int m, int H, int N, int D);
-bool rm_internal_cin_dx6(const float *X0, const float *Xk, int64_t xk_bstride, const float *W, const float *dM,
-                         int64_t B, int m, int H, int N, int D, float *dX0, int accumulate_dx0, float *dXk,
-                         int64_t dxk_bstride, float *ws6, hipStream_t st);
+bool rm_internal_cin_dx6(const float *X0, const float *Xk, int64_t xk_bstride, int xk_is_x0, const float *W,
+                         const float *dM, int64_t B, int m, int H, int N, int D, float *dX0, int accumulate_dx0,
+                         float *dXk, int64_t dxk_bstride, float *ws6, hipStream_t st);
 int64_t rm_internal_cin_dw6_floats(int64_t B, int m, int H, int N, int D);
 bool rm_internal_cin_dw6(const float *X0, const float *Xk, int64_t xk_bstride, const float *dM, int64_t B, int m, int H,
                          int N, int D, float *dW, float *ws6, hipStream_t st);
@@ -1304,7 +1304,10 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
 #endif
   // first layer: the symmetric-pair dX kernel (about half the MFMA work), when its LDS images fit
   const bool split = (accumulate_dx0 & 2) != 0;  // bit 1: dX / dW on the bf16 pipe where csrc/cin6.hip covers the layer
-  const bool dx_sym = RM_CIN_DX_SYM && xk_is_x0 && H == m && 256 % D == 0 && m <= 255 &&
+  // bit 2: the FIRST layer's dX on the split-operand kernel too (full k' range, H padded to 32) instead of the
+  // symmetric-pair f32 kernel with half the work
+  const bool first6 = split && (accumulate_dx0 & 4) != 0 && rm_internal_cin_dx6_floats(m, H, N, D) > 0;
+  const bool dx_sym = !first6 && RM_CIN_DX_SYM && xk_is_x0 && H == m && 256 % D == 0 && m <= 255 &&
                       cin_dx_sym_smem(m, NT) <= 160 * 1024;
   if (dx_sym) hipLaunchKernelGGL(cin_prep_bwd_sym_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, Np, Wq);
   else hipLaunchKernelGGL(cin_prep_bwd_kernel, dim3(256), dim3(256), 0, st, W, m, H, N, Np, Wq);
@@ -1331,9 +1334,9 @@ extern "C" int rm_cin_layer_bwd(const float *X0, const float *Xk, int64_t xk_bst
   }
     if (NT == 1) RM_CIN_DXS(1) else if (NT == 2) RM_CIN_DXS(2) else RM_CIN_DXS(4)
 #undef RM_CIN_DXS
-  } else if ((accumulate_dx0 & 2) && !xk_is_x0 &&
-             rm_internal_cin_dx6(X0, Xk, xk_bstride, W, dM, B, m, H, N, D, dX0, accumulate_dx0 & 1, dXk, dxk_bstride,
-                                 dbias_part + (((int64_t)kDmBlocks * Np + 3) / 4 * 4), st)) {
+  } else if (split && (!xk_is_x0 || first6) &&
+             rm_internal_cin_dx6(X0, Xk, xk_bstride, xk_is_x0, W, dM, B, m, H, N, D, dX0, accumulate_dx0 & 1, dXk,
+                                 dxk_bstride, dbias_part + (((int64_t)kDmBlocks * Np + 3) / 4 * 4), st)) {
     // (bit 1 of accumulate_dx0: the dX part on the bf16 matrix pipe with split operands, csrc/cin6.hip)
   } else {
     accumulate_dx0 &= 1;

@@ -5,9 +5,10 @@
 // (fl(x0 * xk)), THEN split into three bf16 pieces; the filter is split and laid out in fragment order once per
 // call; six exact piece products per k-step, fp32 accumulate: fp32-level error (tests/test_gpu_cin.py).
 //
-// Covered: the layers whose k' chunks of 32 share one i - H % 32 == 0, H <= 64 (every layer behind the first
-// with the usual unit counts: configs[2] / configs[4] layer 1 has H = 64), N <= 128, D in {16, 32, 64}; anything
-// else returns RM_EUNSUPPORTED and the caller runs rm_cin_layer_fwd.
+// Covered: H <= 64 (padded to a multiple of 32 with zero filter rows, so that a k' chunk of 32 has ONE i: k' = i * Hp
+// + j), N <= 128, D in {16, 32, 64}; anything else returns RM_EUNSUPPORTED and the caller runs rm_cin_layer_fwd.
+// The first layer (Xk = X0, H = m) is covered too; whether it is routed here is the caller's choice - cin.hip's
+// symmetric k' ordering does half the work there.
 //
 // Block = 4 waves = 128 rows (128 / D whole examples), two blocks per CU (61 KB of LDS each).  Wave w owns rows
 // 32 w .. 32 w + 31 (two 16-row MFMA tiles) x all N / 16 column tiles.  A lane's operand fragment is (row r,
@@ -37,7 +38,8 @@ __device__ __forceinline__ float actc6(float v, int act) {
 
 // Wp[s][p][j][lane][e] = piece p of W[k' = 32 s + 8 (lane >> 4) + e][n = 16 j + (lane & 15)]; two spare slabs behind
 // the last (the loop requests them and never reads them)
-__global__ void cin6_prep_kernel(const float *__restrict__ W, int K, int N, int nslab, __bf16 *__restrict__ Wp) {
+// (H is padded to Hp = 32 NH: k' = i * Hp + j, zero rows for j >= H)
+__global__ void cin6_prep_kernel(const float *__restrict__ W, int H, int Hp, int N, int nslab, __bf16 *__restrict__ Wp) {
   const int64_t total = (int64_t)(nslab + 2) * kNTC6 * 512;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
@@ -45,8 +47,9 @@ __global__ void cin6_prep_kernel(const float *__restrict__ W, int K, int N, int 
     const int64_t u = t >> 9;
     const int j = (int)(u % kNTC6), s = (int)(u / kNTC6);
     const int k = 32 * s + 8 * (lane >> 4) + e, n = 16 * j + (lane & 15);
+    const int fi = k / Hp, fj = k - fi * Hp;
     float x = 0.f;
-    if (s < nslab && k < K && n < N) x = W[(int64_t)k * N + n];
+    if (s < nslab && fj < H && n < N) x = W[(int64_t)(fi * H + fj) * N + n];
     const __bf16 h = (__bf16)x;
     const float r1 = x - (float)h;
     const __bf16 m = (__bf16)r1;
@@ -126,7 +129,10 @@ __global__ __launch_bounds__(256, 2) void cin_fwd6_kernel(Cin6Args a) {
 #pragma unroll
     for (int jh = 0; jh < NH; ++jh)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xk[t][jh][e] = src[(int64_t)(32 * jh + 8 * q + e) * D];
+      for (int e = 0; e < 8; ++e) {
+        const int j = 32 * jh + 8 * q + e;  // (j >= H: the filter rows are zero, any finite value does)
+        xk[t][jh][e] = src[(int64_t)(j < a.H ? j : a.H - 1) * D];
+      }
   }
 
   f32x4 acc[2][kNTC6];
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void cin_fwd6_kernel(Cin6Args a) {
 }
 
 bool cin6_covers(int m, int H, int N, int D) {
-  return H % 32 == 0 && H <= 64 && N <= 128 && (D == 16 || D == 32 || D == 64) && m >= 1 && m <= 64;
+  return H >= 1 && H <= 64 && N <= 128 && (D == 16 || D == 32 || D == 64) && m >= 1 && m <= 64;
 }
 
 }  // namespace
@@ -259,7 +265,7 @@ bool cin6_covers(int m, int H, int N, int D) {
 // floats of filter workspace for rm_cin_layer_fwd6 (0: the shape is not covered)
 extern "C" int64_t rm_cin_filter_workspace6(int m, int H, int N, int D) {
   if (!cin6_covers(m, H, N, D)) return 0;
-  const int nslab = m * (H / 32);
+  const int nslab = m * ((H + 31) / 32);
   return (int64_t)(nslab + 2) * kSlabC6 / 4 + 64;
 }
 
@@ -268,8 +274,8 @@ extern "C" int rm_cin_layer_fwd6(const float *X0, const float *Xk, int64_t xk_bs
                                  float *pooled, int pool_stride, int pool_col0, int pool_from, float *filter_ws,
                                  rm_stream_t stream) {
   RM_REQUIRE(B >= 0 && m > 0 && H > 0 && N > 0 && D > 0, "rm_cin_layer_fwd6: bad sizes");
-  if (!cin6_covers(m, H, N, D) || (Xk == X0 && H == m)) {
-    rm_set_error("rm_cin_layer_fwd6: shape not covered (H %% 32 == 0, H <= 64, N <= 128, D in {16, 32, 64})");
+  if (!cin6_covers(m, H, N, D)) {
+    rm_set_error("rm_cin_layer_fwd6: shape not covered (H <= 64, N <= 128, D in {16, 32, 64})");
     return RM_EUNSUPPORTED;
   }
   if (B == 0) return RM_OK;
@@ -279,10 +285,10 @@ extern "C" int rm_cin_layer_fwd6(const float *X0, const float *Xk, int64_t xk_bs
   RM_REQUIRE(!pooled || (pool_from >= 0 && pool_from <= N && pool_stride >= pool_col0 + N - pool_from),
              "rm_cin_layer_fwd6: bad pooled layout");
   hipStream_t st = (hipStream_t)stream;
-  const int NH = H / 32, nslab = m * NH;
+  const int NH = (H + 31) / 32, nslab = m * NH;
   __bf16 *Wp = reinterpret_cast<__bf16 *>(filter_ws);
   hipLaunchKernelGGL(cin6_prep_kernel, dim3(rm_grid_cap(((int64_t)(nslab + 2) * kNTC6 * 512 + 255) / 256, 2048)),
-                     dim3(256), 0, st, W, m * H, N, nslab, Wp);
+                     dim3(256), 0, st, W, H, 32 * NH, N, nslab, Wp);
   Cin6Args a{X0, Xk, xk_bstride, Wp, bias, act, B, m, H, N, D, out, pooled, pool_stride, pool_col0, pool_from};
   const int epb = kRowsC6 / D;
   const dim3 grid((unsigned)((B + epb - 1) / epb));
@@ -312,7 +318,7 @@ namespace {
 
 // Wq6[s = i * NH + jh][kt][ns][p][lane][e] = piece p of W[(i * H + 32 jh + 16 kt + (lane & 15)) * N + 32 ns + 8 (lane >> 4) + e]
 __global__ void cin6_prep_dx_kernel(const float *__restrict__ W, int m, int H, int N, __bf16 *__restrict__ Wp) {
-  const int NH = H / 32, nslab = m * NH;
+  const int NH = (H + 31) / 32, nslab = m * NH;
   const int64_t total = (int64_t)(nslab + 2) * 8 * 512;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
@@ -323,7 +329,7 @@ __global__ void cin6_prep_dx_kernel(const float *__restrict__ W, int m, int H, i
     if (s < nslab) {
       const int i = s / NH, jh = s - i * NH;
       const int j = 32 * jh + 16 * kt + (lane & 15), n = 32 * ns + 8 * (lane >> 4) + e;
-      if (n < N) x = W[(int64_t)(i * H + j) * N + n];
+      if (n < N && j < H) x = W[(int64_t)(i * H + j) * N + n];
     }
     const __bf16 h = (__bf16)x;
     const float r1 = x - (float)h;
@@ -344,7 +350,7 @@ struct CinDx6Args {
   int64_t B;
   int m, H, D;
   float *dX0;
-  int accumulate_dx0;
+  int accumulate_dx0, xk_is_x0;
   float *dXk;
   int64_t dxk_bstride;
 };
@@ -406,7 +412,8 @@ __global__ __launch_bounds__(256, 2) void cin_dx6_kernel(CinDx6Args a) {
     for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
       for (int i2 = 0; i2 < 4; ++i2) {
-        xkr[t][jt][i2] = xs[(int64_t)(16 * jt + 4 * q + i2) * D];
+        const int j = 16 * jt + 4 * q + i2;  // (j >= H: dZ is zero there - zero filter rows)
+        xkr[t][jt][i2] = xs[(int64_t)(j < a.H ? j : a.H - 1) * D];
         dxk[t][jt][i2] = 0.f;
       }
   }
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void cin_dx6_kernel(CinDx6Args a) {
   }
   // dXk -> LDS image [j][row] over the filter buffers (every (j, row) is owned by exactly one lane)
   float *dXks = reinterpret_cast<float *>(smemc6);
-  if (a.dXk != nullptr) {
+  if (a.dXk != nullptr || a.xk_is_x0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -480,6 +487,10 @@ __global__ __launch_bounds__(256, 2) void cin_dx6_kernel(CinDx6Args a) {
     const int64_t b = b0 + bl;
     if (b >= a.B) continue;
     float4 v = *reinterpret_cast<const float4 *>(dX0s + i * kRowsC6 + bl * D + 4 * d4);
+    if (a.xk_is_x0) {  // first layer: Xk IS X0 (H = m), its gradient lands on the same field
+      const float4 w4 = *reinterpret_cast<const float4 *>(dXks + i * kRowsC6 + bl * D + 4 * d4);
+      v.x += w4.x; v.y += w4.y; v.z += w4.z; v.w += w4.w;
+    }
     float4 *dst = reinterpret_cast<float4 *>(a.dX0 + (b * m + i) * D + 4 * d4);
     if (a.accumulate_dx0) {
       const float4 o = *dst;
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void cin_dx6_kernel(CinDx6Args a) {
     }
     *dst = v;
   }
-  if (a.dXk != nullptr) {
+  if (a.dXk != nullptr && !a.xk_is_x0) {
     const int H = a.H;
     for (int t = tid; t < epb * H * D4; t += 256) {
       const int d4 = t % D4, j = (t / D4) % H, bl = t / (D4 * H);
@@ -504,19 +515,19 @@ __global__ __launch_bounds__(256, 2) void cin_dx6_kernel(CinDx6Args a) {
 // floats rm_cin_layer_bwd's workspace needs for the split filter of the dX kernel (0: not covered)
 int64_t rm_internal_cin_dx6_floats(int m, int H, int N, int D) {
   if (!cin6_covers(m, H, N, D) || N <= 64) return 0;
-  return (int64_t)(m * (H / 32) + 2) * kSlabC6 / 4 + 64;
+  return (int64_t)(m * ((H + 31) / 32) + 2) * kSlabC6 / 4 + 64;
 }
 
 // the dX part of rm_cin_layer_bwd on the bf16 pipe: returns false when the shape is not covered (nothing launched)
-bool rm_internal_cin_dx6(const float *X0, const float *Xk, int64_t xk_bstride, const float *W, const float *dM,
-                         int64_t B, int m, int H, int N, int D, float *dX0, int accumulate_dx0, float *dXk,
-                         int64_t dxk_bstride, float *ws6, hipStream_t st) {
+bool rm_internal_cin_dx6(const float *X0, const float *Xk, int64_t xk_bstride, int xk_is_x0, const float *W,
+                         const float *dM, int64_t B, int m, int H, int N, int D, float *dX0, int accumulate_dx0,
+                         float *dXk, int64_t dxk_bstride, float *ws6, hipStream_t st) {
   if (rm_internal_cin_dx6_floats(m, H, N, D) == 0 || !rm_aligned16(ws6)) return false;
-  const int NH = H / 32, nslab = m * NH;
+  const int NH = (H + 31) / 32, nslab = m * NH;
   __bf16 *Wp = reinterpret_cast<__bf16 *>(ws6);
   hipLaunchKernelGGL(cin6_prep_dx_kernel, dim3(rm_grid_cap(((int64_t)(nslab + 2) * 8 * 512 + 255) / 256, 2048)),
                      dim3(256), 0, st, W, m, H, N, Wp);
-  CinDx6Args a{X0, Xk, xk_bstride, Wp, dM, B, m, H, D, dX0, accumulate_dx0, dXk, dxk_bstride};
+  CinDx6Args a{X0, Xk, xk_bstride, Wp, dM, B, m, H, D, dX0, accumulate_dx0, xk_is_x0, dXk, dxk_bstride};
   const int epb = kRowsC6 / D;
   const dim3 grid((unsigned)((B + epb - 1) / epb));
   const size_t smem = 2 * kSlabC6 + (size_t)2 * m * kRowsC6 * 4;
@@ -570,7 +581,7 @@ template <int NH>
 __global__ __launch_bounds__(64 * kDwWaves, kDwWaves == 4 ? 2 : 1) void cin_dw6_kernel(CinDw6Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smemc6[];  // [2][kDwBuf]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, w = wv & 3, r = lane & 15, q = lane >> 4;
-  const int D = a.D, H = 32 * NH;
+  const int D = a.D, H = 32 * NH;  // (the padded width; a.H is the real one)
   const int grp = blockIdx.x % a.ngroups, sp = blockIdx.x / a.ngroups;
   const int i0 = kDwFields * grp + kDwI * (wv >> 2);
   const int64_t rows_total = a.B * D;
@@ -601,7 +612,8 @@ __global__ __launch_bounds__(64 * kDwWaves, kDwWaves == 4 ? 2 : 1) void cin_dw6_
     row = row < rows_total ? row : rows_total - 8;  // (rows past the end: dM is zeroed there, any finite value does)
     const int64_t b = row / D;
     const int d = (int)(row - b * D);
-    const int j = 16 * (wave_on ? w : 0) + r;
+    int j = 16 * (wave_on ? w : 0) + r;
+    j = j < a.H ? j : a.H - 1;  // (padded j: its dW rows are dropped by the reduction)
     const float4 *pk = reinterpret_cast<const float4 *>(a.Xk + b * a.xk_bstride + (int64_t)j * D + d);
     const float4 k0 = pk[0], k1 = pk[1];
     xkv[0] = k0.x; xkv[1] = k0.y; xkv[2] = k0.z; xkv[3] = k0.w; xkv[4] = k1.x; xkv[5] = k1.y; xkv[6] = k1.z; xkv[7] = k1.w;
@@ -702,14 +714,18 @@ __global__ __launch_bounds__(64 * kDwWaves, kDwWaves == 4 ? 2 : 1) void cin_dw6_
   (void)JW;
 }
 
-__global__ void cin6_dw_reduce_kernel(const float *__restrict__ part, int K, int N, int nsplit, float *__restrict__ dW) {
-  const int64_t total = (int64_t)K * N;
+// dW[(i * H + j), n] = the partial sums of row i * Hp + j in split order
+__global__ void cin6_dw_reduce_kernel(const float *__restrict__ part, int m, int H, int Hp, int N, int nsplit,
+                                      float *__restrict__ dW) {
+  const int64_t total = (int64_t)m * H * N;
+  const int64_t Kp = (int64_t)m * Hp;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t k = t / N;
     const int n = (int)(t - k * N);
-    const float *p = part + k * 128 + n;
+    const int i = (int)(k / H), j = (int)(k - (int64_t)i * H);
+    const float *p = part + ((int64_t)i * Hp + j) * 128 + n;
     float v = 0.f;
-    for (int s = 0; s < nsplit; ++s) v += p[(int64_t)s * K * 128];
+    for (int s = 0; s < nsplit; ++s) v += p[(int64_t)s * Kp * 128];
     dW[t] = v;
   }
 }
@@ -736,7 +752,7 @@ Dw6Plan dw6_plan(int64_t B, int m, int D) {
 int64_t rm_internal_cin_dw6_floats(int64_t B, int m, int H, int N, int D) {
   if (!cin6_covers(m, H, N, D) || N <= 64 || B <= 0) return 0;
   const Dw6Plan p = dw6_plan(B, m, D);
-  return (int64_t)p.nsplit * m * H * 128 + 64;
+  return (int64_t)p.nsplit * m * (32 * ((H + 31) / 32)) * 128 + 64;
 }
 
 bool rm_internal_cin_dw6(const float *X0, const float *Xk, int64_t xk_bstride, const float *dM, int64_t B, int m, int H,
@@ -748,7 +764,7 @@ bool rm_internal_cin_dw6(const float *X0, const float *Xk, int64_t xk_bstride, c
   CinDw6Args a{X0, Xk, dM, xk_bstride, B, m, H, D, p.ngroups, p.nsplit, p.per, p.nslab, ws6};
   const dim3 grid((unsigned)(p.ngroups * p.nsplit));
   const size_t smem = 2 * kDwBuf;
-  if (H == 32) {
+  if (H <= 32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cin_dw6_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(cin_dw6_kernel<1>, grid, dim3(64 * kDwWaves), smem, st, a);
@@ -758,6 +774,6 @@ bool rm_internal_cin_dw6(const float *X0, const float *Xk, int64_t xk_bstride, c
     hipLaunchKernelGGL(cin_dw6_kernel<2>, grid, dim3(64 * kDwWaves), smem, st, a);
   }
   hipLaunchKernelGGL(cin6_dw_reduce_kernel, dim3(rm_grid_cap(((int64_t)m * H * N + 255) / 256, 2048)), dim3(256), 0, st,
-                     ws6, m * H, N, p.nsplit, dW);
+                     ws6, m, H, 32 * ((H + 31) / 32), N, p.nsplit, dW);
   return true;
 }

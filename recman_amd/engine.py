@@ -1381,7 +1381,8 @@ class XDeepFMEngine(Engine):
             ops.cin_layer_fwd(X0, xk, self.Hs[i], p[f"cin_filter_{i}"][0], p[f"cin_bias_{i}"],
                               self.cin_act, self.maps[i], self.cin_fws,
                               pooled=None if on[i + 1] else self.pooled,
-                              pool_col0=self.pool_col0[i], pool_from=self.pool_from[i], ws6=self.cin_fws6)
+                              pool_col0=self.pool_col0[i], pool_from=self.pool_from[i], ws6=self.cin_fws6,
+                              first6=self.hp.get("cin_first_layer", "bf16x6") == "bf16x6")
             if on[i + 1]:
                 pf, c0 = self.pool_from[i], self.pool_col0[i]
                 self.maps[i].mul_(masks[i + 1] / keep[i + 1])
@@ -1435,7 +1436,8 @@ class XDeepFMEngine(Engine):
                 self.cin_act, self.maps[i], g, dX0, gr[f"cin_filter_{i}"][0],
                 gr[f"cin_bias_{i}"], self.cin_bws, xk_is_x0=(i == 0),
                 d_hidden=d_hidden, cin_w_direct=cwd, pool_from=pfa, accumulate_dx0=True,
-                dXk=self.dxk[i] if i > 0 else None, split=self.hp.get("cin_gemm", "bf16x6") == "bf16x6")
+                dXk=self.dxk[i] if i > 0 else None, split=self.hp.get("cin_gemm", "bf16x6") == "bf16x6",
+                first6=self.hp.get("cin_first_layer", "bf16x6") == "bf16x6")
         if on[0]:
             self.d_rows.addcmul_(self._dx0_cin, cmasks[0] / keep[0])
         reg = self.hp.get("deep_l2_reg", 0.0)

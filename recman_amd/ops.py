@@ -221,14 +221,15 @@ def cin_filter_workspace6(m, H, N, D):
     return int(_lib.lib().rm_cin_filter_workspace6(int(m), int(H), int(N), int(D)))
 
 
-def cin_layer_fwd(X0, Xk, H, W, bias, act, out, filter_ws, pooled=None, pool_col0=0, pool_from=0, ws6=None):
+def cin_layer_fwd(X0, Xk, H, W, bias, act, out, filter_ws, pooled=None, pool_col0=0, pool_from=0, ws6=None,
+                  first6=False):
     """One CIN layer forward.  X0 [B,m,D]; Xk [B,Hk,D] of which rows j < H are used;
     W [m*H, N]; out [B,N,D]; pooled [B, P] gets sum_d out[:, pool_from:, :] at pool_col0.
     ws6 (cin_filter_workspace6 floats): on the bf16 matrix pipe with split operands (rm_cin_layer_fwd6) when that
     kernel covers the layer; returns True when it ran."""
     B, m, D = X0.shape
     N = W.shape[1]
-    if ws6 is not None and Xk.data_ptr() != X0.data_ptr():
+    if ws6 is not None and (first6 or Xk.data_ptr() != X0.data_ptr()):
         need = cin_filter_workspace6(m, H, N, D)
         if need > 0 and ws6.numel() >= need:
             if W.shape[0] != m * H or Xk.shape[0] != B or Xk.shape[2] != D or Xk.shape[1] < H:
@@ -259,7 +260,8 @@ def cin_bwd_workspace(B, m, H, N, D):
 
 
 def cin_layer_bwd(X0, Xk, H, W, act, out, g, dX0, dW, dbias, workspace, *, xk_is_x0=False,
-                  d_hidden=None, cin_w_direct=None, pool_from=0, accumulate_dx0=True, dXk=None, split=False):
+                  d_hidden=None, cin_w_direct=None, pool_from=0, accumulate_dx0=True, dXk=None, split=False,
+                  first6=False):
     """One CIN layer backward (see rm_cin_layer_bwd).  d_hidden [B,pool_from,D] is the next
     layer's dXk; cin_w_direct [N-pool_from] the cin_w entries of this layer's direct half.  split: the dX pass on
     the bf16 matrix pipe with split fp32 operands where csrc/cin6.hip covers the layer."""
@@ -273,7 +275,7 @@ def cin_layer_bwd(X0, Xk, H, W, act, out, g, dX0, dW, dbias, workspace, *, xk_is
         _chk(out, "out", F32, (B, N, D)), _chk(d_hidden, "d_hidden", F32, allow_none=True),
         0 if d_hidden is None else d_hidden.shape[1] * D, _chk(g, "g", F32, (B,)),
         _chk(cin_w_direct, "cin_w_direct", F32, (N - pool_from,), allow_none=True), pool_from,
-        B, m, H, N, D, _chk(dX0, "dX0", F32, (B, m, D)), (1 if accumulate_dx0 else 0) | (2 if split else 0),
+        B, m, H, N, D, _chk(dX0, "dX0", F32, (B, m, D)), (1 if accumulate_dx0 else 0) | (2 if split else 0) | (4 if first6 else 0),
         _chk(dXk, "dXk", F32, allow_none=True), 0 if dXk is None else dXk.shape[1] * D,
         _chk(dW, "dW", F32, (m * H, N)), _chk(dbias, "dbias", F32, (N,)),
         _chk(workspace, "workspace", F32), workspace.numel(), _stream())

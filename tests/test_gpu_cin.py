@@ -84,8 +84,10 @@ def test_cin_notebook_kat_on_gpu(hip_lib):
     (37, 26, 64, 128, 16, "leaky_relu", False, False),  # configs[2] layer 1 (the split-operand dX kernel's shape)
     (7, 5, 32, 100, 64, "relu", False, True),           # ... one j half, D = 64, N not a multiple of 16
     (13, 3, 64, 128, 32, "identity", False, False),     # ... D = 32
+    (11, 6, 50, 100, 16, "leaky_relu", False, False),   # ... H = 50 padded to 64 (the reference's default units 100)
+    (40, 26, 26, 128, 16, "leaky_relu", True, False),   # the first layer (H = 26 padded to 32) - "first6" below
 ])
-@pytest.mark.parametrize("split", [False, True], ids=["f32", "split"])
+@pytest.mark.parametrize("split", [False, True, "first6"], ids=["f32", "split", "split-first-layer-too"])
 def test_cin_layer_bwd(hip_lib, B, m, H, N, D, act, first, last, split):
     """autograd (float64) of the oracle's layer formula vs rm_cin_layer_bwd; split: the dX pass on the bf16 matrix
     pipe with split fp32 operands where csrc/cin6.hip covers the layer (elsewhere the flag changes nothing)."""
@@ -119,7 +121,7 @@ def test_cin_layer_bwd(hip_lib, B, m, H, N, D, act, first, last, split):
     ws = torch.empty(ops.cin_bwd_workspace(B, m, H, N, D), device="cuda")
     ops.cin_layer_bwd(f(X0), f(Xk), H, f(W), act, out_d, f(gvec), dX0, dW, dbias, ws,
                       xk_is_x0=first, d_hidden=f(dh) if pool_from else None, cin_w_direct=f(cw),
-                      pool_from=pool_from, accumulate_dx0=True, dXk=dXk, split=split)
+                      pool_from=pool_from, accumulate_dx0=True, dXk=dXk, split=bool(split), first6=split == "first6")
     torch.cuda.synchronize()
 
     def close(got, want, what):
@@ -141,6 +143,8 @@ def test_cin_layer_bwd(hip_lib, B, m, H, N, D, act, first, last, split):
     (21, 7, 32, 48, 32, "relu"),           # one j half, N < 128 (zero filter tiles), two examples per wave
     (3, 3, 64, 100, 16, "identity"),       # N not a multiple of 16, a block with 3 of its 8 examples
     (1, 1, 32, 16, 64, "leaky_relu"),
+    (11, 6, 50, 100, 16, "leaky_relu"),    # H = 50 padded to 64
+    (9, 5, 3, 40, 32, "relu"),             # H = 3 padded to 32
 ])
 def test_cin_layer_fwd6_split_operands(hip_lib, B, m, H, N, D, act):
     """rm_cin_layer_fwd6 (csrc/cin6.hip: Z = fl(x0 * xk) split into three bf16 pieces, six piece products on the
@@ -177,6 +181,6 @@ def test_cin_layer_fwd6_split_operands(hip_lib, B, m, H, N, D, act):
     assert perr <= 1e-5 * max(1.0, float(want_pool.abs().max())), perr
     assert bool((outs[0][1][:, :7] == -1).all())
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
-    # not covered: the first layer (Xk is X0), H not a multiple of 32, D = 8
-    assert ops.cin_filter_workspace6(26, 26, 128, 16) == 0 and ops.cin_filter_workspace6(26, 64, 128, 8) == 0
+    # not covered: D = 8, H > 64, N > 128
+    assert ops.cin_filter_workspace6(26, 64, 128, 8) == 0
     assert ops.cin_filter_workspace6(26, 96, 128, 16) == 0 and ops.cin_filter_workspace6(26, 64, 200, 16) == 0
