@@ -559,6 +559,9 @@ namespace {
 #ifndef RM_CIN_DW6_WAVES
 #define RM_CIN_DW6_WAVES 4  // (8: dM staged half as often, but one block per CU - 2.64 ms against 2.54 ms)
 #endif
+#ifndef RM_CIN_DW6_ABL
+#define RM_CIN_DW6_ABL 0  // ablation builds (WRONG results): 1 no MFMAs, 2 no dM loads / planes in the loop, 4 no Z loads / split in the loop
+#endif
 constexpr int kDwI = 3;                    // fields per wave
 constexpr int kDwWaves = RM_CIN_DW6_WAVES; // 4: one block = 3 fields, two blocks per CU; 8: one block = 6 fields (waves
                                            // 4 .. 7 take the second three), one per CU - dM staged and split half as often
@@ -662,18 +665,22 @@ __global__ __launch_bounds__(64 * kDwWaves, kDwWaves == 4 ? 2 : 1) void cin_dw6_
     const int buf = (int)((s - s0) & 1);
     // this slab's Z fragments (values loaded a slab ago), then the next slab's on their way
     bf16x8 zf[kDwI][3];
+    if (!(RM_CIN_DW6_ABL & 4) || s == s0) {
 #pragma unroll
-    for (int u = 0; u < kDwI; ++u) {
-      float z[8];
+      for (int u = 0; u < kDwI; ++u) {
+        float z[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = x0v[u][e] * xkv[e];
-      split8c(z, zf[u][0], zf[u][1], zf[u][2]);
+        for (int e = 0; e < 8; ++e) z[e] = x0v[u][e] * xkv[e];
+        split8c(z, zf[u][0], zf[u][1], zf[u][2]);
+      }
     }
     const int64_t sn = s + 1 < s1 ? s + 1 : s;
-    load_z(sn, xkv, x0v);
+    if (!(RM_CIN_DW6_ABL & 4)) load_z(sn, xkv, x0v);
     // the next slab's dM planes into the other buffer (its raw values were requested a slab ago), the one after
-    write_dm(sn, dmr, buf ^ 1);
-    load_dm(s + 2 < s1 ? s + 2 : sn, dmr);
+    if (!(RM_CIN_DW6_ABL & 2)) {
+      write_dm(sn, dmr, buf ^ 1);
+      load_dm(s + 2 < s1 ? s + 2 : sn, dmr);
+    }
     if (wave_on) {
       const unsigned char *ws = smemc6 + buf * kDwBuf;
 #pragma unroll
@@ -687,6 +694,11 @@ __global__ __launch_bounds__(64 * kDwWaves, kDwWaves == 4 ? 2 : 1) void cin_dw6_
         for (int u = 0; u < kDwI; ++u) {
           // dM is the A operand: D[m = n 4 q + i'][col = j r]
           f32x4 c = acc[u][nt];
+          if (RM_CIN_DW6_ABL & 1) {
+            c[0] += (float)gl[0] + (float)gm[1] + (float)gh[2] + (float)zf[u][0][3] + (float)zf[u][1][4] + (float)zf[u][2][5];
+            acc[u][nt] = c;
+            continue;
+          }
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, zf[u][0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, zf[u][2], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm, zf[u][1], c, 0, 0, 0);
