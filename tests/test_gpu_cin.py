@@ -86,6 +86,9 @@ def test_cin_notebook_kat_on_gpu(hip_lib):
     (13, 3, 64, 128, 32, "identity", False, False),     # ... D = 32
     (11, 6, 50, 100, 16, "leaky_relu", False, False),   # ... H = 50 padded to 64 (the reference's default units 100)
     (40, 26, 26, 128, 16, "leaky_relu", True, False),   # the first layer (H = 26 padded to 32) - "first6" below
+    (1, 2, 5, 128, 16, "relu", False, True),            # one example: half a row slab, most of every tile empty
+    (3, 1, 1, 70, 64, "leaky_relu", False, False),      # m = H = 1 (not Xk = X0), N = 70 (> 64: the split dX / dW take it)
+    (129, 4, 33, 128, 32, "identity", False, False),    # H = 33 padded to 64; a last block with one example
 ])
 @pytest.mark.parametrize("split", [False, True, "first6"], ids=["f32", "split", "split-first-layer-too"])
 def test_cin_layer_bwd(hip_lib, B, m, H, N, D, act, first, last, split):
