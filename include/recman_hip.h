@@ -424,11 +424,14 @@ int64_t rm_dense6_workspace(int K, int N, int64_t M);
 /* rm_dense_wgrad6: rm_dense_wgrad (dW[K,N] (+)= [A1 | A2]^T . G, db[N] = column sums of G or NULL) on the same
  * scheme: both activations split into bf16 pieces on the fly, once per block and 32-row slab, through transposed
  * LDS planes; partial tiles per batch split in the workspace, added in split order (deterministic).  Any K / N /
- * strides.  workspace: rm_dense_wgrad6_workspace(K, N, M) floats, 16-byte aligned. */
+ * strides.  G2 [M, N2] + dW2 [K, N2] (or NULL / 0): a second piece of gradient columns against the SAME activations in
+ * the same pass (DCN: the cross net's coefficient columns beside the first dense layer's dA - x0 read once).
+ * workspace: rm_dense_wgrad6_workspace(K, N + N2, M) floats, 16-byte aligned. */
 int64_t rm_dense_wgrad6_workspace(int K, int N, int64_t M);
 int rm_dense_wgrad6(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2, const float *G,
-                    int64_t ldg, int N, int64_t M, float *dW, int64_t lddw, int accumulate, float *db,
-                    float *workspace, int64_t workspace_floats, rm_stream_t stream);
+                    int64_t ldg, int N, const float *G2, int64_t ldg2, int N2, int64_t M, float *dW, int64_t lddw,
+                    float *dW2, int64_t lddw2, int accumulate, float *db, float *workspace,
+                    int64_t workspace_floats, rm_stream_t stream);
 int rm_dense_fwd6(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2, const float *W,
                   int64_t ldw, int w_transposed, int N, const float *bias, int epilogue, int act,
                   const float *aux1, int64_t ld_aux1, int64_t M, float *C, int64_t ldc, const float *dot_w,

@@ -85,7 +85,8 @@ SIGNATURES = {
     "rm_dense_fwd6": [P, I64, c_int, P, I64, c_int, P, I64, c_int, c_int, P, c_int, c_int, P, I64, I64, P, I64,
                       P, P, P, P, P],
     "rm_dense_wgrad": [P, I64, c_int, P, I64, c_int, P, I64, c_int, I64, P, I64, c_int, P, P, I64, P],
-    "rm_dense_wgrad6": [P, I64, c_int, P, I64, c_int, P, I64, c_int, I64, P, I64, c_int, P, P, I64, P],
+    "rm_dense_wgrad6": [P, I64, c_int, P, I64, c_int, P, I64, c_int, P, I64, c_int, I64, P, I64, P, I64, c_int, P, P,
+                        I64, P],
 }
 
 

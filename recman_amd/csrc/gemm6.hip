@@ -477,9 +477,9 @@ constexpr int kTnPlaneA = kTnKC * 64, kTnPlaneG = kTnNC * 64;   // bytes of one 
 constexpr int kTnLds = 3 * (kTnPlaneA + kTnPlaneG);             // 82,944
 
 struct TN6Args {
-  const float *A1, *A2, *G;
-  int64_t lda1, lda2, ldg;
-  int K1, K2, N;
+  const float *A1, *A2, *G, *G2;  // G2 [M, N2]: a second piece of gradient columns behind G's N (or NULL)
+  int64_t lda1, lda2, ldg, ldg2;
+  int K1, K2, N, N2;
   int64_t M;
   int nkh, nnh, nsplit;
   int64_t slabs_per_split, nslab;
@@ -517,7 +517,9 @@ __global__ __launch_bounds__(512) void dense_tn6_kernel(TN6Args a) {
     const float *p;
     int64_t ld;
     bool live;
-    if (isg) { live = c < a.N; p = a.G + (live ? c : 0); ld = a.ldg; }
+    if (isg && c < a.N) { live = true; p = a.G + c; ld = a.ldg; }
+    else if (isg && c < a.N + a.N2) { live = true; p = a.G2 + (c - a.N); ld = a.ldg2; }
+    else if (isg) { live = false; p = a.G; ld = a.ldg; }
     else if (c < a.K1) { live = true; p = a.A1 + c; ld = a.lda1; }
     else if (c < K) { live = true; p = a.A2 + (c - a.K1); ld = a.lda2; }
     else { live = false; p = a.A1; ld = a.lda1; }
@@ -639,21 +641,24 @@ __global__ __launch_bounds__(512) void dense_tn6_kernel(TN6Args a) {
   }
 }
 
-// dW[k][n] (+)= sum over the splits (in order) of the partial tiles; db[n] likewise
+// dW[k][n] (+)= sum over the splits (in order) of the partial tiles; db[n] likewise; the columns behind N (a second
+// piece of gradient columns) go to dW2[k][n - N]
 __global__ void dense6_tn_reduce_kernel(const float *__restrict__ part, const float *__restrict__ db_part, int K,
-                                        int N, int nkh, int nnh, int nsplit, float *__restrict__ dW, int64_t lddw,
-                                        int accumulate, float *__restrict__ db) {
-  const int64_t total = (int64_t)K * N;
+                                        int N, int N2, int nkh, int nnh, int nsplit, float *__restrict__ dW,
+                                        int64_t lddw, float *__restrict__ dW2, int64_t lddw2, int accumulate,
+                                        float *__restrict__ db) {
+  const int Nt = N + N2;
+  const int64_t total = (int64_t)K * Nt;
   const int64_t tile = (int64_t)kTnKC * kTnNC;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total + N;
        t += (int64_t)gridDim.x * blockDim.x) {
     if (t < total) {
-      const int k = (int)(t / N), n = (int)(t % N);
+      const int k = (int)(t / Nt), n = (int)(t % Nt);
       const int kh = k / kTnKC, nh = n / kTnNC;
       const float *p = part + ((int64_t)kh * nnh + nh) * tile + (int64_t)(k % kTnKC) * kTnNC + n % kTnNC;
       float v = 0.f;
       for (int s = 0; s < nsplit; ++s) v += p[(int64_t)s * nkh * nnh * tile];
-      float *d = dW + (int64_t)k * lddw + n;
+      float *d = n < N ? dW + (int64_t)k * lddw + n : dW2 + (int64_t)k * lddw2 + (n - N);
       *d = accumulate ? *d + v : v;
     } else if (db != nullptr) {
       const int n = (int)(t - total);
@@ -693,26 +698,31 @@ extern "C" int64_t rm_dense_wgrad6_workspace(int K, int N, int64_t M) {
 }
 
 extern "C" int rm_dense_wgrad6(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2,
-                               const float *G, int64_t ldg, int N, int64_t M, float *dW, int64_t lddw,
-                               int accumulate, float *db, float *workspace, int64_t workspace_floats,
-                               rm_stream_t stream) {
-  RM_REQUIRE(M >= 0 && K1 > 0 && K2 >= 0 && N > 0, "rm_dense_wgrad6: bad sizes");
+                               const float *G, int64_t ldg, int N, const float *G2, int64_t ldg2, int N2, int64_t M,
+                               float *dW, int64_t lddw, float *dW2, int64_t lddw2, int accumulate, float *db,
+                               float *workspace, int64_t workspace_floats, rm_stream_t stream) {
+  RM_REQUIRE(M >= 0 && K1 > 0 && K2 >= 0 && N > 0 && N2 >= 0, "rm_dense_wgrad6: bad sizes");
   RM_REQUIRE(A1 && G && dW && workspace && rm_aligned16(workspace), "rm_dense_wgrad6: NULL / unaligned argument");
   RM_REQUIRE(K2 == 0 || A2, "rm_dense_wgrad6: K2 > 0 needs A2");
+  RM_REQUIRE(N2 == 0 || (G2 && dW2 && ldg2 >= N2 && lddw2 >= N2), "rm_dense_wgrad6: N2 > 0 needs G2 and dW2");
   RM_REQUIRE(lda1 >= K1 && (K2 == 0 || lda2 >= K2) && ldg >= N && lddw >= N,
              "rm_dense_wgrad6: a leading dimension is too small");
-  const int K = K1 + K2;
+  const int K = K1 + K2, Nt = N + N2;
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
-    if (!accumulate) (void)hipMemset2DAsync(dW, lddw * 4, 0, (size_t)N * 4, K, st);
+    if (!accumulate) {
+      (void)hipMemset2DAsync(dW, lddw * 4, 0, (size_t)N * 4, K, st);
+      if (N2) (void)hipMemset2DAsync(dW2, lddw2 * 4, 0, (size_t)N2 * 4, K, st);
+    }
     if (db) (void)hipMemsetAsync(db, 0, (size_t)N * 4, st);
     return RM_OK;
   }
-  RM_REQUIRE(workspace_floats >= rm_dense_wgrad6_workspace(K, N, M), "rm_dense_wgrad6: workspace too small");
-  const Tn6Plan p = tn6_plan(K, N, M);
+  RM_REQUIRE(workspace_floats >= rm_dense_wgrad6_workspace(K, Nt, M), "rm_dense_wgrad6: workspace too small");
+  const Tn6Plan p = tn6_plan(K, Nt, M);
   float *part = workspace;
   float *db_part = db ? workspace + (int64_t)p.nsplit * p.nkh * p.nnh * kTnKC * kTnNC : nullptr;
-  TN6Args a{A1, A2, G, lda1, lda2, ldg, K1, K2, N, M, p.nkh, p.nnh, p.nsplit, p.per, p.nslab, part, db_part};
+  TN6Args a{A1, A2, G, G2, lda1, lda2, ldg, ldg2, K1, K2, N, N2, M, p.nkh, p.nnh, p.nsplit, p.per, p.nslab, part,
+            db_part};
   const dim3 grid((unsigned)(p.nsplit * p.nkh * p.nnh));
   if (M % 32 != 0) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_tn6_kernel<true>),
@@ -723,8 +733,8 @@ extern "C" int rm_dense_wgrad6(const float *A1, int64_t lda1, int K1, const floa
                               hipFuncAttributeMaxDynamicSharedMemorySize, kTnLds);
     hipLaunchKernelGGL(dense_tn6_kernel<false>, grid, dim3(512), kTnLds, st, a);
   }
-  hipLaunchKernelGGL(dense6_tn_reduce_kernel, dim3(rm_grid_cap(((int64_t)K * N + N + 255) / 256, 2048)), dim3(256), 0,
-                     st, part, db_part, K, N, p.nkh, p.nnh, p.nsplit, dW, lddw, accumulate, db);
+  hipLaunchKernelGGL(dense6_tn_reduce_kernel, dim3(rm_grid_cap(((int64_t)K * Nt + N + 255) / 256, 2048)), dim3(256), 0,
+                     st, part, db_part, K, N, N2, p.nkh, p.nnh, p.nsplit, dW, lddw, dW2, lddw2, accumulate, db);
   RM_CHECK_LAUNCH("rm_dense_wgrad6");
   return RM_OK;
 }

@@ -235,14 +235,29 @@ class MLP:
         if getattr(self, "dense_gemm", "bf16x6") == "bf16x6":
             kmax = max(dims)
             self._fws6 = torch.empty(ops.dense6_workspace(kmax, kmax, self._B), dtype=F32, device=device)
-            self._wws6 = torch.empty(max(ops.dense_wgrad6_workspace(dims[i], dims[i + 1], self._B)
+            # (+ 16 columns: DCN rides the cross net's coefficient columns along the first layer's pass, wgrad0)
+            self._wws6 = torch.empty(max(ops.dense_wgrad6_workspace(dims[i], dims[i + 1] + 16, self._B)
                                          for i in range(len(self.hidden))), dtype=F32, device=device)
         self._wws = torch.empty(max(ww, 1), dtype=F32, device=device)
         self._wws_B = self._B
         self._ws = torch.empty(256 * 1024, dtype=F32, device=device)
         self._ones = torch.ones(self._B, dtype=F32, device=device)
 
-    def backward(self, g, dxe, fm_sum=None, lin_grads=None):
+    def wgrad0(self, G2=None, dW2=None):
+        """The first layer's weight gradient of a backward(..., defer_wgrad0=True) call, optionally with a second piece
+        of gradient columns G2 [B, N2] -> dW2 [K, N2] against the SAME x = [xe | xd] in the same pass (DCN: the cross
+        net's coefficient columns - x0 is then read once, rm_dense_wgrad6)."""
+        da, gW, db = self._deferred
+        self._deferred = None
+        ops.dense_wgrad(self.xe, self.xd if self.Dn else None, da, gW, self._wws, db=db, ws6=self._wws6, G2=G2, dW2=dW2)
+
+    def can_defer_wgrad0(self):
+        """backward(defer_wgrad0=True) + wgrad0(G2, dW2) is available: wide layers on the split-operand path, no input
+        dropout (the MLP's x is then the caller's x0 itself)."""
+        return (not self.fused_ok and getattr(self, "_wws6", None) is not None
+                and not (self.keep[0] < 1 and self.masks[0] is not None))
+
+    def backward(self, g, dxe, fm_sum=None, lin_grads=None, defer_wgrad0=False):
         """g [B] = dLoss/dlogit; writes dLoss/dxe into dxe [B,FD] and the parameter
         gradients into self.g.  (No gradient is needed for the dense inputs.)
         fm_sum [B,D]: also add the FM second-order gradient g*(S - E) (fused path only;
@@ -302,7 +317,10 @@ class MLP:
             # it rides along in the weight-gradient kernel (which stages da in LDS anyway)
             db = None if (sums and i == n - 1) else gr[f"{pre}dnn_layer_{i}_bias"]
             if i == 0:
-                ops.dense_wgrad(self.xe, self.xd if self.Dn else None, da, gW, self._wws, db=db, ws6=self._wws6)
+                if defer_wgrad0:
+                    self._deferred = (da, gW, db)
+                else:
+                    ops.dense_wgrad(self.xe, self.xd if self.Dn else None, da, gW, self._wws, db=db, ws6=self._wws6)
                 # dLoss/dxe = da W[:FD]^T (the dense inputs need no gradient)
                 ops.dense_fwd(da, None, W[: self.FD], dxe, self._fws, transposed=True, epilogue=ops.DENSE_ADD,
                               ws6=self._fws6)
@@ -1212,7 +1230,12 @@ class DCNEngine(Engine):
         p, gr = self.params, self.grads
         xe, xd = self.E.view(-1, self.FD), (dense if self.Dn else None)
         g_dnn = g if self.dnn_coef == 1.0 else g * self.dnn_coef
-        self.mlp.backward(g_dnn, self.dxe_dnn)
+        L = self.L
+        # the first dense layer's dW = x0^T dA0 and the cross net's P = x0^T coef read the same x0: one pass
+        # (rm_dense_wgrad6 with a second piece of gradient columns) once both operands exist
+        fold = (not self.matrix and L + 1 <= 16 and self.mlp.can_defer_wgrad0()
+                and self.hp.get("dcn_fold_cross_wgrad", True))
+        self.mlp.backward(g_dnn, self.dxe_dnn, defer_wgrad0=fold)
         if self.matrix:
             self._cross_matrix_bwd(g)
             self._cross_l2_grads()
@@ -1221,10 +1244,12 @@ class DCNEngine(Engine):
         # buffer: with no FM term d_rows IS dLoss/dE (no separate embed_bwd launch)
         ops.cross_bwd(p["cross_w"], p["cross_b"], p["cross_w_out"].view(-1), g,
                       self.cross_p, self.d_rows.view(-1, self.FD), self.coef, dx_in_e=self.dxe_dnn)
-        L = self.L
         # P = x0^T coef[:, :L+1]: a batch-reduction GEMM with x0 = [xe | xd] read in place, and the
         # column sums of coef in one pass (rm_linear_dense_bwd with unit weights)
-        ops.dense_wgrad(xe, xd if self.Dn else None, self.coef[:, : L + 1], self.P, self._cross_wws)
+        if fold:
+            self.mlp.wgrad0(G2=self.coef[:, : L + 1], dW2=self.P)
+        else:
+            ops.dense_wgrad(xe, xd if self.Dn else None, self.coef[:, : L + 1], self.P, self._cross_wws)
         ops.linear_dense_bwd(self._ones_b, self.coef, self._coef_sum, None, self.ws)
         colsum = self._coef_sum[L + 1:]
         ops.cross_param_grads(self.P, colsum, p["cross_w"], p["cross_b"],

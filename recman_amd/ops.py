@@ -784,9 +784,10 @@ def dense_wgrad6_workspace(K, N, M):
     return int(_lib.lib().rm_dense_wgrad6_workspace(int(K), int(N), int(M)))
 
 
-def dense_wgrad(a1, a2, G, dW, ws, accumulate=False, db=None, ws6=None):
+def dense_wgrad(a1, a2, G, dW, ws, accumulate=False, db=None, ws6=None, G2=None, dW2=None):
     """dW[K,N] (+)= [a1 | a2].T @ G (rm_dense_wgrad); db [N] = G.sum(0) when given.  ws6 (dense_wgrad6_workspace
-    floats): on the bf16 matrix pipe with split operands (rm_dense_wgrad6)."""
+    floats): on the bf16 matrix pipe with split operands (rm_dense_wgrad6); there G2 [M,N2] / dW2 [K,N2] add a second
+    piece of gradient columns to the same pass (ws6 sized for N + N2)."""
     p1, lda1, K1 = _rows2d(a1, "a1")
     p2, lda2, K2 = _rows2d(a2, "a2", allow_none=True)
     pg, ldg, N = _rows2d(G, "G")
@@ -796,9 +797,16 @@ def dense_wgrad(a1, a2, G, dW, ws, accumulate=False, db=None, ws6=None):
     pd, lddw, nd = _rows2d(dW, "dW")
     if dW.shape[0] != K1 + K2 or nd != N:
         raise ValueError(f"dW {tuple(dW.shape)} must be [{K1 + K2},{N}]")
+    if G2 is not None and ws6 is None:
+        raise ValueError("dense_wgrad: G2 needs the ws6 path")
     if ws6 is not None:
-        _lib.call("rm_dense_wgrad6", p1, lda1, K1, p2, lda2, K2, pg, ldg, N, M, pd, lddw, int(bool(accumulate)),
-                  _chk(db, "db", F32, (N,), allow_none=True), _chk(ws6, "ws6", F32), ws6.numel(), _stream())
+        pg2, ldg2, N2 = _rows2d(G2, "G2", allow_none=True)
+        pd2, lddw2, nd2 = _rows2d(dW2, "dW2", allow_none=True)
+        if G2 is not None and (G2.shape[0] != M or dW2 is None or dW2.shape[0] != K1 + K2 or nd2 != N2):
+            raise ValueError("dense_wgrad: G2 / dW2 shape mismatch")
+        _lib.call("rm_dense_wgrad6", p1, lda1, K1, p2, lda2, K2, pg, ldg, N, pg2, ldg2, N2, M, pd, lddw, pd2, lddw2,
+                  int(bool(accumulate)), _chk(db, "db", F32, (N,), allow_none=True), _chk(ws6, "ws6", F32),
+                  ws6.numel(), _stream())
         return
     _lib.call("rm_dense_wgrad", p1, lda1, K1, p2, lda2, K2, pg, ldg, N, M, pd, lddw, int(bool(accumulate)),
               _chk(db, "db", F32, (N,), allow_none=True), _chk(ws, "ws", F32), ws.numel(), _stream())

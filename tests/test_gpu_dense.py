@@ -317,3 +317,14 @@ def test_dense_wgrad6_split_operands(hip_lib, M, K1, K2, N):
     ops.dense_wgrad(a1d, a2d, G.cuda(), acc[:, :N], ws, accumulate=True, ws6=ws6)
     _close(acc[:, :N], want + base[:, :N].cpu().double(), tol=tol, what="accumulate")
     assert torch.equal(acc[:, N:], base[:, N:])
+    # a second piece of gradient columns against the same activations in the same pass (DCN's cross coefficients)
+    N2 = 7
+    G2full = torch.randn(M, 2 * N2 + 2, generator=g)
+    ws62 = torch.empty(ops.dense_wgrad6_workspace(K, N + N2, M), device="cuda")
+    dW2 = torch.full((K, N2), float("nan"), device="cuda")
+    dW.fill_(float("nan"))
+    db.fill_(float("nan"))
+    ops.dense_wgrad(a1d, a2d, G.cuda(), dW, ws, db=db, ws6=ws62, G2=G2full.cuda()[:, :N2], dW2=dW2)
+    _close(dW, want, tol=tol, what="dW beside a second piece")
+    _close(dW2, x.t() @ G2full[:, :N2].double(), tol=tol, what="dW2")
+    _close(db, G.double().sum(0), tol=tol, what="db beside a second piece")
