@@ -167,8 +167,19 @@ __global__ __launch_bounds__(kThreads6, kWaves6 == 4 ? 2 : 1) void dense_nn6_ker
   // requests, with a ring of 2 this slab's own LDS-DMA pieces too (only the 4 row loads behind them may remain)
   constexpr int kVmPerSlab = kRing6 == 3 ? kDmaPerWave + 4 : 4;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int g = blockIdx.x % a.ngroups;
-  const int64_t row0 = (int64_t)(blockIdx.x / a.ngroups) * kRows6 + 32 * w;
+  // blockIdx -> (row tile, column group): consecutive workgroups go round-robin to the 8 XCDs (each its own L2);
+  // the column groups of ONE row tile are 8 blocks apart - the same XCD, dispatched together - so that the second
+  // reader of the A tile finds it in that L2 (tile * ngroups + g put them on two XCDs: 711 MB of HBM traffic for
+  // 436 MB of operands).  Super-groups of 8 tiles x ngroups; a ragged last super-group falls back to the plain map.
+  int g;
+  int64_t tile;
+  {
+    const int64_t per = 8 * (int64_t)a.ngroups, sg = blockIdx.x / per, in = blockIdx.x % per;
+    const int64_t ntiles = (a.M + kRows6 - 1) / kRows6;
+    if ((sg + 1) * 8 <= ntiles) { g = (int)(in / 8); tile = sg * 8 + in % 8; }
+    else { const int64_t rest = blockIdx.x - sg * per; g = (int)(rest % a.ngroups); tile = sg * 8 + rest / a.ngroups; }
+  }
+  const int64_t row0 = tile * kRows6 + 32 * w;
   const int r = lane & 15, q = lane >> 4;
   const unsigned char *Wg = reinterpret_cast<const unsigned char *>(a.Wp) + (int64_t)g * (a.nslab + 2) * kSlabBytes;
 
