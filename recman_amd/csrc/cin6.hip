@@ -585,7 +585,15 @@ __global__ __launch_bounds__(64 * kDwWaves, kDwWaves == 4 ? 2 : 1) void cin_dw6_
   extern __shared__ __attribute__((aligned(16))) unsigned char smemc6[];  // [2][kDwBuf]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, w = wv & 3, r = lane & 15, q = lane >> 4;
   const int D = a.D, H = 32 * NH;  // (the padded width; a.H is the real one)
-  const int grp = blockIdx.x % a.ngroups, sp = blockIdx.x / a.ngroups;
+  // blockIdx -> (field group, row split): the field groups of ONE row split - they stream the same dM rows at about
+  // the same pace - are 8 blocks apart, i.e. on the same XCD (consecutive workgroups go round-robin to the 8 XCDs,
+  // each with its own L2): dM comes from HBM about once instead of once per field group
+  int grp, sp;
+  {
+    const int per = 8 * a.ngroups, sg = blockIdx.x / per, in = blockIdx.x % per;
+    if ((sg + 1) * 8 <= a.nsplit) { grp = in / 8; sp = sg * 8 + in % 8; }
+    else { const int rest = blockIdx.x - sg * per; grp = rest % a.ngroups; sp = sg * 8 + rest / a.ngroups; }
+  }
   const int i0 = kDwFields * grp + kDwI * (wv >> 2);
   const int64_t rows_total = a.B * D;
   constexpr int JW = NH * 2 / 4 > 0 ? NH * 2 / 4 : 1;  // 16-j tiles per wave: H = 64 -> 1, H = 32 -> waves 2, 3 idle
