@@ -503,10 +503,15 @@ __global__ __launch_bounds__(512) void dense_tn6_kernel(TN6Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  int bid = blockIdx.x;
-  const int nh = bid % a.nnh; bid /= a.nnh;
-  const int kh = bid % a.nkh;
-  const int sp = bid / a.nkh;
+  // blockIdx -> (output tile, batch split): the nkh x nnh tiles of ONE split read the same rows of A and G; they
+  // are put 8 blocks apart = on the same XCD (round-robin placement), so those rows come from HBM about once
+  int tile_id, sp;
+  {
+    const int nt = a.nkh * a.nnh, per = 8 * nt, sg = blockIdx.x / per, in = blockIdx.x % per;
+    if ((sg + 1) * 8 <= a.nsplit) { tile_id = in / 8; sp = sg * 8 + in % 8; }
+    else { const int rest = blockIdx.x - sg * per; tile_id = rest % nt; sp = sg * 8 + rest / nt; }
+  }
+  const int nh = tile_id % a.nnh, kh = tile_id / a.nnh;
   const int K = a.K1 + a.K2;
   const int kcol0 = kTnKC * kh, ncol0 = kTnNC * nh;
 
