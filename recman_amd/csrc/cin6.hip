@@ -16,7 +16,8 @@
 // its registers for the whole block; X0's 128 x m tile sits in LDS (one value per row tile and slab).  The filter
 // streams by LDS-DMA into two slab buffers, one raw barrier per slab; the next slab's products and split run between
 // this slab's MFMAs.  Z is the MFMA's A operand: a lane ends with 4 consecutive d of one filter n - with D = 16 a
-// 16 x 16 tile is ONE contiguous KiB of out[b, 16 j .. 16 j + 15, :].
+// 16 x 16 tile is ONE contiguous KiB of out[b, 16 j .. 16 j + 15, :].  (The same kernel on v_mfma_f32_32x32x16_bf16 -
+// half the MFMA instructions for the same matrix work, one row per lane - took 2.20 ms against 2.03 ms.)
 #include <type_traits>
 
 #include "rm_common.h"
