@@ -648,8 +648,13 @@ def measure(a, wname, dev, rank, world, dist, rehearse, sharded, live_traffic, f
                    "rows_per_field": V,
                    "dense_fields": w["Dn"], "emb_dim": w["D"], "hp": {k: v for k, v in w["hp"].items()},
                    "indices": "uniform" if zipf == 0 else f"zipf({zipf})",
-                   "table_row_loads": ("cached" if hp["table_row_reuse"] == "cache"
-                                       else "non-temporal (ids with little reuse per batch)"),
+                   "table_row_loads": (
+                       # DeepFM's one-kernel step (rm_deepfm_step) has its own switch, hp step_row_loads: cached by
+                       # default (non-temporal row loads measured slower there, profiles/r03_deepfm_step.md)
+                       ("cached" if hp.get("step_row_loads", "cache") == "cache" else "non-temporal")
+                       + " (rm_deepfm_step)" if getattr(engine, "_step_ok", None) is True
+                       else ("cached" if hp["table_row_reuse"] == "cache"
+                             else "non-temporal (ids with little reuse per batch)")),
                    "row_gradient_stores": ("cached (as in fit(): the optimizer step gathers them next)"
                                            if hp["d_rows_reuse"] == "cache" else "non-temporal"),
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
