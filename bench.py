@@ -658,6 +658,16 @@ def measure(a, wname, dev, rank, world, dist, rehearse, sharded, live_traffic, f
                    "row_gradient_stores": ("cached (as in fit(): the optimizer step gathers them next)"
                                            if hp["d_rows_reuse"] == "cache" else "non-temporal"),
                    "embedding_l2_reg": 0.0, "dropout_keep": 1.0, "optimizer_step": "excluded",
+                   # how the GEMM-shaped kernels of this workload multiply: fp32 in, fp32 out, fp32
+                   # accumulate everywhere; the wide dense layers and CIN form every fp32 product from three bf16
+                   # pieces per operand on the bf16 matrix pipe (six exact piece products, error at fp32 level:
+                   # `parity_check` beside this record is measured on THIS path)
+                   "matrix_arithmetic": ({"dcn": "fp32 operands split into 3 bf16 pieces, 6 exact piece products per "
+                                                 "k-step on the bf16 MFMA, fp32 accumulate (rm_dense_fwd6 / rm_dense_wgrad6)",
+                                          "xdeepfm": "CIN: fp32 operands split into 3 bf16 pieces, 6 exact piece products "
+                                                     "per k-step on the bf16 MFMA, fp32 accumulate (csrc/cin6.hip; the "
+                                                     "first layer's dW and the skinny DNN: f32 MFMA)"}.get(wname,
+                                         "f32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate")),
                    "host_enqueue_ms_per_step": round(enq_ms, 4), "batches_rotated": rotation or 1,
                    "prewarm_s": a.prewarm, "hipgraph": graph_kind,
                    "table": (f"row-sharded mod {world}, fused [D+4] rows, all_to_all over xGMI, "
